@@ -1,0 +1,130 @@
+"""Pin oracle/ to the golden vectors captured from the imported reference
+(tests/golden/make_golden.py).  CPU only."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pcgnn_oracle as O
+from tests.util import GOLDEN, PARAM_KEYS, GoldenCase
+
+CASES = ["yelp_small", "amazon_small", "single_rel"]
+FTOL = 2e-6   # float outputs: oracle vs reference (different sgemm column order only)
+
+
+@pytest.fixture(scope="module", params=CASES)
+def case(request):
+    return GoldenCase(request.param)
+
+
+def _model(c, rho, dense=True):
+    return O.OraclePCGNN(torch.from_numpy(c.X), c.adj_lists(), c.train_pos, c.params(), rho, c.alpha,
+                         dense_mask=dense)
+
+
+def test_kat_choose():
+    z = np.load(os.path.join(GOLDEN, "kat.npz"))
+    got = O.choose_row(torch.tensor(float(z["kat1_center"])), z["kat1_ids"].tolist(),
+                       torch.tensor(z["kat1_s0"], dtype=torch.float32), int(z["kat1_k"]))
+    assert sorted(got) == z["kat1_out"].tolist() == [11, 12, 14]
+    for rho in (0.2, 0.5, 0.8, 2.0, 3.5):
+        k = int(z["kat2_k"])
+        got = O.choose_row(torch.tensor(float(z["kat2_center"])), z["kat2_ids"].tolist(),
+                           torch.tensor(z["kat2_s0"], dtype=torch.float32), k,
+                           (z["kat2_pos_ids"].tolist(), torch.tensor(z["kat2_pos_s0"], dtype=torch.float32),
+                            int(k * rho)))
+        assert sorted(got) == z[f"kat2_out_rho{rho}"].tolist()
+    for deg, kept in zip(z["kat3_deg"].tolist(), z["kat3_kept"].tolist()):
+        k = O.sample_count(deg, 0.5)
+        got = O.choose_row(torch.tensor(0.0), list(range(100, 100 + deg)), torch.linspace(0.1, 1.0, deg), k)
+        assert len(got) == kept
+
+
+def test_pick_matches_reference(case):
+    c = case
+    idx_train = c.z["idx_train"].tolist()
+    y_train = c.labels[np.array(idx_train)]
+    homo = c.adj(None)
+    w = O.pick_weights(idx_train, y_train, homo)
+    cum = O.pick_cum_weights(w)
+    got = O.pick_from_uniforms(idx_train, cum, c.z["pick_uniforms"].tolist())
+    assert got == c.z["pick_out"].tolist()
+    # and through random.choices itself with the generator's seed
+    seed = {"yelp_small": 3, "amazon_small": 5, "single_rel": 9}[c.name]
+    assert O.pick_step(idx_train, y_train, homo, len(got), random.Random(seed)) == got
+
+
+def test_table_scores(case):
+    c = case
+    W, b = c.params()["inter1.label_clf.weight"], c.params()["inter1.label_clf.bias"]
+    got = torch.nn.functional.linear(torch.from_numpy(c.X), W, b).numpy()
+    np.testing.assert_allclose(got, c.z["table_scores"], rtol=0, atol=FTOL)
+
+
+def test_forward_sets_and_logits(case):
+    c = case
+    for rho in c.rhos:
+        m = _model(c, rho)
+        logits, cs = m.forward(c.nodes, c.batch_labels, True)
+        key = f"rho{rho}_train"
+        for r in range(c.R):
+            assert m.last_sets[r] == c.sel(key, r), f"{c.name} rho={rho} relation {r}: chosen sets differ"
+        np.testing.assert_allclose(logits.detach().numpy(), c.z[key + "_logits"], rtol=0, atol=FTOL)
+        np.testing.assert_allclose(cs.detach().numpy(), c.z[key + "_center_scores"], rtol=0, atol=FTOL)
+    # inference mode (choose_step_test)
+    m = _model(c, c.rhos[0])
+    logits, _ = m.forward(c.nodes, c.batch_labels, False)
+    for r in range(c.R):
+        assert m.last_sets[r] == c.sel("test", r)
+        np.testing.assert_allclose(m.last_feats[r + 1].detach().numpy(), c.z[f"test_feats{r}"], rtol=0, atol=FTOL)
+    np.testing.assert_allclose(logits.detach().numpy(), c.z["test_logits"], rtol=0, atol=FTOL)
+    np.testing.assert_allclose(m.last_combined.detach().numpy(), c.z["test_combined"], rtol=0, atol=FTOL)
+    gp, _ = m.to_prob(c.nodes, c.batch_labels, False)
+    np.testing.assert_allclose(gp.detach().numpy(), c.z["test_gnn_prob"], rtol=0, atol=FTOL)
+
+
+def test_sparse_equals_dense_aggregate(case):
+    c = case
+    sets = c.sel("test", 0)
+    X = torch.from_numpy(c.X)
+    np.testing.assert_allclose(O.sparse_aggregate(sets, X).numpy(), O.dense_mask_aggregate(sets, X).numpy(),
+                               rtol=0, atol=FTOL)
+
+
+def test_loss_grads_adam(case):
+    c = case
+    rho = c.rhos[0]
+    tag = f"rho{rho}"
+    m = _model(c, rho)
+    opt = O.make_adam(m, c.lr, c.wd)
+    opt.zero_grad()
+    loss = m.loss(c.nodes, c.batch_labels)
+    loss.backward()
+    assert abs(loss.item() - float(c.z[tag + "_loss"])) < FTOL
+    for k in PARAM_KEYS(c.R):
+        np.testing.assert_allclose(m.p[k].grad.numpy(), c.z[f"{tag}_grad_{k}"], rtol=0, atol=FTOL, err_msg=k)
+    opt.step()
+    for k in PARAM_KEYS(c.R):
+        # Adam's first step moves every weight by ~lr*sign(g): where |g| ~ eps the
+        # step is ill-conditioned, so compare with a tolerance scaled by lr
+        np.testing.assert_allclose(m.p[k].detach().numpy(), c.z[f"{tag}_step_{k}"], rtol=0, atol=c.lr * 2e-2,
+                                   err_msg=k)
+    for rho in c.rhos[1:]:
+        m = _model(c, rho)
+        assert abs(float(m.loss(c.nodes, c.batch_labels)) - float(c.z[f"rho{rho}_loss"])) < FTOL
+
+
+def test_graphsage_aggregators(case):
+    c = case
+    X = torch.from_numpy(c.X)
+    homo = c.adj(None)
+    sub = c.z["s1_nodes"].tolist()
+    np.testing.assert_allclose(O.sage_mean(sub, homo, X).numpy(), c.z["s1_mean"], rtol=0, atol=FTOL)
+    np.testing.assert_allclose(O.sage_mean(sub, homo, X, gcn=True).numpy(), c.z["s1_mean_gcn"], rtol=0, atol=FTOL)
+    np.testing.assert_allclose(O.gcn_mean(sub, homo, X).numpy(), c.z["s1_gcn"], rtol=0, atol=FTOL)
+    enc = O.encoder_forward(O.sage_mean(sub, homo, X, gcn=True), None, torch.from_numpy(c.z["s1_sage_enc_w"]))
+    np.testing.assert_allclose(enc.numpy(), c.z["s1_sage_enc"], rtol=0, atol=FTOL)
+    enc = O.encoder_forward(O.gcn_mean(sub, homo, X), None, torch.from_numpy(c.z["s1_gcn_enc_w"]))
+    np.testing.assert_allclose(enc.numpy(), c.z["s1_gcn_enc"], rtol=0, atol=5e-6)
