@@ -1,0 +1,159 @@
+/*
+ * pcgnn.h - C ABI of libpcgnn_hip.so: the MI355X (gfx950) PC-GNN hot path.
+ *
+ * The reference (h22hyeon/PC-GNN) is 100 % Python and has no FFI of its own; its
+ * "plugin API" for this path is the forward() of PCALayer / InterAgg* / IntraAgg
+ * and pick_step().  This header is what a ctypes binding inside those methods
+ * calls instead of the Python set / torch.sort / dense-mask code.  Each entry
+ * point names the reference lines it replaces (paths relative to the
+ * reference root).  INTEGRATION.md shows the reference-side ctypes stub.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer owned by the caller (e.g. a torch tensor
+ *     that outlives the call) unless the parameter is documented "host";
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*); no entry point
+ *     synchronises the stream, allocates, or frees device memory;
+ *   - return value: 0 = enqueued, <0 = rejected before anything was enqueued
+ *     (PCG_E_*).  Conditions only knowable on the device (a selection buffer
+ *     too small) are reported through the caller-provided `status` word;
+ *   - one host thread per device; re-entrant across devices.
+ *
+ * Data layout in HBM (built once per graph, resident for the whole run - mirrors
+ * the frozen nn.Embedding + adj_lists the reference keeps, model_handler.py:85-87):
+ *   X          float  [n_nodes, feat_stride]  row-major, feat_stride % 4 == 0,
+ *                     columns feat_dim..feat_stride-1 are zero, 16-byte aligned
+ *   indptr[r]  int64  [n_nodes + 1]           CSR row offsets of relation r
+ *   indices[r] int32  [nnz_r]                 neighbour ids, ASCENDING inside a row,
+ *                                             self-loops kept (utils.py:226-239)
+ *   train_pos  int32  [n_pos]                 ids of training positives, no duplicates
+ */
+#ifndef PCGNN_H
+#define PCGNN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCG_MAX_REL 8
+
+enum {
+    PCG_OK = 0,
+    PCG_E_ARG = -1,        /* null / misaligned pointer, bad size                   */
+    PCG_E_UNSUPPORTED = -2,/* shape outside what the kernels handle                 */
+    PCG_E_LAUNCH = -3      /* hipLaunchKernel reported an error                     */
+};
+
+/* bits of the device-side status word */
+enum {
+    PCG_ST_SEL_OVERFLOW = 1   /* sel_indices capacity too small; nothing was written past it */
+};
+
+enum { PCG_NORM_COUNT = 0, PCG_NORM_SQRT_COUNT = 1 };
+
+typedef struct pcg_graph_desc {
+    int64_t n_nodes;
+    int32_t feat_dim;
+    int32_t feat_stride;
+    int32_t n_rel;
+    int32_t n_pos;
+    int32_t max_degree;                 /* max over relations and rows (host-computed) */
+    int32_t _pad;
+    const float *X;
+    const int32_t *train_pos;
+    const int64_t *indptr[PCG_MAX_REL];
+    const int32_t *indices[PCG_MAX_REL];
+} pcg_graph_desc;
+
+/* library / build identification: "pcgnn_hip gfx950 <abi>" (host pointer, static) */
+const char *pcg_version(void);
+int pcg_abi_version(void);
+
+/* ---- label-aware scores -------------------------------------------------------
+ * Replaces  batch_scores = self.label_clf(self.features(unique_nodes))
+ *           (src/layers.py:230-237) by scoring the whole table once per step.
+ * s0[i] = b[0] + sum_f X[i,f] * W[0,f]   (class-0 logit; the only column the
+ * choose step reads, layers.py:649-650).  W is label_clf.weight [2, feat_dim]
+ * row-major, b is label_clf.bias [2].  Rows [row_begin, row_end). */
+int pcg_score_table(const pcg_graph_desc *g, const float *W, const float *b,
+                    int64_t row_begin, int64_t row_end, float *s0, void *stream);
+
+/* center_scores = batch_scores[nodes]  (layers.py:243): both logits of the given
+ * rows, bit-identical in column 0 to pcg_score_table.  out is [n_ids, 2]. */
+int pcg_score_rows(const pcg_graph_desc *g, const float *W, const float *b,
+                   const int32_t *ids, int32_t n_ids, float *out, void *stream);
+
+/* Sort the training positives by class-0 logit once per step; replaces the
+ * per-centre torch.sort over all of pos_scores (layers.py:683-688).
+ * keys [pcg_pos_sort_capacity(n_pos)] uint64: (orderable(s0[train_pos[p]]) << 32) | p,
+ * ascending, padded with UINT64_MAX. */
+int64_t pcg_pos_sort_capacity(int32_t n_pos);
+int pcg_pos_sort(const pcg_graph_desc *g, const float *s0, uint64_t *keys, void *stream);
+
+/* ---- choose + aggregate (the hot kernel) ---------------------------------------
+ * Replaces, for every relation r and batch centre b:
+ *   neighbour lookup + score slicing            layers.py:217-219, 246-253
+ *   num_sample = ceil(deg * threshold[r])        layers.py:260-262
+ *   choose_step_neighs / choose_step_test        layers.py:633-738
+ *   dense-mask mean  mask.div(n).mm(X[unique])   layers.py:594-624
+ * Selection rule: if deg > k+1 keep the k neighbours with the smallest
+ * |s0[centre] - s0[j]|, ties by ascending position in the (ascending-id) row;
+ * else keep all.  If train_flag and labels[b]==1 additionally take the
+ * m = min(int(k*rho[r]), n_pos) training positives nearest in the same metric, ties
+ * by position in train_pos; the union is de-duplicated (set(), layers.py:694).
+ *
+ *   nodes   int32 [B]   batch centre ids (duplicates allowed)
+ *   labels  int32 [B]   batch labels; may be NULL when train_flag == 0
+ *   s0      float [n_nodes] from pcg_score_table;  pos_keys from pcg_pos_sort
+ *   center_s0 float [B] or NULL: the centres' class-0 logits if they are not to be
+ *           read from s0[nodes[b]] (IntraAgg.forward called with explicit
+ *           batch_scores, layers.py:562)
+ *   agg     float [n_rel, B, agg_stride]  mean of the chosen rows (cols < feat_dim)
+ *   cnt     int32 [n_rel, B] or NULL      |chosen set|
+ * Optional materialisation of the chosen index sets (parity tests, callers that
+ * want samp_neighs): sel_begin int64 [n_rel*B] (start of row (r,b) inside
+ * sel_indices, caller-computed upper-bound layout, see pcg_sel_capacity_row),
+ * sel_indices int32 [sel_capacity]; pass NULL/NULL/0 to skip.
+ *   workspace: pcg_choose_workspace_bytes(g, B) bytes, 256-byte aligned.
+ *   status   : uint32 device word, OR-ed with PCG_ST_* bits (zero it yourself). */
+int64_t pcg_choose_workspace_bytes(const pcg_graph_desc *g, int32_t B);
+int pcg_choose_aggregate(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B,
+                         const float *s0, const float *center_s0, const uint64_t *pos_keys,
+                         const double *thresholds /* host [n_rel] */, const double *rho /* host [n_rel] */,
+                         int32_t train_flag,
+                         int32_t norm, int32_t add_self,
+                         float *agg, int32_t agg_stride, int32_t *cnt,
+                         const int64_t *sel_begin, int32_t *sel_indices, int64_t sel_capacity,
+                         void *workspace, uint32_t *status, void *stream);
+
+/* Upper bound on |chosen set| of one row, what the caller lays sel_begin out with
+ * (host helper, pure arithmetic): (deg > k+1 ? k : deg) + m [+1 if add_self]. */
+int64_t pcg_sel_capacity_row(int64_t deg, double threshold, double rho, int32_t positive_train,
+                             int32_t n_pos, int32_t add_self);
+
+/* ---- segmented mean over explicit index lists -----------------------------------
+ * out[i,:] = sum_{j in idx[begin[i] .. begin[i]+count[i])} X[j,:] / norm(count[i])
+ * Replaces mask.div(num_neigh).mm(embed_matrix) for a given samp_neighs
+ * (layers.py:599-624; graphsage.py:82-95 and, with PCG_NORM_SQRT_COUNT, 216-231). */
+int pcg_segment_mean(const pcg_graph_desc *g, const int64_t *begin, const int32_t *count,
+                     const int32_t *idx, int32_t n_rows, int32_t norm,
+                     float *out, int32_t out_stride, void *stream);
+
+/* ---- pick (label-balanced sampler) ------------------------------------------------
+ * Replaces random.choices(idx_train, weights=deg/LF, k) (src/utils.py:274-278):
+ * out[i] = idx_train[bisect_right(cum, u[i] * cum[n-1], 0, n-1)].
+ * cum is the sequential fp64 running sum of the weights (host-computed once, it
+ * is epoch-invariant).  uniforms: fp64 [k] in [0,1); if NULL they are drawn on
+ * the device from Philox4x32-10(seed, counter = draw index). */
+int pcg_pick(const double *cum, const int32_t *idx_train, int32_t n_train,
+             const double *uniforms, uint64_t seed, uint64_t epoch, int32_t k, int32_t *out, void *stream);
+
+/* gather rows: out[i, :feat_dim] = X[ids[i], :feat_dim]  (self_feats, layers.py:273-277) */
+int pcg_gather_rows(const pcg_graph_desc *g, const int32_t *ids, int32_t n_ids,
+                    float *out, int32_t out_stride, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCGNN_H */

@@ -1,0 +1,91 @@
+"""ctypes binding of libpcgnn_hip.so (the C ABI in include/pcgnn.h).
+
+There is NO fallback: if the library is missing or an entry point is absent the
+import of the product path raises.  Build it with ``python -m pcgnn_amd.build``
+(or ``__graft_entry__.build()``).
+"""
+import ctypes as C
+import os
+
+from .build import lib_path
+
+PCG_MAX_REL = 8
+PCG_OK, PCG_E_ARG, PCG_E_UNSUPPORTED, PCG_E_LAUNCH = 0, -1, -2, -3
+PCG_ST_SEL_OVERFLOW = 1
+PCG_NORM_COUNT, PCG_NORM_SQRT_COUNT = 0, 1
+ABI_VERSION = 1
+
+
+class GraphDesc(C.Structure):
+    _fields_ = [
+        ("n_nodes", C.c_int64),
+        ("feat_dim", C.c_int32),
+        ("feat_stride", C.c_int32),
+        ("n_rel", C.c_int32),
+        ("n_pos", C.c_int32),
+        ("max_degree", C.c_int32),
+        ("_pad", C.c_int32),
+        ("X", C.c_void_p),
+        ("train_pos", C.c_void_p),
+        ("indptr", C.c_void_p * PCG_MAX_REL),
+        ("indices", C.c_void_p * PCG_MAX_REL),
+    ]
+
+
+_P, _I32, _I64, _U64, _F64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double
+_G = C.POINTER(GraphDesc)
+
+# name -> (restype, argtypes); must list every symbol include/pcgnn.h declares
+PROTOTYPES = {
+    "pcg_version": (C.c_char_p, []),
+    "pcg_abi_version": (C.c_int, []),
+    "pcg_score_table": (C.c_int, [_G, _P, _P, _I64, _I64, _P, _P]),
+    "pcg_score_rows": (C.c_int, [_G, _P, _P, _P, _I32, _P, _P]),
+    "pcg_pos_sort_capacity": (_I64, [_I32]),
+    "pcg_pos_sort": (C.c_int, [_G, _P, _P, _P]),
+    "pcg_choose_workspace_bytes": (_I64, [_G, _I32]),
+    "pcg_choose_aggregate": (C.c_int, [_G, _P, _P, _I32, _P, _P, _P, C.POINTER(_F64), C.POINTER(_F64), _I32, _I32, _I32,
+                                       _P, _I32, _P, _P, _P, _I64, _P, _P, _P]),
+    "pcg_sel_capacity_row": (_I64, [_I64, _F64, _F64, _I32, _I32, _I32]),
+    "pcg_segment_mean": (C.c_int, [_G, _P, _P, _P, _I32, _I32, _P, _I32, _P]),
+    "pcg_pick": (C.c_int, [_P, _P, _I32, _P, _U64, _U64, _I32, _P, _P]),
+    "pcg_gather_rows": (C.c_int, [_G, _P, _I32, _P, _I32, _P]),
+}
+
+_lib = None
+
+
+class PcgnnLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library once; raise (never fall back) if that fails."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise PcgnnLibraryError(
+            f"{path} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` (needs hipcc). There is no CPU fallback for the product path.")
+    lib = C.CDLL(path)
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise PcgnnLibraryError(f"{path} does not export {name}: stale build? rebuild it") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.pcg_abi_version() != ABI_VERSION:
+        raise PcgnnLibraryError(f"{path}: ABI {lib.pcg_abi_version()} != expected {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+_ERR = {PCG_E_ARG: "bad argument", PCG_E_UNSUPPORTED: "unsupported shape", PCG_E_LAUNCH: "kernel launch failed"}
+
+
+def check(rc, what):
+    if rc != PCG_OK:
+        raise PcgnnLibraryError(f"{what} failed: {_ERR.get(rc, rc)} ({rc})")

@@ -1,0 +1,73 @@
+// Shared device helpers for the gfx950 PC-GNN kernels (wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pcgnn.h"
+
+#define PCG_WAVE 64
+
+#define PCG_LAUNCH_CHECK()                                   \
+    do {                                                     \
+        if (hipGetLastError() != hipSuccess) return PCG_E_LAUNCH; \
+    } while (0)
+
+namespace pcg {
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (PCG_WAVE - 1); }
+
+__device__ __forceinline__ uint64_t lanemask_lt() {
+    return (1ull << lane_id()) - 1ull;
+}
+
+// number of lanes in the wave for which pred holds (wave-uniform result)
+__device__ __forceinline__ int wave_count(bool pred) { return __popcll(__ballot(pred)); }
+
+// |c - s| as an unsigned key: for non-negative floats the bit pattern orders like the value.
+__device__ __forceinline__ uint32_t dist_key(float c, float s) { return __float_as_uint(fabsf(c - s)); }
+
+// total order on floats as uint32 (negative < positive), used for the train-pos sort
+__device__ __forceinline__ uint32_t orderable(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float from_orderable(uint32_t k) {
+    uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+
+// lanes-per-row for a row of `stride` floats read as float4: power of two in [8, 64]
+__host__ __device__ __forceinline__ int lanes_per_row(int stride) {
+    int q = stride >> 2;
+    int l = 8;
+    while (l < q && l < 64) l <<= 1;
+    return l;
+}
+
+// Partial dot of one feature row with a weight vector, in a fixed order: lane `sub`
+// of `lpr` walks float4 chunks sub, sub+lpr, ...; inside a chunk a 4-long fma chain.
+// The cross-lane butterfly that finishes it is in score_reduce().  Both score
+// kernels use exactly these two functions, so their column 0 agrees bit for bit.
+__device__ __forceinline__ float score_partial(const float *__restrict__ xrow, const float *__restrict__ w,
+                                               int feat_dim, int stride, int sub, int lpr) {
+    float p = 0.f;
+    for (int ch = sub; ch < (stride >> 2); ch += lpr) {
+        const float4 x = *reinterpret_cast<const float4 *>(xrow + 4 * ch);
+        const int f = 4 * ch;
+        const float w0 = (f + 0 < feat_dim) ? w[f + 0] : 0.f;
+        const float w1 = (f + 1 < feat_dim) ? w[f + 1] : 0.f;
+        const float w2 = (f + 2 < feat_dim) ? w[f + 2] : 0.f;
+        const float w3 = (f + 3 < feat_dim) ? w[f + 3] : 0.f;
+        p = fmaf(x.x, w0, p);
+        p = fmaf(x.y, w1, p);
+        p = fmaf(x.z, w2, p);
+        p = fmaf(x.w, w3, p);
+    }
+    return p;
+}
+__device__ __forceinline__ float score_reduce(float p, int lpr) {
+    for (int o = 1; o < lpr; o <<= 1) p += __shfl_xor(p, o);
+    return p;
+}
+
+}  // namespace pcg

@@ -1,0 +1,105 @@
+// Per-step sort of the training positives by class-0 logit.
+// Replaces the per-centre torch.sort over all pos_scores (src/layers.py:683-688):
+// sorted once, every positive centre then finds its m nearest by a window search.
+// Keys are unique 64-bit (orderable(score) << 32 | position in train_pos), so the
+// bitonic network's result is a total order: equal scores stay in list order.
+#include "common.h"
+
+namespace pcg {
+
+constexpr int SORT_CHUNK = 4096;    // keys sorted per workgroup in LDS (32 KiB)
+constexpr int SORT_THREADS = 1024;
+
+__device__ __forceinline__ uint64_t make_pos_key(const float *s0, const int32_t *train_pos, int i, int n_pos) {
+    if (i >= n_pos) return ~0ull;
+    return ((uint64_t)orderable(s0[train_pos[i]]) << 32) | (uint32_t)i;
+}
+
+__device__ __forceinline__ void cmp_swap(uint64_t &a, uint64_t &b, bool ascending) {
+    if ((a > b) == ascending) {
+        const uint64_t t = a;
+        a = b;
+        b = t;
+    }
+}
+
+// LDS bitonic steps j = j_start .. 1 of merge size k on this block's chunk
+__device__ __forceinline__ void lds_steps(uint64_t *sh, int chunk_base, int k, int j_start) {
+    for (int j = j_start; j > 0; j >>= 1) {
+        for (int p = threadIdx.x; p < SORT_CHUNK / 2; p += SORT_THREADS) {
+            const int i = 2 * j * (p / j) + (p % j);
+            const bool asc = (((chunk_base + i) & k) == 0);
+            cmp_swap(sh[i], sh[i + j], asc);
+        }
+        __syncthreads();
+    }
+}
+
+// build the keys and fully sort each SORT_CHUNK-sized chunk (alternating directions)
+__global__ void __launch_bounds__(SORT_THREADS) pos_sort_local(const float *__restrict__ s0,
+                                                               const int32_t *__restrict__ train_pos, int n_pos,
+                                                               uint64_t *__restrict__ keys) {
+    __shared__ uint64_t sh[SORT_CHUNK];
+    const int base = blockIdx.x * SORT_CHUNK;
+    for (int t = threadIdx.x; t < SORT_CHUNK; t += SORT_THREADS) sh[t] = make_pos_key(s0, train_pos, base + t, n_pos);
+    __syncthreads();
+    for (int k = 2; k <= SORT_CHUNK; k <<= 1) lds_steps(sh, base, k, k >> 1);
+    for (int t = threadIdx.x; t < SORT_CHUNK; t += SORT_THREADS) keys[base + t] = sh[t];
+}
+
+__global__ void __launch_bounds__(256) bitonic_global_step(uint64_t *__restrict__ keys, int64_t n_pairs, int j, int k) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    const int64_t i = 2 * (int64_t)j * (p / j) + (p % j);
+    uint64_t a = keys[i], b = keys[i + j];
+    const bool asc = ((i & k) == 0);
+    if ((a > b) == asc) {
+        keys[i] = b;
+        keys[i + j] = a;
+    }
+}
+
+__global__ void __launch_bounds__(SORT_THREADS) bitonic_local_merge(uint64_t *__restrict__ keys, int k) {
+    __shared__ uint64_t sh[SORT_CHUNK];
+    const int base = blockIdx.x * SORT_CHUNK;
+    for (int t = threadIdx.x; t < SORT_CHUNK; t += SORT_THREADS) sh[t] = keys[base + t];
+    __syncthreads();
+    lds_steps(sh, base, k, SORT_CHUNK >> 1);
+    for (int t = threadIdx.x; t < SORT_CHUNK; t += SORT_THREADS) keys[base + t] = sh[t];
+}
+
+static int64_t sort_capacity(int32_t n_pos) {
+    int64_t c = SORT_CHUNK;
+    while (c < n_pos) c <<= 1;
+    return c;
+}
+
+}  // namespace pcg
+
+extern "C" {
+
+int64_t pcg_pos_sort_capacity(int32_t n_pos) { return n_pos < 0 ? PCG_E_ARG : pcg::sort_capacity(n_pos); }
+
+int pcg_pos_sort(const pcg_graph_desc *g, const float *s0, uint64_t *keys, void *stream) {
+    if (!g || !s0 || !keys || g->n_pos < 0 || (g->n_pos > 0 && !g->train_pos)) return PCG_E_ARG;
+    if (g->n_pos == 0) return PCG_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t cap = pcg::sort_capacity(g->n_pos);
+    const int chunks = (int)(cap / pcg::SORT_CHUNK);
+    hipLaunchKernelGGL(pcg::pos_sort_local, dim3(chunks), dim3(pcg::SORT_THREADS), 0, st, s0, g->train_pos, g->n_pos,
+                       keys);
+    PCG_LAUNCH_CHECK();
+    for (int64_t k = 2 * pcg::SORT_CHUNK; k <= cap; k <<= 1) {
+        for (int64_t j = k >> 1; j >= pcg::SORT_CHUNK; j >>= 1) {
+            const int64_t pairs = cap / 2;
+            hipLaunchKernelGGL(pcg::bitonic_global_step, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, keys,
+                               pairs, (int)j, (int)k);
+            PCG_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(pcg::bitonic_local_merge, dim3(chunks), dim3(pcg::SORT_THREADS), 0, st, keys, (int)k);
+        PCG_LAUNCH_CHECK();
+    }
+    return PCG_OK;
+}
+
+}  // extern "C"

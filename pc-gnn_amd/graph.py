@@ -1,0 +1,115 @@
+"""Device-resident graph container: multi-relation CSR + frozen feature table.
+
+Input contract = what the reference hands its layers:
+``adj_lists``: list of ``dict[int -> set[int]]`` per relation, symmetric, with
+self-loops (src/utils.py:226-239); ``features``: frozen ``nn.Embedding`` weight
+``[N, F]`` (src/model_handler.py:85-87); ``train_pos``: list of ids.
+
+Layout in HBM (see include/pcgnn.h): X ``[N, Fs]`` f32 with ``Fs = ceil4(F)``
+zero-padded so every row is a whole number of 16-byte chunks (128-B rows for
+YelpChi F=32 and for Amazon F=25), per relation ``indptr`` int64 ``[N+1]`` and
+``indices`` int32 ascending inside a row, ``train_pos`` int32.
+"""
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Set, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+AdjList = Dict[int, Set[int]]
+
+
+def adj_to_csr(adj: AdjList, n_nodes: int) -> Tuple[np.ndarray, np.ndarray]:
+    """dict-of-sets -> (indptr int64 [N+1], indices int32, ascending per row)."""
+    deg = np.zeros(n_nodes, dtype=np.int64)
+    for v, s in adj.items():
+        deg[int(v)] = len(s)
+    indptr = np.zeros(n_nodes + 1, dtype=np.int64)
+    np.cumsum(deg, out=indptr[1:])
+    indices = np.empty(int(indptr[-1]), dtype=np.int32)
+    for v, s in adj.items():
+        if s:
+            v = int(v)
+            row = np.fromiter(s, dtype=np.int32, count=len(s))
+            row.sort()
+            indices[indptr[v]:indptr[v + 1]] = row
+    return indptr, indices
+
+
+class DeviceGraph:
+    def __init__(self, X, csr: Sequence[Tuple[np.ndarray, np.ndarray]], train_pos: Sequence[int],
+                 device: Optional[torch.device] = None):
+        _lib.load()
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.PcgnnLibraryError("DeviceGraph needs a GPU device: the PC-GNN hot path has no CPU fallback")
+        X = torch.as_tensor(X, dtype=torch.float32)
+        self.n_nodes, self.feat_dim = int(X.shape[0]), int(X.shape[1])
+        self.feat_stride = (self.feat_dim + 3) // 4 * 4
+        if self.feat_stride > 512:
+            raise _lib.PcgnnLibraryError(f"feat_dim {self.feat_dim} > 512 is not supported by the gather kernels")
+        Xp = torch.zeros(self.n_nodes, self.feat_stride, dtype=torch.float32, device=self.device)
+        Xp[:, :self.feat_dim] = X.to(self.device)
+        self.X = Xp
+        self.R = len(csr)
+        if not 1 <= self.R <= _lib.PCG_MAX_REL:
+            raise ValueError(f"1..{_lib.PCG_MAX_REL} relations supported, got {self.R}")
+        self.indptr, self.indices, self.deg_host = [], [], []
+        self.max_degree = 0
+        for indptr, indices in csr:
+            indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+            indices = np.ascontiguousarray(indices, dtype=np.int32)
+            if indptr.shape[0] != self.n_nodes + 1 or indptr[-1] != indices.shape[0]:
+                raise ValueError("CSR shape does not match the feature table")
+            if indices.size and (indices.min() < 0 or indices.max() >= self.n_nodes):
+                raise ValueError("neighbour id out of range")
+            deg = np.diff(indptr)
+            self.deg_host.append(deg)
+            self.max_degree = max(self.max_degree, int(deg.max()) if deg.size else 0)
+            self.indptr.append(torch.from_numpy(indptr).to(self.device))
+            self.indices.append(torch.from_numpy(indices).to(self.device) if indices.size
+                                else torch.zeros(1, dtype=torch.int32, device=self.device))
+        tp = np.asarray(list(train_pos), dtype=np.int64)
+        if tp.size and (tp.min() < 0 or tp.max() >= self.n_nodes):
+            raise ValueError("train_pos id out of range")
+        if np.unique(tp).size != tp.size:
+            raise ValueError("train_pos contains duplicate ids (the reference builds it with pos_neg_split, "
+                             "src/utils.py:256-271, which never does)")
+        self.n_pos = int(tp.size)
+        self.train_pos_host = tp
+        self.train_pos = (torch.from_numpy(tp.astype(np.int32)).to(self.device) if tp.size
+                          else torch.zeros(1, dtype=torch.int32, device=self.device))
+        self._desc = None
+
+    # -- constructors ---------------------------------------------------------
+    @classmethod
+    def from_adj_lists(cls, features_weight, adj_lists: Sequence[AdjList], train_pos, device=None):
+        n = int(features_weight.shape[0])
+        return cls(features_weight.detach().cpu() if torch.is_tensor(features_weight) else features_weight,
+                   [adj_to_csr(a, n) for a in adj_lists], train_pos, device)
+
+    # -- C ABI view -------------------------------------------------------------
+    @property
+    def desc(self) -> _lib.GraphDesc:
+        if self._desc is None:
+            d = _lib.GraphDesc()
+            d.n_nodes, d.feat_dim, d.feat_stride = self.n_nodes, self.feat_dim, self.feat_stride
+            d.n_rel, d.n_pos, d.max_degree = self.R, self.n_pos, self.max_degree
+            d.X = self.X.data_ptr()
+            d.train_pos = self.train_pos.data_ptr()
+            for r in range(self.R):
+                d.indptr[r] = self.indptr[r].data_ptr()
+                d.indices[r] = self.indices[r].data_ptr()
+            self._desc = d
+        return self._desc
+
+    def desc_ref(self):
+        return C.byref(self.desc)
+
+    def nbytes(self) -> int:
+        return (self.X.numel() * 4 + sum(t.numel() * 8 for t in self.indptr) + sum(t.numel() * 4 for t in self.indices)
+                + self.train_pos.numel() * 4)

@@ -1,0 +1,359 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle and the
+golden vectors captured from the reference.  Run with ``pytest -m gpu`` on an MI355X.
+
+Bars: chosen index sets bit-exact (given the same class-0 scores); floats within
+the tolerance written at each assert (north_star: logits within 1e-4 fp32).
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pcgnn_oracle as O
+from tests.util import GOLDEN, PARAM_KEYS, GoldenCase, csr_to_adj, synth_graph
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["yelp_small", "amazon_small", "single_rel"]
+LOGIT_TOL = 1e-4     # north_star tolerance for logits
+FEAT_TOL = 2e-5      # aggregated features / activations
+
+
+@pytest.fixture(scope="module")
+def P():
+    import pcgnn_amd
+    from pcgnn_amd import ops  # noqa: F401  (fails loudly if the .so is missing)
+    return pcgnn_amd
+
+
+@pytest.fixture(scope="module", params=CASES)
+def case(request):
+    return GoldenCase(request.param)
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+def graph_of(P, c):
+    return P.DeviceGraph(c.X, c.csr, c.train_pos, dev())
+
+
+def build_model(P, c, rho, graph=None):
+    feats = torch.nn.Embedding(c.n, c.f)
+    feats.weight = torch.nn.Parameter(torch.from_numpy(c.X.copy()), requires_grad=False)
+    intras = [P.IntraAgg(feats, c.f, c.emb, c.train_pos, rho, cuda=True) for _ in range(c.R)]
+    inter = P.InterAgg(feats, c.f, c.emb, c.train_pos, graph if graph is not None else c.adj_lists(), intras, cuda=True)
+    model = P.PCALayer(2, inter, c.alpha)
+    sd = model.state_dict()
+    for k, v in c.params().items():
+        sd[k].copy_(v)
+    return model.cuda()
+
+
+# ---------------------------------------------------------------------------
+def test_library_loaded(P):
+    from pcgnn_amd import _lib
+    assert _lib.load().pcg_version().startswith(b"pcgnn_hip gfx950")
+
+
+def test_score_table_and_rows(P, case):
+    c, ops = case, P.ops
+    g = graph_of(P, c)
+    W = c.params()["inter1.label_clf.weight"].cuda()
+    b = c.params()["inter1.label_clf.bias"].cuda()
+    s0 = ops.score_table(g, W, b)
+    ref = c.z["table_scores"]
+    np.testing.assert_allclose(s0.cpu().numpy(), ref[:, 0], rtol=0, atol=2e-6)
+    ids = torch.arange(c.n, dtype=torch.int32, device=dev())
+    both = ops.score_rows(g, W, b, ids)
+    assert torch.equal(both[:, 0], s0), "score_rows column 0 must be bit-identical to score_table"
+    np.testing.assert_allclose(both.cpu().numpy(), ref, rtol=0, atol=2e-6)
+    # partial range leaves the rest untouched
+    out = torch.full((c.n,), 7.0, device=dev())
+    ops.score_table(g, W, b, out=out, row_begin=10, row_end=20)
+    assert torch.equal(out[10:20], s0[10:20]) and float(out[:10].min()) == 7.0 and float(out[20:].max()) == 7.0
+
+
+def test_pos_sort(P, case):
+    c, ops = case, P.ops
+    g = graph_of(P, c)
+    s0 = torch.from_numpy(c.z["table_scores"][:, 0].copy()).cuda()
+    keys = ops.pos_sort(g, s0).cpu().numpy().view(np.uint64)
+    n = len(c.train_pos)
+    assert np.all(keys[n:] == np.uint64(0xFFFFFFFFFFFFFFFF))
+    pos = (keys[:n] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    sc = c.z["table_scores"][np.array(c.train_pos), 0]
+    order = np.lexsort((np.arange(n), sc))       # by score, then position
+    assert np.array_equal(pos, order)
+
+
+def test_chosen_sets_bit_exact_golden(P, case):
+    """Feed the reference's own class-0 scores: the chosen sets must be identical."""
+    c, ops = case, P.ops
+    g = graph_of(P, c)
+    s0 = torch.from_numpy(c.z["table_scores"][:, 0].copy()).cuda()
+    keys = ops.pos_sort(g, s0)
+    nodes = torch.tensor(c.nodes, dtype=torch.int32, device=dev())
+    labels = torch.from_numpy(c.batch_labels.astype(np.int32)).cuda()
+    X = torch.from_numpy(c.X)
+    for rho in c.rhos:
+        sets, agg, cnt = ops.chosen_sets(g, nodes, labels, s0, keys, [0.5] * c.R, rho, True)
+        for r in range(c.R):
+            want = c.sel(f"rho{rho}_train", r)
+            assert sets[r] == want, f"{c.name} rho={rho} rel={r}"
+            assert cnt[r].cpu().tolist() == [len(s) for s in want]
+            np.testing.assert_allclose(agg[r].cpu().numpy(), O.sparse_aggregate(want, X).numpy(), rtol=0, atol=FEAT_TOL)
+    sets, agg, cnt = ops.chosen_sets(g, nodes, None, s0, None, [0.5] * c.R, 0.5, False)
+    for r in range(c.R):
+        assert sets[r] == c.sel("test", r)
+
+
+def test_forward_matches_reference(P, case):
+    c = case
+    for rho in c.rhos:
+        m = build_model(P, c, rho)
+        logits, cs = m.forward(c.nodes, torch.from_numpy(c.batch_labels).cuda(), True)
+        key = f"rho{rho}_train"
+        got_sets = m.inter1.chosen_sets(c.nodes, c.batch_labels, True)
+        for r in range(c.R):
+            assert got_sets[r] == c.sel(key, r)
+        np.testing.assert_allclose(logits.detach().cpu().numpy(), c.z[key + "_logits"], rtol=0, atol=LOGIT_TOL)
+        np.testing.assert_allclose(cs.detach().cpu().numpy(), c.z[key + "_center_scores"], rtol=0, atol=1e-5)
+    m = build_model(P, c, c.rhos[0])
+    gp, _ = m.to_prob(c.nodes, c.batch_labels, train_flag=False)
+    np.testing.assert_allclose(gp.detach().cpu().numpy(), c.z["test_gnn_prob"], rtol=0, atol=LOGIT_TOL)
+    comb, _ = m.inter1(c.nodes, c.batch_labels, False)
+    assert tuple(comb.shape) == (c.emb, len(c.nodes))
+    np.testing.assert_allclose(comb.detach().cpu().numpy(), c.z["test_combined"], rtol=0, atol=FEAT_TOL)
+
+
+def test_loss_grads_adam_match_reference(P, case):
+    c = case
+    rho = c.rhos[0]
+    tag = f"rho{rho}"
+    m = build_model(P, c, rho)
+    opt = torch.optim.Adam(filter(lambda p: p.requires_grad, m.parameters()), lr=c.lr, weight_decay=c.wd)
+    opt.zero_grad()
+    loss = m.loss(c.nodes, torch.from_numpy(c.batch_labels).cuda())
+    loss.backward()
+    assert abs(loss.item() - float(c.z[tag + "_loss"])) < LOGIT_TOL
+    named = dict(m.named_parameters())
+    for k in PARAM_KEYS(c.R):
+        np.testing.assert_allclose(named[k].grad.cpu().numpy(), c.z[f"{tag}_grad_{k}"], rtol=0, atol=2e-5, err_msg=k)
+    opt.step()
+    sd = m.state_dict()
+    for k in PARAM_KEYS(c.R):
+        np.testing.assert_allclose(sd[k].cpu().numpy(), c.z[f"{tag}_step_{k}"], rtol=0, atol=c.lr * 5e-2, err_msg=k)
+    # state-dict names of the reference, incl. the frozen feature table copies
+    keys = set(sd.keys())
+    assert {"weight", "inter1.weight", "inter1.features.weight", "inter1.label_clf.weight",
+            "inter1.label_clf.bias", "inter1.intra_agg1.weight", "inter1.intra_agg1.features.weight"} <= keys
+
+
+def test_pick_golden(P, case):
+    c, ops = case, P.ops
+    idx_train = c.z["idx_train"]
+    y = c.labels[idx_train]
+    indptr, _ = c.homo_csr
+    deg = np.diff(indptr)[idx_train]
+    lf = (y.sum() - len(y)) * y + len(y)
+    cum = np.cumsum(deg / lf)
+    out = ops.pick(torch.from_numpy(cum).cuda(), torch.from_numpy(idx_train.astype(np.int32)).cuda(),
+                   len(c.z["pick_uniforms"]), uniforms=torch.from_numpy(c.z["pick_uniforms"]).cuda())
+    assert out.cpu().tolist() == c.z["pick_out"].tolist()
+
+
+def test_kat(P):
+    z = np.load(os.path.join(GOLDEN, "kat.npz"))
+    ops = P.ops
+    # KAT 1: centre node 0 (score 0) with neighbours 10..14
+    n = 40
+    X = np.random.RandomState(0).randn(n, 8).astype(np.float32)
+    indptr = np.zeros(n + 1, dtype=np.int64)
+    indptr[1:] = 5
+    g = P.DeviceGraph(X, [(indptr, np.array([10, 11, 12, 13, 14], dtype=np.int32))], [], dev())
+    s0 = torch.zeros(n, device=dev())
+    s0[10:15] = torch.tensor(z["kat1_s0"], dtype=torch.float32)
+    sets, _, _ = ops.chosen_sets(g, torch.tensor([0], dtype=torch.int32, device=dev()), None, s0, None, [0.5], 0.5, False)
+    assert sorted(sets[0][0]) == z["kat1_out"].tolist()
+    # KAT 2: positive centre (score 1.0), single neighbour 20, train_pos [20,31,32,33]
+    indptr = np.zeros(n + 1, dtype=np.int64)
+    indptr[1:] = 1
+    g = P.DeviceGraph(X, [(indptr, np.array([20], dtype=np.int32))], [20, 31, 32, 33], dev())
+    s0 = torch.zeros(n, device=dev())
+    s0[0] = 1.0
+    s0[torch.tensor([20, 31, 32, 33])] = torch.tensor(z["kat2_pos_s0"], dtype=torch.float32)
+    # the neighbour's own score in the KAT is 0.4 but node 20 is also a train-pos with score 1.5;
+    # keep-all applies (deg 1), so only the minority part matters
+    keys = ops.pos_sort(g, s0)
+    for rho in (0.2, 0.5, 0.8, 2.0, 3.5):
+        sets, _, _ = ops.chosen_sets(g, torch.tensor([0], dtype=torch.int32, device=dev()),
+                                     torch.tensor([1], dtype=torch.int32, device=dev()), s0, keys, [0.5], rho, True)
+        assert sorted(sets[0][0]) == z[f"kat2_out_rho{rho}"].tolist(), rho
+    # KAT 3: keep-all table
+    for deg, kept in zip(z["kat3_deg"].tolist(), z["kat3_kept"].tolist()):
+        indptr = np.zeros(n + 1, dtype=np.int64)
+        indptr[1:] = deg
+        g = P.DeviceGraph(X, [(indptr, np.arange(20, 20 + deg, dtype=np.int32))], [], dev())
+        s0 = torch.zeros(n, device=dev())
+        s0[20:20 + deg] = torch.linspace(0.1, 1.0, deg)
+        _, _, cnt = ops.chosen_sets(g, torch.tensor([0], dtype=torch.int32, device=dev()), None, s0, None, [0.5], 0.5,
+                                    False)
+        assert int(cnt[0, 0]) == kept
+
+
+# ---------------------------------------------------------------------------
+# seeded synthetic graphs against the oracle (same device scores => bit-exact sets)
+# ---------------------------------------------------------------------------
+def oracle_sets(csr, n, nodes, labels, s0, train_pos, thr, rho, train):
+    s0 = torch.from_numpy(s0)
+    indptr, idx = csr
+    lists = [idx[indptr[v]:indptr[v + 1]].tolist() for v in nodes]
+    nscore = [s0[torch.as_tensor(l, dtype=torch.long)] for l in lists]
+    return O.choose_sets(s0[torch.as_tensor(nodes, dtype=torch.long)], labels, lists, nscore, list(train_pos),
+                         s0[torch.as_tensor(list(train_pos), dtype=torch.long)], thr, rho, train)
+
+
+def hub_graph(seed, n, hub_degs, base_deg=6.0, feat=32):
+    """Graph with explicit hub rows (node i gets hub_degs[i] neighbours) to drive the
+    block path (deg > 2048) and the global-scratch path (deg > 24576)."""
+    X, labels, csrs = synth_graph(seed, n, feat, (base_deg,), 0.1, hub=False)
+    indptr, idx = csrs[0]
+    rs = np.random.RandomState(seed + 1)
+    rows = [idx[indptr[v]:indptr[v + 1]] for v in range(n)]
+    for v, d in enumerate(hub_degs):
+        rows[v] = np.unique(np.concatenate([rs.choice(n, size=d, replace=False).astype(np.int32), [v]]))
+    indptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum([len(r) for r in rows], out=indptr[1:])
+    return X, labels, (indptr, np.concatenate(rows).astype(np.int32))
+
+
+@pytest.mark.parametrize("quantize", [False, True])
+def test_hub_rows_block_and_scratch_paths(P, quantize):
+    ops = P.ops
+    n = 60000
+    hub_degs = [30000, 9000, 2500, 2049, 2048, 2047, 1000, 65, 64, 63]
+    X, labels, csr = hub_graph(11, n, hub_degs)
+    if quantize:   # many exact distance ties: the positional tie-break must match the oracle
+        X = np.round(X * 2) / 2
+    train_pos = np.flatnonzero(labels[: n // 2] == 1)[:3000].tolist()
+    g = P.DeviceGraph(X, [csr], train_pos, dev())
+    W = torch.randn(2, 32, generator=torch.Generator().manual_seed(1)).cuda() * (0.25 if quantize else 1.0)
+    if quantize:
+        W = torch.round(W * 4) / 4
+    b = torch.zeros(2).cuda()
+    s0 = ops.score_table(g, W, b)
+    keys = ops.pos_sort(g, s0)
+    nodes = list(range(len(hub_degs))) + [0, 1, 777, 778]
+    lab = [1, 0, 1, 1, 0, 1, 1, 1, 0, 1, 1, 0, 1, 0]
+    for rho in (0.5, 2.0):
+        sets, agg, cnt = ops.chosen_sets(g, torch.tensor(nodes, dtype=torch.int32, device=dev()),
+                                         torch.tensor(lab, dtype=torch.int32, device=dev()), s0, keys, [0.5], rho, True)
+        want = oracle_sets(csr, n, nodes, lab, s0.cpu().numpy(), train_pos, 0.5, rho, True)
+        for bidx in range(len(nodes)):
+            assert sets[0][bidx] == want[bidx], f"row {bidx} (deg {len(csr[1][csr[0][nodes[bidx]]:csr[0][nodes[bidx]+1]])}) rho {rho}"
+        np.testing.assert_allclose(agg[0].cpu().numpy(), O.sparse_aggregate(want, torch.from_numpy(X)).numpy(),
+                                   rtol=0, atol=5e-5)
+    sets, _, _ = ops.chosen_sets(g, torch.tensor(nodes, dtype=torch.int32, device=dev()), None, s0, None, [0.5], 0.5, False)
+    want = oracle_sets(csr, n, nodes, None, s0.cpu().numpy(), train_pos, 0.5, 0.5, False)
+    assert sets[0] == want
+
+
+@pytest.mark.parametrize("feat", [10, 25, 32, 64, 100, 166, 400])
+def test_feature_widths(P, feat):
+    ops = P.ops
+    n = 3000
+    X, labels, csrs = synth_graph(21, n, feat, (4, 20), 0.1)
+    train_pos = np.flatnonzero(labels == 1)[:200].tolist()
+    g = P.DeviceGraph(X, csrs, train_pos, dev())
+    W = torch.randn(2, feat, generator=torch.Generator().manual_seed(2)).cuda()
+    b = torch.randn(2, generator=torch.Generator().manual_seed(3)).cuda()
+    s0 = ops.score_table(g, W, b)
+    ref = torch.nn.functional.linear(torch.from_numpy(X), W.cpu(), b.cpu())[:, 0]
+    np.testing.assert_allclose(s0.cpu().numpy(), ref.numpy(), rtol=0, atol=1e-4)
+    keys = ops.pos_sort(g, s0)
+    rs = np.random.RandomState(5)
+    nodes = rs.randint(0, n, size=97).tolist()
+    lab = labels[np.array(nodes)].tolist()
+    sets, agg, cnt = ops.chosen_sets(g, torch.tensor(nodes, dtype=torch.int32, device=dev()),
+                                     torch.tensor(lab, dtype=torch.int32, device=dev()), s0, keys, [0.5, 0.5], 0.8, True)
+    for r in range(2):
+        want = oracle_sets(csrs[r], n, nodes, lab, s0.cpu().numpy(), train_pos, 0.5, 0.8, True)
+        assert sets[r] == want
+        np.testing.assert_allclose(agg[r].cpu().numpy(), O.sparse_aggregate(want, torch.from_numpy(X)).numpy(),
+                                   rtol=0, atol=FEAT_TOL)
+    got = ops.gather_rows(g, torch.tensor(nodes, dtype=torch.int32, device=dev()))
+    assert np.array_equal(got.cpu().numpy(), X[np.array(nodes)])
+
+
+def test_edge_cases(P):
+    ops = P.ops
+    n = 500
+    X, labels, csrs = synth_graph(31, n, 32, (6,), 0.2)
+    train_pos = np.flatnonzero(labels == 1).tolist()
+    g = P.DeviceGraph(X, csrs, train_pos, dev())
+    W = torch.randn(2, 32, generator=torch.Generator().manual_seed(4)).cuda()
+    b = torch.zeros(2).cuda()
+    s0 = ops.score_table(g, W, b)
+    keys = ops.pos_sort(g, s0)
+    # empty batch
+    agg, cnt = ops.choose_aggregate(g, torch.zeros(0, dtype=torch.int32, device=dev()),
+                                    torch.zeros(0, dtype=torch.int32, device=dev()), s0, keys, [0.5], 0.5, True)
+    assert agg.shape == (1, 0, 32)
+    # single node, duplicates, rho = 0 (no over-sampling), rho huge (all train-pos)
+    for nodes, rho in (([3], 0.5), ([5, 5, 5, 9, 5], 0.5), ([1, 2, 3, 4], 0.0), ([1, 2, 3, 4], 1e6)):
+        lab = [1] * len(nodes)
+        sets, agg, cnt = ops.chosen_sets(g, torch.tensor(nodes, dtype=torch.int32, device=dev()),
+                                         torch.tensor(lab, dtype=torch.int32, device=dev()), s0, keys, [0.5], rho, True)
+        want = oracle_sets(csrs[0], n, nodes, lab, s0.cpu().numpy(), train_pos, 0.5, rho, True)
+        assert sets[0] == want
+        np.testing.assert_allclose(agg[0].cpu().numpy(), O.sparse_aggregate(want, torch.from_numpy(X)).numpy(),
+                                   rtol=0, atol=FEAT_TOL)
+    # thresholds other than 0.5 (BASELINE config 5 sweeps; layers.py:193 fixes 0.5)
+    nodes = list(range(40))
+    for thr in (0.2, 0.8, 1.0):
+        sets, _, _ = ops.chosen_sets(g, torch.tensor(nodes, dtype=torch.int32, device=dev()), None, s0, None, [thr], 0.5, False)
+        assert sets[0] == oracle_sets(csrs[0], n, nodes, None, s0.cpu().numpy(), train_pos, thr, 0.5, False)
+    # no training positives at all
+    g0 = P.DeviceGraph(X, csrs, [], dev())
+    sets, _, _ = ops.chosen_sets(g0, torch.tensor(nodes, dtype=torch.int32, device=dev()),
+                                 torch.ones(40, dtype=torch.int32, device=dev()), s0, None, [0.5], 0.5, True)
+    assert sets[0] == oracle_sets(csrs[0], n, nodes, [1] * 40, s0.cpu().numpy(), [], 0.5, 0.5, True)
+
+
+def test_segment_mean_and_graphsage_aggregators(P, case):
+    c, ops = case, P.ops
+    g = P.DeviceGraph(c.X, [c.homo_csr], [], dev())
+    sub = c.z["s1_nodes"].tolist()
+    indptr, idx = c.homo_csr
+    begin = torch.from_numpy(indptr[np.array(sub)]).cuda()
+    count = torch.from_numpy(np.diff(indptr)[np.array(sub)].astype(np.int32)).cuda()
+    idx_d = torch.from_numpy(idx).cuda()
+    got = ops.segment_mean(g, begin, count, idx_d, 0)
+    np.testing.assert_allclose(got.cpu().numpy(), c.z["s1_mean"], rtol=0, atol=FEAT_TOL)
+    # GCN: union self, / sqrt(count); SAGE gcn=True: union self, / count - through the fused kernel (threshold 1 => keep all)
+    s0 = torch.zeros(c.n, device=dev())
+    nodes = torch.tensor(sub, dtype=torch.int32, device=dev())
+    agg, _ = ops.choose_aggregate(g, nodes, None, s0, None, [1.0], 0.0, False, norm=1, add_self=True)
+    np.testing.assert_allclose(agg[0].cpu().numpy(), c.z["s1_gcn"], rtol=0, atol=FEAT_TOL)
+    agg, _ = ops.choose_aggregate(g, nodes, None, s0, None, [1.0], 0.0, False, norm=0, add_self=True)
+    np.testing.assert_allclose(agg[0].cpu().numpy(), c.z["s1_mean_gcn"], rtol=0, atol=FEAT_TOL)
+
+
+def test_intra_agg_reference_signature(P, case):
+    """IntraAgg.forward called the way the reference's InterAgg calls it (layers.py:268)."""
+    c = case
+    rho = c.rhos[0]
+    m = build_model(P, c, rho)
+    table = torch.from_numpy(c.z["table_scores"].copy())
+    adj = c.adj(0)
+    lists = [sorted(adj[v]) for v in c.nodes]
+    nscores = [table[torch.as_tensor(l)] for l in lists]
+    samples = [math.ceil(len(l) * 0.5) for l in lists]
+    center = table[torch.as_tensor(c.nodes)]
+    pos_scores = table[torch.as_tensor(c.train_pos)]
+    feats, _ = m.inter1.intra_agg1.forward(c.nodes, c.batch_labels, lists, center, nscores, pos_scores, samples, False)
+    np.testing.assert_allclose(feats.detach().cpu().numpy(), c.z["test_feats0"], rtol=0, atol=FEAT_TOL)
