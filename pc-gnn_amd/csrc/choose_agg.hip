@@ -497,7 +497,9 @@ int pcg_choose_aggregate(const pcg_graph_desc *g, const int32_t *nodes, const in
                          int32_t train_flag, int32_t norm, int32_t add_self, float *agg, int32_t agg_stride,
                          int32_t *cnt, const int64_t *sel_begin, int32_t *sel_indices, int64_t sel_capacity,
                          void *workspace, uint32_t *status, void *stream) {
-    if (!g || !nodes || !s0 || !thresholds || !agg || !workspace || B < 0) return PCG_E_ARG;
+    if (!g || B < 0) return PCG_E_ARG;
+    if (B == 0) return PCG_OK;  // empty trailing batch (model_handler.py:134 produces one): nothing to do
+    if (!nodes || !s0 || !thresholds || !agg || !workspace) return PCG_E_ARG;
     if (train_flag && !rho) return PCG_E_ARG;
     if (g->n_rel < 1 || g->n_rel > PCG_MAX_REL || !g->X) return PCG_E_ARG;
     if (g->feat_stride % 4 != 0 || g->feat_stride < g->feat_dim || agg_stride < g->feat_dim) return PCG_E_ARG;
@@ -507,7 +509,6 @@ int pcg_choose_aggregate(const pcg_graph_desc *g, const int32_t *nodes, const in
     if (sel_indices && !status) return PCG_E_ARG;
     for (int r = 0; r < g->n_rel; ++r)
         if (!g->indptr[r] || !g->indices[r]) return PCG_E_ARG;
-    if (B == 0) return PCG_OK;
 
     pcg::ChooseArgs a;
     a.g = *g;

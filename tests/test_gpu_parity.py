@@ -176,7 +176,7 @@ def test_kat(P):
     indptr[1:] = 5
     g = P.DeviceGraph(X, [(indptr, np.array([10, 11, 12, 13, 14], dtype=np.int32))], [], dev())
     s0 = torch.zeros(n, device=dev())
-    s0[10:15] = torch.tensor(z["kat1_s0"], dtype=torch.float32)
+    s0[10:15] = torch.tensor(z["kat1_s0"], dtype=torch.float32, device=dev())
     sets, _, _ = ops.chosen_sets(g, torch.tensor([0], dtype=torch.int32, device=dev()), None, s0, None, [0.5], 0.5, False)
     assert sorted(sets[0][0]) == z["kat1_out"].tolist()
     # KAT 2: positive centre (score 1.0), single neighbour 20, train_pos [20,31,32,33]
@@ -185,7 +185,7 @@ def test_kat(P):
     g = P.DeviceGraph(X, [(indptr, np.array([20], dtype=np.int32))], [20, 31, 32, 33], dev())
     s0 = torch.zeros(n, device=dev())
     s0[0] = 1.0
-    s0[torch.tensor([20, 31, 32, 33])] = torch.tensor(z["kat2_pos_s0"], dtype=torch.float32)
+    s0[torch.tensor([20, 31, 32, 33], device=dev())] = torch.tensor(z["kat2_pos_s0"], dtype=torch.float32, device=dev())
     # the neighbour's own score in the KAT is 0.4 but node 20 is also a train-pos with score 1.5;
     # keep-all applies (deg 1), so only the minority part matters
     keys = ops.pos_sort(g, s0)
@@ -199,7 +199,7 @@ def test_kat(P):
         indptr[1:] = deg
         g = P.DeviceGraph(X, [(indptr, np.arange(20, 20 + deg, dtype=np.int32))], [], dev())
         s0 = torch.zeros(n, device=dev())
-        s0[20:20 + deg] = torch.linspace(0.1, 1.0, deg)
+        s0[20:20 + deg] = torch.linspace(0.1, 1.0, deg).to(dev())
         _, _, cnt = ops.chosen_sets(g, torch.tensor([0], dtype=torch.int32, device=dev()), None, s0, None, [0.5], 0.5,
                                     False)
         assert int(cnt[0, 0]) == kept
