@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py - sampled-nodes/sec of the PC-GNN train step on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload yelp|amazon|powerlaw]
+
+A "step" is one mini-batch through the whole hot path: label-aware scoring,
+train-pos sort, choose + aggregate, dense tail, loss, backward, Adam - the
+reference's timed window (src/model_handler.py:143-155) - plus, at every epoch
+start, the pick + shuffle (:130-133).  Steps walk real epochs: 2*|train_pos|
+picked nodes -> ceil(./B) batches, the last one partial; `value` counts the nodes
+actually processed.  Inputs (graph, features, labels) are resident in HBM before
+the timed region.
+
+N=1 workload: BASELINE.json configs[1] - YelpChi-shaped synthetic graph
+(N=45,954, F=32, 3 relations with 49,315 / 573,616 / 3,402,743 undirected edges,
+14.53 % positives, 40 % train), emb 64, batch 1024, rho 0.5.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = choose_agg,
+HIP events inside the timed region) and `cpu_baseline` (the oracle port timed on
+the host cores on a bounded sample of the same batches; rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=12)
+    ap.add_argument("--workload", default="yelp", choices=["yelp", "amazon", "powerlaw"])
+    ap.add_argument("--batch-size", type=int, default=None)
+    ap.add_argument("--emb", type=int, default=64)
+    ap.add_argument("--rho", type=float, default=0.5)
+    ap.add_argument("--nodes", type=int, default=2_000_000, help="powerlaw only")
+    ap.add_argument("--edges", type=int, default=40_000_000, help="powerlaw only")
+    ap.add_argument("--cpu-batches", type=int, default=2, help="oracle batches timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--seed", type=int, default=0)
+    return ap.parse_args()
+
+
+def make_workload(args):
+    from pcgnn_amd import synth
+    if args.workload == "yelp":
+        return synth.yelp_like(args.seed), 1024, 0.01, 0.001
+    if args.workload == "amazon":
+        return synth.amazon_like(args.seed), 256, 0.005, 0.0005
+    return synth.power_law(args.nodes, args.edges, args.seed), 4096, 0.01, 0.001
+
+
+def algorithmic_bytes(graph, ids_host, counts_host):
+    """HBM bytes the choose+aggregate launch must move for one batch:
+    CSR row bounds + neighbour ids + neighbour class-0 scores + chosen feature rows + output."""
+    B = len(ids_host)
+    total = 0
+    for r in range(graph.R):
+        D = int(graph.deg_host[r][ids_host].sum())
+        S = int(counts_host[r].sum())
+        total += 4 * (2 * B + D) + 4 * D + 4 * graph.feat_dim * S + 4 * B * graph.feat_dim
+    return total
+
+
+def cpu_baseline(w, trainer, cfg, batches, n_batches):
+    """Time the oracle (CPU port of the reference algorithm, same Python/torch shape) on the
+    first `n_batches` batches the GPU run used.  Test infrastructure used as the baseline
+    leg only - nothing here feeds the GPU path."""
+    from oracle import pcgnn_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    adj = []
+    for indptr, idx in w.csr:
+        adj.append({v: set(idx[indptr[v]:indptr[v + 1]].tolist()) for v in range(w.n)})
+    params = {k: v.detach().cpu().clone() for k, v in trainer.model.state_dict().items() if "features" not in k}
+    om = O.OraclePCGNN(torch.from_numpy(w.X), adj, w.train_pos, params, cfg["rho"], cfg["alpha"], dense_mask=True)
+    opt = O.make_adam(om, cfg["lr"], cfg["weight_decay"])
+    nodes, spent = 0, 0.0
+    for ids in batches[:n_batches]:
+        t0 = time.perf_counter()
+        O.train_step(om, opt, ids.tolist(), w.labels[ids])
+        spent += time.perf_counter() - t0
+        nodes += len(ids)
+    return {"value": nodes / spent, "unit": "nodes/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_batches} batches ({nodes} nodes) of the same workload, same picked ids, "
+                      f"oracle/pcgnn_oracle.py train_step (dense-mask formulation as in the reference), {spent:.1f} s"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import pcgnn_amd  # noqa: F401  (raises if libpcgnn_hip.so is missing - no fallback)
+    from pcgnn_amd.handler import PCGNNTrainer
+
+    w, default_b, lr, wd = make_workload(args)
+    B = args.batch_size or default_b
+    cfg = dict(emb_size=args.emb, rho=args.rho, alpha=2.0, lr=lr, weight_decay=wd, batch_size=B,
+               seed=args.seed + 1000 * rank)
+    tr = PCGNNTrainer(w, cfg, dev)
+    torch.manual_seed(args.seed)                     # identical initial weights on every rank
+    for p in tr.model.parameters():
+        if p.requires_grad:
+            torch.nn.init.xavier_uniform_(p) if p.dim() > 1 else torch.nn.init.zeros_(p)
+
+    params = [p for p in tr.model.parameters() if p.requires_grad]
+
+    def sync_grads():
+        if dist is None:
+            return
+        flat = torch.cat([p.grad.reshape(-1) for p in params])
+        dist.all_reduce(flat)
+        flat /= world
+        o = 0
+        for p in params:
+            n = p.numel()
+            p.grad.copy_(flat[o:o + n].view_as(p))
+            o += n
+
+    def one_step(ids):
+        labels = tr.labels_dev[ids.long()]
+        tr.opt.zero_grad(set_to_none=True)
+        loss = tr.model.loss(ids, labels)
+        loss.backward()
+        sync_grads()
+        tr.opt.step()
+
+    state = {"epoch": 0, "ids": None, "b": 0}
+    nb = tr.batches_per_epoch()
+
+    def next_batch():
+        if state["ids"] is None or state["b"] == nb:
+            state["ids"] = tr.start_epoch(state["epoch"])      # pick + shuffle on the device
+            state["epoch"] += 1
+            state["b"] = 0
+        b = state["b"]
+        state["b"] += 1
+        return state["ids"][b * B:(b + 1) * B]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        one_step(next_batch())
+
+    inter = tr.model.inter1
+    inter._prof = []                                   # (start, end) HIP events around the choose+aggregate launch
+    used = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ids = next_batch()
+        one_step(ids)
+        used.append((ids, inter.last_counts))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    events, inter._prof = inter._prof, None
+
+    nodes_local = sum(int(i.numel()) for i, _ in used)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    n = torch.tensor([nodes_local], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(n, op=dist.ReduceOp.SUM)
+    elapsed, nodes_total = float(t.item()), float(n.item())
+
+    if rank == 0:
+        kern_ms = [a.elapsed_time(b) for a, b in events]
+        batches_host = [i.cpu().numpy().astype(np.int64) for i, _ in used]
+        abytes = [algorithmic_bytes(tr.graph, i, c.cpu().numpy()) for i, (_, c) in zip(batches_host, used)]
+        avg_ms = float(np.mean(kern_ms))
+        achieved = float(np.mean(abytes)) / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.workload, {}).get("choose_agg_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "sampled-nodes/sec", "value": nodes_total / elapsed, "unit": "nodes/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{w.name} N={w.n} F={w.X.shape[1]} R={len(w.csr)} "
+                                   f"edges={'/'.join(str(e) for e in w.meta['rel_edges'])} "
+                                   f"endpoints={w.meta['endpoints']}, PCGNN emb={args.emb} batch={B} rho={args.rho}, "
+                                   f"pick 2*|train_pos|={tr.pick_size}/epoch",
+                       "global_batch": B * world, "parallelism": "single" if world == 1 else f"dp{world}-replicated-graph",
+                       "nodes_processed": int(nodes_total)},
+            "roofline": {"bound": "hbm", "kernel": "choose_agg_wave(+choose_agg_block)", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": float(np.mean(abytes))},
+        }
+        if world == 1 and args.cpu_batches > 0:
+            out["cpu_baseline"] = cpu_baseline(w, tr, cfg, batches_host, args.cpu_batches)
+            out["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

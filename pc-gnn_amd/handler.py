@@ -1,0 +1,84 @@
+"""Training harness: the counterpart of ``ModelHandler.train`` (src/model_handler.py:77-178)
+for the HIP path.  Same config keys, same loop structure:
+
+    for epoch:  pick 2*|train_pos| nodes (:130) -> shuffle (:133) -> batches of batch_size (:134-148)
+                per batch: zero_grad, loss, backward, Adam step (:149-153)   <- the reference's timed window
+
+but ids / labels stay on the device for the whole epoch (one pick kernel, one
+permutation, batch = a slice), and the empty trailing batch the reference's
+``int(len/B)+1`` produces (and crashes on) is not run.
+"""
+import time
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .graph import DeviceGraph
+from .layers import InterAgg, IntraAgg
+from .model import PCALayer
+from .sampler import PickSampler
+
+DEFAULTS = dict(model="PCGNN", emb_size=64, rho=0.5, alpha=2.0, lr=0.01, weight_decay=0.001, batch_size=1024,
+                epochs=1, seed=0)
+
+
+class PCGNNTrainer:
+    def __init__(self, workload, config: Optional[Dict] = None, device=None):
+        cfg = dict(DEFAULTS)
+        cfg.update(config or {})
+        self.cfg = cfg
+        self.w = workload
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        torch.manual_seed(cfg["seed"])
+        w = workload
+        self.graph = DeviceGraph(w.X, w.csr, w.train_pos, self.device)
+        feats = nn.Embedding(w.n, w.X.shape[1])
+        feats.weight = nn.Parameter(torch.from_numpy(w.X), requires_grad=False)      # model_handler.py:85-86
+        f = w.X.shape[1]
+        intras = [IntraAgg(feats, f, cfg["emb_size"], w.train_pos, cfg["rho"], cuda=True) for _ in w.csr]
+        inter = InterAgg(feats, f, cfg["emb_size"], w.train_pos, self.graph, intras, cuda=True)   # :103-113
+        self.model = PCALayer(2, inter, cfg["alpha"]).to(self.device)                 # :114,:122
+        self.opt = torch.optim.Adam([p for p in self.model.parameters() if p.requires_grad], lr=cfg["lr"],
+                                    weight_decay=cfg["weight_decay"])                 # :124
+        self.labels_dev = torch.from_numpy(w.labels).to(self.device)
+        self.sampler = PickSampler(w.idx_train, w.labels[w.idx_train], w.homo_deg[w.idx_train], self.device,
+                                   seed=cfg["seed"])
+        self.pick_size = 2 * len(w.train_pos)                                          # :130
+        self.batch_size = cfg["batch_size"]
+        self._gen = torch.Generator(device=self.device)
+        self._gen.manual_seed(cfg["seed"])
+
+    # ------------------------------------------------------------------
+    def batches_per_epoch(self) -> int:
+        return (self.pick_size + self.batch_size - 1) // self.batch_size
+
+    def start_epoch(self, epoch: int) -> torch.Tensor:
+        """pick + shuffle (model_handler.py:130-133) -> int32 ids on the device."""
+        picked = self.sampler.pick(self.pick_size, epoch)
+        perm = torch.randperm(self.pick_size, device=self.device, generator=self._gen)
+        return picked[perm]
+
+    def step(self, batch_ids: torch.Tensor) -> torch.Tensor:
+        """One iteration of the batch loop (model_handler.py:147-153)."""
+        labels = self.labels_dev[batch_ids.long()]
+        self.opt.zero_grad(set_to_none=True)
+        loss = self.model.loss(batch_ids, labels)
+        loss.backward()
+        self.opt.step()
+        return loss
+
+    def train_epoch(self, epoch: int):
+        """Returns (#sampled nodes, seconds inside the reference's per-batch window,
+        seconds including pick + shuffle)."""
+        torch.cuda.synchronize(self.device)
+        t_all = time.perf_counter()
+        ids = self.start_epoch(epoch)
+        torch.cuda.synchronize(self.device)
+        t0 = time.perf_counter()
+        for b in range(self.batches_per_epoch()):
+            self.step(ids[b * self.batch_size:(b + 1) * self.batch_size])
+        torch.cuda.synchronize(self.device)
+        t1 = time.perf_counter()
+        return self.pick_size, t1 - t0, t1 - t_all

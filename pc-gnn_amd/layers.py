@@ -137,6 +137,8 @@ class InterAgg(nn.Module):
         self._ws = None
         self._s0 = None
         self._keys = None
+        self._prof = None
+        self.last_counts = None
 
     # ------------------------------------------------------------------
     @property
@@ -173,8 +175,14 @@ class InterAgg(nn.Module):
         s0 = ops.score_table(g, W, b, out=self._s0)                                  # :230-237
         keys = ops.pos_sort(g, s0, self._keys) if (train_flag and g.n_pos) else None   # :683-688
         rho = [a.rho for a in self.intra_aggs]
+        if self._prof is not None:       # bench.py: HIP events around the dominant launch
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         agg, self.last_counts = ops.choose_aggregate(g, ids, lab, s0, keys, self.thresholds, rho,
                                                      bool(train_flag), ws=self._ws)   # :246-270
+        if self._prof is not None:
+            ev[1].record()
+            self._prof.append(ev)
         self_feats = ops.gather_rows(g, ids)                                          # :273-277
         center_scores = _CenterScores.apply(W, b, self_feats, ids, g)                 # :243
         feats = [self_feats] + [a.transform(self_feats, agg[r]) for r, a in enumerate(self.intra_aggs)]

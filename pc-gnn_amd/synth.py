@@ -1,0 +1,116 @@
+"""Seeded synthetic workloads with the statistics of the reference's datasets.
+
+No real dataset exists offline, so bench / tests use graphs
+of the same node / edge / feature-dim / positive-rate shape, built the way
+``sparse_to_adjlist`` builds the real ones (src/utils.py:226-239): undirected,
+symmetrised, de-duplicated, one self-loop per node.
+
+    yelp_like    N=45,954 F=32  edges 49,315 / 573,616 / 3,402,743   pos 14.53 %
+    amazon_like  N=11,944 F=25  edges 175,608 / 3,566,479 / 1,036,737 pos 6.87 %, 3,305 unlabeled
+    power_law    N, E free (BASELINE config 4: 10 M nodes / 200 M edges / 3 relations, pos 1 %)
+"""
+from dataclasses import dataclass, field
+from typing import List, Tuple
+
+import numpy as np
+
+
+@dataclass
+class Workload:
+    name: str
+    X: np.ndarray                       # [N, F] f32
+    labels: np.ndarray                  # [N] int64
+    csr: List[Tuple[np.ndarray, np.ndarray]]   # per relation (indptr int64, indices int32 ascending)
+    homo_deg: np.ndarray                # [N] degree in the union graph (pick weights, utils.py:275)
+    idx_train: np.ndarray               # sorted ids
+    train_pos: List[int]
+    meta: dict = field(default_factory=dict)
+
+    @property
+    def n(self):
+        return self.X.shape[0]
+
+
+def _csr_from_pairs(n, src, dst):
+    a = np.concatenate([src, dst, np.arange(n, dtype=np.int64)])
+    b = np.concatenate([dst, src, np.arange(n, dtype=np.int64)])
+    key = np.unique(a * n + b)
+    rows = key // n
+    cols = (key - rows * n).astype(np.int32)
+    indptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(np.bincount(rows, minlength=n), out=indptr[1:])
+    return indptr, cols
+
+
+def _endpoints(rs, n, m, skew, max_share=None):
+    """m endpoints: uniform (skew None) or Pareto-popularity weighted."""
+    if skew is None:
+        return rs.randint(0, n, size=m).astype(np.int64)
+    pop = rs.pareto(skew, n) + 0.02
+    if max_share is not None:
+        pop = np.minimum(pop, max_share * pop.sum())
+    cdf = np.cumsum(pop)
+    cdf /= cdf[-1]
+    return np.searchsorted(cdf, rs.rand(m)).astype(np.int64).clip(0, n - 1)
+
+
+def _homo_degree(n, csr):
+    keys = []
+    for indptr, idx in csr:
+        rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(indptr))
+        keys.append(rows * n + idx)
+    key = np.unique(np.concatenate(keys))
+    return np.bincount(key // n, minlength=n).astype(np.int64)
+
+
+def _split(rs, labels, first_labeled, train_ratio):
+    """40 % stratified training split (model_handler.py:36-48, sklearn there)."""
+    ids = np.arange(first_labeled, len(labels))
+    train = []
+    for cls in (0, 1):
+        c = ids[labels[ids] == cls]
+        train.append(rs.choice(c, size=int(round(len(c) * train_ratio)), replace=False))
+    idx_train = np.sort(np.concatenate(train))
+    return idx_train, [int(v) for v in idx_train if labels[v] == 1]
+
+
+def make_workload(name, n, feat, rel_edges, pos_rate, seed=0, skew=2.0, first_labeled=0, train_ratio=0.4,
+                  nonneg=False, max_share=0.002) -> Workload:
+    rs = np.random.RandomState(seed)
+    X = rs.randn(n, feat).astype(np.float32)
+    if nonneg:   # Amazon features are non-negative and row-normalised (utils.py:213-223)
+        X = np.abs(X)
+        X = (X / (X.sum(1, keepdims=True) + 0.01)).astype(np.float32)
+    labels = (rs.rand(n) < pos_rate).astype(np.int64)
+    csr = []
+    for m in rel_edges:
+        src = _endpoints(rs, n, m, skew, max_share)
+        dst = rs.randint(0, n, size=m).astype(np.int64)
+        csr.append(_csr_from_pairs(n, src, dst))
+    idx_train, train_pos = _split(rs, labels, first_labeled, train_ratio)
+    return Workload(name, X, labels, csr, _homo_degree(n, csr), idx_train, train_pos,
+                    {"n": n, "feat": feat, "rel_edges": list(rel_edges), "pos_rate": pos_rate, "seed": seed,
+                     "endpoints": "uniform" if skew is None else f"pareto({skew}) x uniform"})
+
+
+def yelp_like(seed=0, skew=2.0) -> Workload:
+    return make_workload("yelpchi-like", 45954, 32, (49315, 573616, 3402743), 0.1453, seed, skew)
+
+
+def amazon_like(seed=0, skew=2.0) -> Workload:
+    return make_workload("amazon-like", 11944, 25, (175608, 3566479, 1036737), 0.0687, seed, skew,
+                         first_labeled=3305, nonneg=True)
+
+
+def power_law(n, n_edges, seed=0, feat=32, pos_rate=0.01, split=(0.05, 0.25, 0.70), skew=1.1, max_share=1e-4) -> Workload:
+    """Heavy-tailed graph (BASELINE config 4 shape).  Pareto(1.1) popularity ~ degree
+    exponent 2.1; the most popular node is capped at max_share of all endpoints."""
+    return make_workload(f"powerlaw-{n}n-{n_edges}e", n, feat, [int(n_edges * s) for s in split], pos_rate, seed,
+                         skew, max_share=max_share)
+
+
+def pick_cum_weights(w: Workload) -> np.ndarray:
+    """deg / LF, then the sequential fp64 running sum random.choices uses (utils.py:275-278)."""
+    y = w.labels[w.idx_train]
+    lf = (y.sum() - len(y)) * y + len(y)
+    return np.cumsum(w.homo_deg[w.idx_train] / lf)
