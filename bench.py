@@ -47,6 +47,11 @@ def parse():
     ap.add_argument("--edges", type=int, default=40_000_000, help="powerlaw only")
     ap.add_argument("--cpu-batches", type=int, default=2, help="oracle batches timed for cpu_baseline (0 = skip)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--event-every", type=int, default=4,
+                    help="graph engine: bracket the choose+aggregate launch with HIP events on every Nth timed step")
+    ap.add_argument("--engine", default=None, choices=["graph", "fused", "torch"],
+                    help="graph: fused HIP step replayed from a hipGraph (default at 1 GPU); fused: same kernels "
+                         "launched eagerly (default at N>1, gradient all-reduce in between); torch: torch dense tail")
     return ap.parse_args()
 
 
@@ -76,7 +81,7 @@ def cpu_baseline(w, trainer, cfg, batches, n_batches):
     first `n_batches` batches the GPU run used.  Test infrastructure used as the baseline
     leg only - nothing here feeds the GPU path."""
     from oracle import pcgnn_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))     # the GPU box gives one GPU a 16-core share
     adj = []
     for indptr, idx in w.csr:
         adj.append({v: set(idx[indptr[v]:indptr[v + 1]].tolist()) for v in range(w.n)})
@@ -114,35 +119,41 @@ def main():
 
     w, default_b, lr, wd = make_workload(args)
     B = args.batch_size or default_b
+    engine = args.engine or ("graph" if world == 1 else "fused")
     cfg = dict(emb_size=args.emb, rho=args.rho, alpha=2.0, lr=lr, weight_decay=wd, batch_size=B,
-               seed=args.seed + 1000 * rank)
+               seed=args.seed + 1000 * rank, engine=engine, world_size=world)
     tr = PCGNNTrainer(w, cfg, dev)
     torch.manual_seed(args.seed)                     # identical initial weights on every rank
-    for p in tr.model.parameters():
-        if p.requires_grad:
-            torch.nn.init.xavier_uniform_(p) if p.dim() > 1 else torch.nn.init.zeros_(p)
+    with torch.no_grad():
+        for p in tr.model.parameters():
+            if p.requires_grad:
+                torch.nn.init.xavier_uniform_(p) if p.dim() > 1 else torch.nn.init.zeros_(p)
 
     params = [p for p in tr.model.parameters() if p.requires_grad]
 
-    def sync_grads():
-        if dist is None:
-            return
-        flat = torch.cat([p.grad.reshape(-1) for p in params])
+    def allreduce(flat):                             # gradients are already scaled by 1/(B*world)
         dist.all_reduce(flat)
-        flat /= world
-        o = 0
-        for p in params:
-            n = p.numel()
-            p.grad.copy_(flat[o:o + n].view_as(p))
-            o += n
 
-    def one_step(ids):
-        labels = tr.labels_dev[ids.long()]
-        tr.opt.zero_grad(set_to_none=True)
-        loss = tr.model.loss(ids, labels)
-        loss.backward()
-        sync_grads()
-        tr.opt.step()
+    def one_step(ids, timed=False):
+        if engine == "torch":
+            labels = tr.labels_dev[ids.long()]
+            tr.opt.zero_grad(set_to_none=True)
+            loss = tr.model.loss(ids, labels)
+            if dist is not None:
+                loss = loss / world
+            loss.backward()
+            if dist is not None:
+                flat = torch.cat([p.grad.reshape(-1) for p in params])
+                dist.all_reduce(flat)
+                o = 0
+                for p in params:
+                    p.grad.copy_(flat[o:o + p.numel()].view_as(p))
+                    o += p.numel()
+            tr.opt.step()
+        elif dist is None:
+            tr.step(ids, timed)
+        else:
+            tr.fused.train_step(ids, tr.labels_i32[ids.long()], allreduce=allreduce)
 
     state = {"epoch": 0, "ids": None, "b": 0}
     nb = tr.batches_per_epoch()
@@ -165,19 +176,23 @@ def main():
         one_step(next_batch())
 
     inter = tr.model.inter1
-    inter._prof = []                                   # (start, end) HIP events around the choose+aggregate launch
-    used = []
+    prof = tr.fused if tr.fused is not None else inter
+    prof._prof = []                                    # (start, end) HIP events around the choose+aggregate launch
+    used, used_ev = [], []
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for k in range(args.steps):
         ids = next_batch()
-        one_step(ids)
-        used.append((ids, inter.last_counts))
+        timed = engine != "graph" or k % args.event_every == 0    # graph engine: events on every Nth step
+        one_step(ids, timed)
+        if timed:
+            used_ev.append((ids, prof.last_counts.clone()))
+        used.append(ids)
     barrier()
     elapsed = time.perf_counter() - t0
-    events, inter._prof = inter._prof, None
+    events, prof._prof = prof._prof, None
 
-    nodes_local = sum(int(i.numel()) for i, _ in used)
+    nodes_local = sum(int(i.numel()) for i in used)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     n = torch.tensor([nodes_local], dtype=torch.float64, device=dev)
     if dist is not None:
@@ -187,8 +202,8 @@ def main():
 
     if rank == 0:
         kern_ms = [a.elapsed_time(b) for a, b in events]
-        batches_host = [i.cpu().numpy().astype(np.int64) for i, _ in used]
-        abytes = [algorithmic_bytes(tr.graph, i, c.cpu().numpy()) for i, (_, c) in zip(batches_host, used)]
+        batches_host = [i.cpu().numpy().astype(np.int64) for i in used]
+        abytes = [algorithmic_bytes(tr.graph, i.cpu().numpy().astype(np.int64), c.cpu().numpy()) for i, c in used_ev]
         avg_ms = float(np.mean(kern_ms))
         achieved = float(np.mean(abytes)) / (avg_ms * 1e-3) / 1e9
         traffic = None
@@ -208,10 +223,12 @@ def main():
                                    f"endpoints={w.meta['endpoints']}, PCGNN emb={args.emb} batch={B} rho={args.rho}, "
                                    f"pick 2*|train_pos|={tr.pick_size}/epoch",
                        "global_batch": B * world, "parallelism": "single" if world == 1 else f"dp{world}-replicated-graph",
+                       "engine": engine,
                        "nodes_processed": int(nodes_total)},
-            "roofline": {"bound": "hbm", "kernel": "choose_agg_wave(+choose_agg_block)", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "pcg_choose_aggregate (choose_agg_t1 + choose_agg_wide<4|16>)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": float(np.mean(abytes))},
+                         "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": float(np.mean(abytes)),
+                         "launches_timed": len(kern_ms)},
         }
         if world == 1 and args.cpu_batches > 0:
             out["cpu_baseline"] = cpu_baseline(w, tr, cfg, batches_host, args.cpu_batches)

@@ -115,7 +115,8 @@ int pcg_pos_sort(const pcg_graph_desc *g, const float *s0, uint64_t *keys, void 
  * want samp_neighs): sel_begin int64 [n_rel*B] (start of row (r,b) inside
  * sel_indices, caller-computed upper-bound layout, see pcg_sel_capacity_row),
  * sel_indices int32 [sel_capacity]; pass NULL/NULL/0 to skip.
- *   workspace: pcg_choose_workspace_bytes(g, B) bytes, 256-byte aligned.
+ *   workspace: pcg_choose_workspace_bytes(g, B) bytes, 256-byte aligned; its first 256
+ *              bytes must be ZERO before the first call (every call leaves them zero).
  *   status   : uint32 device word, OR-ed with PCG_ST_* bits (zero it yourself). */
 int64_t pcg_choose_workspace_bytes(const pcg_graph_desc *g, int32_t B);
 int pcg_choose_aggregate(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B,
@@ -148,6 +149,40 @@ int pcg_segment_mean(const pcg_graph_desc *g, const int64_t *begin, const int32_
  * the device from Philox4x32-10(seed, counter = draw index). */
 int pcg_pick(const double *cum, const int32_t *idx_train, int32_t n_train,
              const double *uniforms, uint64_t seed, uint64_t epoch, int32_t k, int32_t *out, void *stream);
+
+/* ---- dense tail: relation / inter GEMMs, classifier, loss, backward, Adam ---------------
+ * Parameters live in ONE flat f32 buffer `theta` in this order (offsets from
+ * pcg_dense_param_offset; shapes are the reference's state-dict shapes, row-major):
+ *   which 0  weight                      [2, E]          src/model.py:29
+ *   which 1  inter1.weight               [F + R*E, E]    src/layers.py:196
+ *   which 2  inter1.intra_agg{rel+1}.weight [2F, E]      src/layers.py:559
+ *   which 3  inter1.label_clf.weight     [2, F]          src/layers.py:200
+ *   which 4  inter1.label_clf.bias       [2]
+ * pcg_dense_step replaces, for one batch (B rows, tiles of 16 rows):
+ *   self_feats gather, cat/mm/relu per relation   layers.py:273-277, 625-629
+ *   cat/mm/relu of the inter aggregator           layers.py:284-289 ([B,E], not transposed)
+ *   scores = W_cls . embeds, label-aware logits   model.py:38, layers.py:236-243
+ *   both CrossEntropyLoss terms + loss.backward() model.py:54-61, model_handler.py:152
+ * Outputs: logits [B,2], center [B,2]; optional combined [B,E], row_loss [B]
+ * (per-row  xent(gnn) + lambda_1*xent(label); the batch loss is inv_count * sum).
+ * slabs != NULL (training): labels required; slabs [pcg_dense_n_tiles(B), n_params]
+ * receives per-tile partial gradients (already scaled by inv_count = 1/global batch),
+ * and *step_counter (int32, may be NULL) is incremented.  slabs == NULL: inference.
+ * pcg_adam_step sums the slabs in tile order (bitwise reproducible) and, if `apply`,
+ * performs torch.optim.Adam's update with coupled weight decay on theta/m/v using
+ * t = *step_counter (model_handler.py:124,153); grad_out [n_params] (optional)
+ * receives the summed gradient. */
+int64_t pcg_dense_n_params(int32_t feat_dim, int32_t emb, int32_t n_rel);
+int64_t pcg_dense_param_offset(int32_t feat_dim, int32_t emb, int32_t n_rel, int32_t which, int32_t rel);
+int32_t pcg_dense_n_tiles(int32_t B);
+int pcg_dense_step(const pcg_graph_desc *g, const float *theta, int32_t emb,
+                   const int32_t *ids, const int32_t *labels, int32_t B,
+                   const float *agg, int32_t agg_stride, float lambda_1, float inv_count,
+                   float *logits, float *center, float *combined, float *row_loss,
+                   float *slabs, int32_t *step_counter, void *stream);
+int pcg_adam_step(float *theta, float *m, float *v, const float *slabs, int32_t n_slabs, int64_t n_params,
+                  const int32_t *step_counter, double lr, double beta1, double beta2, double eps,
+                  double weight_decay, float *grad_out, int32_t apply, void *stream);
 
 /* gather rows: out[i, :feat_dim] = X[ids[i], :feat_dim]  (self_feats, layers.py:273-277) */
 int pcg_gather_rows(const pcg_graph_desc *g, const int32_t *ids, int32_t n_ids,

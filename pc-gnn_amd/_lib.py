@@ -50,6 +50,12 @@ PROTOTYPES = {
     "pcg_segment_mean": (C.c_int, [_G, _P, _P, _P, _I32, _I32, _P, _I32, _P]),
     "pcg_pick": (C.c_int, [_P, _P, _I32, _P, _U64, _U64, _I32, _P, _P]),
     "pcg_gather_rows": (C.c_int, [_G, _P, _I32, _P, _I32, _P]),
+    "pcg_dense_n_params": (_I64, [_I32, _I32, _I32]),
+    "pcg_dense_param_offset": (_I64, [_I32, _I32, _I32, _I32, _I32]),
+    "pcg_dense_n_tiles": (_I32, [_I32]),
+    "pcg_dense_step": (C.c_int, [_G, _P, _I32, _P, _P, _I32, _P, _I32, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P,
+                                 _P]),
+    "pcg_adam_step": (C.c_int, [_P, _P, _P, _P, _I32, _I64, _P, _F64, _F64, _F64, _F64, _F64, _P, _I32, _P]),
 }
 
 _lib = None

@@ -1,0 +1,391 @@
+// Dense tail of the PC-GNN step for gfx950: relation GEMMs, inter GEMM, classifier,
+// the two cross-entropy terms, their backward and Adam - two launches per step.
+//
+//   dense_step : one 256-thread workgroup per tile of 16 batch rows does the whole
+//                forward for its rows, the loss gradients, and this tile's partial
+//                weight gradients (split-K over the batch: one partial "slab" per
+//                tile, no atomics => bitwise reproducible).  GEMMs run on the f32
+//                matrix cores (v_mfma_f32_16x16x4_f32: exact fmaf chains).
+//   adam_reduce: sums the slabs in tile order and applies torch.optim.Adam's update
+//                (coupled L2 weight decay) to the flat parameter buffer.
+//
+// Reference lines replaced: src/layers.py:273-289, 625-629; src/model.py:34-62;
+// src/model_handler.py:124,149-153 (optimizer.zero_grad / loss.backward / optimizer.step).
+// Gradients never flow into the gathered features or the selection (features frozen,
+// model_handler.py:86; selection is index-only), so backward is dense GEMMs only.
+#include "common.h"
+
+namespace pcg {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TB = 16;          // batch rows per workgroup (one MFMA M-tile)
+constexpr int DENSE_WAVES = 4;
+
+struct DenseArgs {
+    const float *X;
+    int32_t feat_dim, feat_stride, n_rel, emb;
+    const int32_t *ids;
+    const int32_t *labels;      // null => inference (no loss, no gradients)
+    int32_t B;
+    const float *agg;           // [R, B, agg_stride]
+    int32_t agg_stride;
+    const float *W_cls;         // [2, E]
+    const float *W_inter;       // [F + R*E, E]
+    const float *W_intra[PCG_MAX_REL];  // [2F, E]
+    const float *W_clf;         // [2, F]
+    const float *b_clf;         // [2]
+    float lambda_1, inv_count;
+    float *logits;              // [B, 2]
+    float *center;              // [B, 2]
+    float *combined;            // [B, E] or null
+    float *row_loss;            // [B] or null
+    float *slabs;               // [n_tiles, n_params] or null
+    int64_t n_params;
+    int32_t *step_counter;      // incremented once per training launch (Adam's t), or null
+};
+
+// flat parameter / gradient order: W_cls | W_inter | W_intra[0..R) | W_clf | b_clf
+__host__ __device__ inline int64_t off_cls(int F, int E, int R) { return 0; }
+__host__ __device__ inline int64_t off_inter(int F, int E, int R) { return 2 * (int64_t)E; }
+__host__ __device__ inline int64_t off_intra(int F, int E, int R, int r) {
+    return off_inter(F, E, R) + (int64_t)(F + R * E) * E + (int64_t)r * 2 * F * E;
+}
+__host__ __device__ inline int64_t off_clf(int F, int E, int R) { return off_intra(F, E, R, R); }
+__host__ __device__ inline int64_t off_bias(int F, int E, int R) { return off_clf(F, E, R) + 2 * (int64_t)F; }
+__host__ __device__ inline int64_t n_params_of(int F, int E, int R) { return off_bias(F, E, R) + 2; }
+
+// C[16x16] += A[16 x K] (LDS, row-major, leading dim lda, zero-padded to Kp) * B[K x ..] (global, ld ldb, column n0..n0+15)
+__device__ __forceinline__ f32x4 tile_lds_glob(const float *A, int lda, const float *__restrict__ Bg, int ldb, int n0,
+                                               int K, int Kp, int lane) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int r = lane & 15, kq = lane >> 4;
+#pragma unroll 4
+    for (int k0 = 0; k0 < Kp; k0 += 4) {
+        const int k = k0 + kq;
+        const float a = A[r * lda + k];
+        const float b = (k < K) ? Bg[(size_t)k * ldb + n0 + r] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// C[16x16] = At^T * Bt with both operands row tiles in LDS: C[m][n] = sum_t At[t][m0+m] * Bt[t][n0+n], t < 16
+__device__ __forceinline__ f32x4 tile_ldsT_lds(const float *At, int lda, int m0, int M, const float *Bt, int ldb, int n0,
+                                               int lane) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int r = lane & 15, kq = lane >> 4;
+    const bool mok = m0 + r < M;
+#pragma unroll
+    for (int t0 = 0; t0 < TB; t0 += 4) {
+        const int t = t0 + kq;
+        const float a = mok ? At[t * lda + m0 + r] : 0.f;
+        const float b = Bt[t * ldb + n0 + r];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+__device__ __forceinline__ void xent2(float a, float b, int y, float &loss, float &da, float &db) {
+    const float mx = fmaxf(a, b);
+    const float ea = expf(a - mx), eb = expf(b - mx);
+    const float s = ea + eb;
+    const float lse = mx + logf(s);
+    loss = lse - (y == 1 ? b : a);
+    da = ea / s - (y == 0 ? 1.f : 0.f);
+    db = eb / s - (y == 1 ? 1.f : 0.f);
+}
+
+__global__ void __launch_bounds__(DENSE_WAVES *PCG_WAVE) dense_step_kernel(const DenseArgs a) {
+    extern __shared__ __align__(16) float sm[];
+    const int F = a.feat_dim, E = a.emb, R = a.n_rel;
+    const int K1 = 2 * F, K1p = (K1 + 3) & ~3, K2 = F + R * E, K2p = (K2 + 3) & ~3;
+    const int ld1 = K1p + 1, ld2 = K2p + 1, ldE = E + 1;
+    float *s_catr = sm;                       // [TB][ld1]  [self | agg_r] of the relation being processed
+    float *s_cat = s_catr + TB * ld1;         // [TB][ld2]  [self | h_1 .. h_R]
+    float *s_comb = s_cat + TB * ld2;         // [TB][ldE]
+    float *s_dcomb = s_comb + TB * ldE;       // [TB][ldE]
+    float *s_dh = s_dcomb + TB * ldE;         // [TB][ldE]
+    float *s_dlog = s_dh + TB * ldE;          // [TB][2] d loss / d gnn logits
+    float *s_dcl = s_dlog + TB * 2;           // [TB][2] d loss / d centre scores (already times lambda_1)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = blockIdx.x * TB;
+    const bool train = a.slabs != nullptr;
+    if (train && a.step_counter && blockIdx.x == 0 && tid == 0) a.step_counter[0] += 1;
+
+    // zero the padded tiles, then load self rows into cat[:, :F]
+    for (int i = tid; i < TB * ld2; i += blockDim.x) s_cat[i] = 0.f;
+    for (int i = tid; i < TB * ld1; i += blockDim.x) s_catr[i] = 0.f;
+    __syncthreads();
+    for (int i = tid; i < TB * F; i += blockDim.x) {
+        const int t = i / F, f = i - t * F;
+        const int b = row0 + t;
+        if (b < a.B) s_cat[t * ld2 + f] = a.X[(size_t)a.ids[b] * a.feat_stride + f];
+    }
+    __syncthreads();
+
+    // ---- forward: h_r = relu([self | agg_r] W_r)   (layers.py:625-629) -----------------
+    const int ntile_e = E / 16;
+    for (int r = 0; r < R; ++r) {
+        for (int i = tid; i < TB * F; i += blockDim.x) {
+            const int t = i / F, f = i - t * F;
+            const int b = row0 + t;
+            s_catr[t * ld1 + f] = s_cat[t * ld2 + f];
+            s_catr[t * ld1 + F + f] = b < a.B ? a.agg[((size_t)r * a.B + b) * a.agg_stride + f] : 0.f;
+        }
+        __syncthreads();
+        for (int ct = wave; ct < ntile_e; ct += DENSE_WAVES) {
+            const f32x4 c = tile_lds_glob(s_catr, ld1, a.W_intra[r], E, ct * 16, K1, K1p, lane);
+            const int col = ct * 16 + (lane & 15), rq = (lane >> 4) * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s_cat[(rq + i) * ld2 + F + r * E + col] = fmaxf(c[i], 0.f);
+        }
+        __syncthreads();
+    }
+    // ---- combined = relu(cat W)   (layers.py:284-289) -------------------------------------
+    for (int ct = wave; ct < ntile_e; ct += DENSE_WAVES) {
+        const f32x4 c = tile_lds_glob(s_cat, ld2, a.W_inter, E, ct * 16, K2, K2p, lane);
+        const int col = ct * 16 + (lane & 15), rq = (lane >> 4) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float v = fmaxf(c[i], 0.f);
+            s_comb[(rq + i) * ldE + col] = v;
+            const int b = row0 + rq + i;
+            if (a.combined && b < a.B) a.combined[(size_t)b * E + col] = v;
+        }
+    }
+    __syncthreads();
+    // ---- logits, centre scores, loss gradients (model.py:38, layers.py:243, model.py:54-61) ---
+    if (tid < TB * 4) {                       // thread = (row t, which of the 4 dot products)
+        const int t = tid >> 2, which = tid & 3;
+        float acc = 0.f;
+        if (which < 2) {
+            for (int e = 0; e < E; ++e) acc = fmaf(s_comb[t * ldE + e], a.W_cls[which * E + e], acc);
+        } else {
+            const int cls = which - 2;
+            for (int f = 0; f < F; ++f) acc = fmaf(s_cat[t * ld2 + f], a.W_clf[cls * F + f], acc);
+            acc += a.b_clf[cls];
+        }
+        s_dh[t * 4 + which] = acc;            // scratch: [t][g0, g1, c0, c1]
+    }
+    __syncthreads();
+    if (tid < TB) {
+        const int t = tid, b = row0 + t;
+        const float g0 = s_dh[t * 4 + 0], g1 = s_dh[t * 4 + 1], c0 = s_dh[t * 4 + 2], c1 = s_dh[t * 4 + 3];
+        float dg0 = 0.f, dg1 = 0.f, dc0 = 0.f, dc1 = 0.f;
+        if (b < a.B) {
+            a.logits[2 * b] = g0;
+            a.logits[2 * b + 1] = g1;
+            a.center[2 * b] = c0;
+            a.center[2 * b + 1] = c1;
+            if (a.labels) {
+                const int y = a.labels[b];
+                float lg, lc;
+                xent2(g0, g1, y, lg, dg0, dg1);
+                xent2(c0, c1, y, lc, dc0, dc1);
+                if (a.row_loss) a.row_loss[b] = lg + a.lambda_1 * lc;
+                dg0 *= a.inv_count; dg1 *= a.inv_count;
+                dc0 *= a.inv_count * a.lambda_1; dc1 *= a.inv_count * a.lambda_1;
+            }
+        }
+        s_dlog[2 * t] = dg0; s_dlog[2 * t + 1] = dg1;
+        s_dcl[2 * t] = dc0; s_dcl[2 * t + 1] = dc1;
+    }
+    __syncthreads();
+    if (!train) return;
+
+    float *slab = a.slabs + (size_t)blockIdx.x * a.n_params;
+    // ---- backward ----------------------------------------------------------------------------
+    // dcomb = (dlogits W_cls) * relu'(combined)
+    for (int i = tid; i < TB * E; i += blockDim.x) {
+        const int t = i / E, e = i - t * E;
+        const float g = s_dlog[2 * t] * a.W_cls[e] + s_dlog[2 * t + 1] * a.W_cls[E + e];
+        s_dcomb[t * ldE + e] = s_comb[t * ldE + e] > 0.f ? g : 0.f;
+    }
+    // dW_cls[c][e] = sum_t dlogits[t][c] comb[t][e];  dW_clf[c][f] = sum_t dcl[t][c] self[t][f];  db_clf
+    for (int i = tid; i < 2 * E; i += blockDim.x) {
+        const int cidx = i / E, e = i - cidx * E;
+        float s = 0.f;
+        for (int t = 0; t < TB; ++t) s = fmaf(s_dlog[2 * t + cidx], s_comb[t * ldE + e], s);
+        slab[off_cls(F, E, R) + i] = s;
+    }
+    for (int i = tid; i < 2 * F; i += blockDim.x) {
+        const int cidx = i / F, f = i - cidx * F;
+        float s = 0.f;
+        for (int t = 0; t < TB; ++t) s = fmaf(s_dcl[2 * t + cidx], s_cat[t * ld2 + f], s);
+        slab[off_clf(F, E, R) + i] = s;
+    }
+    if (tid < 2) {
+        float s = 0.f;
+        for (int t = 0; t < TB; ++t) s += s_dcl[2 * t + tid];
+        slab[off_bias(F, E, R) + tid] = s;
+    }
+    __syncthreads();
+    // dW_inter[m][n] = sum_t cat[t][m] dcomb[t][n]
+    {
+        const int mt = (K2 + 15) / 16;
+        float *dst = slab + off_inter(F, E, R);
+        for (int tile = wave; tile < mt * ntile_e; tile += DENSE_WAVES) {
+            const int m0 = (tile / ntile_e) * 16, n0 = (tile % ntile_e) * 16;
+            const f32x4 c = tile_ldsT_lds(s_cat, ld2, m0, K2, s_dcomb, ldE, n0, lane);
+            const int col = n0 + (lane & 15), rq = (lane >> 4) * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (m0 + rq + i < K2) dst[(size_t)(m0 + rq + i) * E + col] = c[i];
+        }
+    }
+    // per relation: dh_r = (dcomb W[F+rE.., :]^T) * relu'(h_r);  dW_r = [self|agg_r]^T dh_r
+    for (int r = 0; r < R; ++r) {
+        __syncthreads();
+        for (int i = tid; i < TB * F; i += blockDim.x) {     // reload [self | agg_r]
+            const int t = i / F, f = i - t * F;
+            const int b = row0 + t;
+            s_catr[t * ld1 + f] = s_cat[t * ld2 + f];
+            s_catr[t * ld1 + F + f] = b < a.B ? a.agg[((size_t)r * a.B + b) * a.agg_stride + f] : 0.f;
+        }
+        const float *Wr = a.W_inter + (size_t)(F + r * E) * E;   // rows of W_inter that multiply h_r
+        for (int ct = wave; ct < ntile_e; ct += DENSE_WAVES) {
+            // out[t][j] = sum_e dcomb[t][e] * Wr[j][e]
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const int rr = lane & 15, kq = lane >> 4;
+#pragma unroll 4
+            for (int e0 = 0; e0 < E; e0 += 4) {
+                const float av = s_dcomb[rr * ldE + e0 + kq];
+                const float bv = Wr[(size_t)(ct * 16 + rr) * E + e0 + kq];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+            }
+            const int col = ct * 16 + rr, rq = kq * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                s_dh[(rq + i) * ldE + col] = s_cat[(rq + i) * ld2 + F + r * E + col] > 0.f ? acc[i] : 0.f;
+        }
+        __syncthreads();
+        const int mt = (K1 + 15) / 16;
+        float *dst = slab + off_intra(F, E, R, r);
+        for (int tile = wave; tile < mt * ntile_e; tile += DENSE_WAVES) {
+            const int m0 = (tile / ntile_e) * 16, n0 = (tile % ntile_e) * 16;
+            const f32x4 c = tile_ldsT_lds(s_catr, ld1, m0, K1, s_dh, ldE, n0, lane);
+            const int col = n0 + (lane & 15), rq = (lane >> 4) * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (m0 + rq + i < K1) dst[(size_t)(m0 + rq + i) * E + col] = c[i];
+        }
+    }
+}
+
+// g = sum over slabs (tile order); torch.optim.Adam step with coupled weight decay
+__global__ void __launch_bounds__(256) adam_reduce_kernel(float *__restrict__ theta, float *__restrict__ m,
+                                                          float *__restrict__ v, const float *__restrict__ slabs,
+                                                          int n_slabs, int64_t n_params,
+                                                          const int32_t *__restrict__ step_counter, float lr,
+                                                          float beta1, float beta2, float eps, float wd,
+                                                          float *__restrict__ grad_out, int apply) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_params) return;
+    float g = 0.f;
+    for (int s = 0; s < n_slabs; ++s) g += slabs[(size_t)s * n_params + i];
+    if (grad_out) grad_out[i] = g;
+    if (!apply) return;
+    const float p = theta[i];
+    g = fmaf(wd, p, g);
+    const float mi = beta1 * m[i] + (1.f - beta1) * g;
+    const float vi = beta2 * v[i] + (1.f - beta2) * g * g;
+    m[i] = mi;
+    v[i] = vi;
+    const float t = (float)step_counter[0];
+    const float bc1 = 1.f - powf(beta1, t), bc2 = 1.f - powf(beta2, t);
+    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+    theta[i] = p - (lr / bc1) * (mi / denom);
+}
+
+static size_t dense_smem_bytes(int F, int E, int R) {
+    const int K1p = (2 * F + 3) & ~3, K2p = (F + R * E + 3) & ~3;
+    return sizeof(float) * (size_t)(TB * (K1p + 1) + TB * (K2p + 1) + 3 * TB * (E + 1) + 4 * TB);
+}
+
+}  // namespace pcg
+
+extern "C" {
+
+int64_t pcg_dense_n_params(int32_t feat_dim, int32_t emb, int32_t n_rel) {
+    if (feat_dim < 1 || emb < 1 || n_rel < 1 || n_rel > PCG_MAX_REL) return PCG_E_ARG;
+    return pcg::n_params_of(feat_dim, emb, n_rel);
+}
+
+int64_t pcg_dense_param_offset(int32_t feat_dim, int32_t emb, int32_t n_rel, int32_t which, int32_t rel) {
+    switch (which) {
+        case 0: return pcg::off_cls(feat_dim, emb, n_rel);
+        case 1: return pcg::off_inter(feat_dim, emb, n_rel);
+        case 2: return pcg::off_intra(feat_dim, emb, n_rel, rel);
+        case 3: return pcg::off_clf(feat_dim, emb, n_rel);
+        case 4: return pcg::off_bias(feat_dim, emb, n_rel);
+        default: return PCG_E_ARG;
+    }
+}
+
+int32_t pcg_dense_n_tiles(int32_t B) { return B < 0 ? PCG_E_ARG : (B + pcg::TB - 1) / pcg::TB; }
+
+int pcg_dense_step(const pcg_graph_desc *g, const float *theta, int32_t emb, const int32_t *ids, const int32_t *labels,
+                   int32_t B, const float *agg, int32_t agg_stride, float lambda_1, float inv_count, float *logits,
+                   float *center, float *combined, float *row_loss, float *slabs, int32_t *step_counter, void *stream) {
+    if (!g || !g->X || !theta || B < 0) return PCG_E_ARG;
+    if (B == 0) return PCG_OK;
+    if (!ids || !agg || !logits || !center) return PCG_E_ARG;
+    if (emb < 16 || emb % 16 != 0 || g->n_rel < 1 || g->n_rel > PCG_MAX_REL) return PCG_E_UNSUPPORTED;
+    if (slabs && !labels) return PCG_E_ARG;
+    const int F = g->feat_dim, E = emb, R = g->n_rel;
+    const size_t smem = pcg::dense_smem_bytes(F, E, R);
+    if (smem > 160 * 1024) return PCG_E_UNSUPPORTED;
+    pcg::DenseArgs a;
+    a.X = g->X;
+    a.feat_dim = F;
+    a.feat_stride = g->feat_stride;
+    a.n_rel = R;
+    a.emb = E;
+    a.ids = ids;
+    a.labels = labels;
+    a.B = B;
+    a.agg = agg;
+    a.agg_stride = agg_stride;
+    a.W_cls = theta + pcg::off_cls(F, E, R);
+    a.W_inter = theta + pcg::off_inter(F, E, R);
+    for (int r = 0; r < PCG_MAX_REL; ++r) a.W_intra[r] = r < R ? theta + pcg::off_intra(F, E, R, r) : nullptr;
+    a.W_clf = theta + pcg::off_clf(F, E, R);
+    a.b_clf = theta + pcg::off_bias(F, E, R);
+    a.lambda_1 = lambda_1;
+    a.inv_count = inv_count;
+    a.logits = logits;
+    a.center = center;
+    a.combined = combined;
+    a.row_loss = row_loss;
+    a.slabs = slabs;
+    a.n_params = pcg::n_params_of(F, E, R);
+    a.step_counter = step_counter;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(pcg::dense_step_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return PCG_E_LAUNCH;
+        attr = true;
+    }
+    hipLaunchKernelGGL(pcg::dense_step_kernel, dim3((B + pcg::TB - 1) / pcg::TB), dim3(pcg::DENSE_WAVES * PCG_WAVE),
+                       smem, static_cast<hipStream_t>(stream), a);
+    PCG_LAUNCH_CHECK();
+    return PCG_OK;
+}
+
+int pcg_adam_step(float *theta, float *m, float *v, const float *slabs, int32_t n_slabs, int64_t n_params,
+                  const int32_t *step_counter, double lr, double beta1, double beta2, double eps, double weight_decay,
+                  float *grad_out, int32_t apply, void *stream) {
+    if (!slabs || n_slabs < 0 || n_params < 1) return PCG_E_ARG;
+    if (apply && (!theta || !m || !v || !step_counter)) return PCG_E_ARG;
+    if (!apply && !grad_out) return PCG_E_ARG;
+    hipLaunchKernelGGL(pcg::adam_reduce_kernel, dim3((unsigned)((n_params + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), theta, m, v, slabs, n_slabs, n_params, step_counter, (float)lr,
+                       (float)beta1, (float)beta2, (float)eps, (float)weight_decay, grad_out, apply);
+    PCG_LAUNCH_CHECK();
+    return PCG_OK;
+}
+
+}  // extern "C"

@@ -68,6 +68,45 @@ __global__ void __launch_bounds__(SORT_THREADS) bitonic_local_merge(uint64_t *__
     for (int t = threadIdx.x; t < SORT_CHUNK; t += SORT_THREADS) keys[base + t] = sh[t];
 }
 
+// ---- rank sort: one launch, no step barriers (n_pos <= RANK_MAX) -------------------
+// Keys are unique, so rank(i) = #{j : key_j < key_i} is a permutation.  Every block
+// stages all keys in LDS, owns 64 of them (one per lane) and splits the j-range over
+// its 16 waves; LDS reads are wave-wide broadcasts.
+constexpr int RANK_MAX = 16384;
+constexpr int RANK_WAVES = 16;
+
+__global__ void __launch_bounds__(RANK_WAVES *PCG_WAVE) pos_rank_sort(const float *__restrict__ s0,
+                                                                      const int32_t *__restrict__ train_pos,
+                                                                      int n_pos, int cap, uint64_t *__restrict__ keys) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    uint64_t *sh = reinterpret_cast<uint64_t *>(smem_raw);
+    int *part = reinterpret_cast<int *>(sh + n_pos);          // [RANK_WAVES][64]
+    for (int t = threadIdx.x; t < n_pos; t += blockDim.x) sh[t] = make_pos_key(s0, train_pos, t, n_pos);
+    __syncthreads();
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * PCG_WAVE + lane;
+    const uint64_t mine = i < n_pos ? sh[i] : ~0ull;
+    const int chunk = (n_pos + RANK_WAVES - 1) / RANK_WAVES;
+    const int j0 = wave * chunk, j1 = (j0 + chunk < n_pos) ? j0 + chunk : n_pos;
+    int c = 0;
+    int j = j0;
+    for (; j + 4 <= j1; j += 4) {
+        const uint64_t a0 = sh[j], a1 = sh[j + 1], a2 = sh[j + 2], a3 = sh[j + 3];
+        c += (a0 < mine) + (a1 < mine) + (a2 < mine) + (a3 < mine);
+    }
+    for (; j < j1; ++j) c += sh[j] < mine;
+    part[wave * PCG_WAVE + lane] = c;
+    __syncthreads();
+    if (wave == 0 && i < n_pos) {
+        int rank = 0;
+#pragma unroll
+        for (int w = 0; w < RANK_WAVES; ++w) rank += part[w * PCG_WAVE + lane];
+        keys[rank] = mine;
+    }
+    if (blockIdx.x == 0)
+        for (int t = n_pos + threadIdx.x; t < cap; t += blockDim.x) keys[t] = ~0ull;
+}
+
 static int64_t sort_capacity(int32_t n_pos) {
     int64_t c = SORT_CHUNK;
     while (c < n_pos) c <<= 1;
@@ -85,6 +124,20 @@ int pcg_pos_sort(const pcg_graph_desc *g, const float *s0, uint64_t *keys, void 
     if (g->n_pos == 0) return PCG_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t cap = pcg::sort_capacity(g->n_pos);
+    if (g->n_pos <= pcg::RANK_MAX) {
+        const size_t smem = sizeof(uint64_t) * g->n_pos + sizeof(int) * pcg::RANK_WAVES * PCG_WAVE;
+        static bool attr = false;
+        if (!attr) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(pcg::pos_rank_sort),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return PCG_E_LAUNCH;
+            attr = true;
+        }
+        hipLaunchKernelGGL(pcg::pos_rank_sort, dim3((g->n_pos + PCG_WAVE - 1) / PCG_WAVE),
+                           dim3(pcg::RANK_WAVES * PCG_WAVE), smem, st, s0, g->train_pos, g->n_pos, (int)cap, keys);
+        PCG_LAUNCH_CHECK();
+        return PCG_OK;
+    }
     const int chunks = (int)(cap / pcg::SORT_CHUNK);
     hipLaunchKernelGGL(pcg::pos_sort_local, dim3(chunks), dim3(pcg::SORT_THREADS), 0, st, s0, g->train_pos, g->n_pos,
                        keys);

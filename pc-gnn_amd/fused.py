@@ -1,0 +1,249 @@
+"""Whole-step driver: every launch of one PC-GNN train step, back to back on one
+stream, no torch ops and no host synchronisation in between:
+
+    score_table -> pos_sort -> choose_aggregate -> dense_step -> adam_step
+
+and the same sequence captured once per batch size into a hipGraph
+(``torch.cuda.CUDAGraph``) so that a step costs one graph launch on the host.
+
+The model's parameters are re-pointed into ONE flat f32 buffer (order: see
+``pcg_dense_step`` in include/pcgnn.h); the ``nn.Parameter`` objects, their names
+and ``state_dict()`` stay exactly the reference's.
+
+Reference loop replaced: src/model_handler.py:147-153 (and :305 of utils.py for
+``predict``).
+"""
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib, ops
+from .graph import DeviceGraph
+from .model import PCALayer
+
+_p = ops._p
+
+
+class FusedPCGNN:
+    def __init__(self, model: PCALayer, lr: float, weight_decay: float, betas=(0.9, 0.999), eps: float = 1e-8,
+                 max_batch: int = 1024, global_batch_scale: int = 1):
+        lib = _lib.load()
+        self.lib = lib
+        self.model = model
+        inter = model.inter1
+        self.g: DeviceGraph = inter.graph()
+        g = self.g
+        self.dev = g.device
+        self.F, self.E, self.R = g.feat_dim, inter.embed_dim, g.R
+        self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
+        self.lambda_1 = float(model.lambda_1)
+        self.scale = global_batch_scale           # ranks sharing one global batch (loss is a mean over all of it)
+        self.thresholds = list(inter.thresholds)
+        self.rho = [a.rho for a in inter.intra_aggs]
+
+        n = lib.pcg_dense_n_params(self.F, self.E, self.R)
+        self.n_params = int(n)
+        self.theta = torch.zeros(n, dtype=torch.float32, device=self.dev)
+        named = dict(model.named_parameters())
+        spec = [("weight", 0, 0), ("inter1.weight", 1, 0)] + \
+               [(f"inter1.intra_agg{r + 1}.weight", 2, r) for r in range(self.R)] + \
+               [("inter1.label_clf.weight", 3, 0), ("inter1.label_clf.bias", 4, 0)]
+        self.views: Dict[str, torch.Tensor] = {}
+        for name, which, rel in spec:
+            p = named[name]
+            off = lib.pcg_dense_param_offset(self.F, self.E, self.R, which, rel)
+            view = self.theta[off:off + p.numel()].view(p.shape)
+            view.copy_(p.data.to(self.dev))
+            p.data = view                      # the Parameter now lives inside the flat buffer
+            self.views[name] = view
+        self.w_clf = self.views["inter1.label_clf.weight"]
+        self.b_clf = self.views["inter1.label_clf.bias"]
+        self.m = torch.zeros_like(self.theta)
+        self.v = torch.zeros_like(self.theta)
+        self.step_counter = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self.grad = torch.zeros_like(self.theta)
+
+        self._alloc(max_batch)
+        self._graphs = {}
+        self._prof = None          # bench.py: list of (start, end) events around the choose+aggregate launch
+        self.last_counts = None
+
+    # ------------------------------------------------------------------
+    def _alloc(self, B: int):
+        g, dev = self.g, self.dev
+        self.maxB = B
+        self.s0 = torch.empty(g.n_nodes, dtype=torch.float32, device=dev)
+        self.keys = torch.empty(self.lib.pcg_pos_sort_capacity(g.n_pos), dtype=torch.int64, device=dev)
+        self.ws = ops.ChooseWorkspace(g, B)
+        self.agg = torch.empty(g.R, B, g.feat_dim, dtype=torch.float32, device=dev)
+        self.cnt = torch.empty(g.R, B, dtype=torch.int32, device=dev)
+        self.logits = torch.empty(B, 2, dtype=torch.float32, device=dev)
+        self.center = torch.empty(B, 2, dtype=torch.float32, device=dev)
+        self.row_loss = torch.zeros(B, dtype=torch.float32, device=dev)
+        self.slabs = torch.empty(self.lib.pcg_dense_n_tiles(B), self.n_params, dtype=torch.float32, device=dev)
+        self.ids_buf = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.lab_buf = torch.zeros(B, dtype=torch.int32, device=dev)
+
+    def _stream(self):
+        return ops._stream(self.dev)
+
+    # ------------------------------------------------------------------
+    def _enqueue_scores(self, train_flag):
+        """label-aware score table + per-step sort of the train positives."""
+        g = self.g
+        ops.score_table(g, self.w_clf, self.b_clf, out=self.s0)
+        return ops.pos_sort(g, self.s0, self.keys) if (train_flag and g.n_pos) else None
+
+    def _enqueue_choose(self, ids, labels, B, keys, train_flag):
+        g = self.g
+        agg = self.agg.view(-1)[:g.R * B * g.feat_dim].view(g.R, B, g.feat_dim)
+        cnt = self.cnt.view(-1)[:g.R * B].view(g.R, B)
+        timed = self._prof is not None and not torch.cuda.is_current_stream_capturing()
+        if timed:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        ops.choose_aggregate(g, ids, labels if train_flag else None, self.s0, keys, self.thresholds, self.rho,
+                             train_flag, ws=self.ws, agg=agg, cnt=cnt)
+        if timed:
+            ev[1].record()
+            self._prof.append(ev)
+        self.last_counts = cnt
+        return agg, cnt
+
+    def _enqueue_sample(self, ids, labels, B, train_flag):
+        """score table, train-pos sort, choose + aggregate for one batch (views sized to B)."""
+        keys = self._enqueue_scores(train_flag)
+        return self._enqueue_choose(ids, labels, B, keys, train_flag)
+
+    def _enqueue_dense(self, ids, labels, B, agg, train: bool, combined=None):
+        g = self.g
+        _lib.check(self.lib.pcg_dense_step(
+            g.desc_ref(), _p(self.theta), self.E, _p(ids), _p(labels), B, _p(agg), agg.stride(1), self.lambda_1,
+            1.0 / (B * self.scale), _p(self.logits), _p(self.center), _p(combined),
+            _p(self.row_loss) if labels is not None else None, _p(self.slabs) if train else None,
+            _p(self.step_counter) if train else None, self._stream()), "pcg_dense_step")
+
+    def _enqueue_adam(self, B, apply=True, want_grad=False, from_grad=False):
+        """from_grad: the (all-reduced) flat gradient in self.grad is the single slab."""
+        b1, b2 = self.betas
+        slabs, n_slabs = (self.grad, 1) if from_grad else (self.slabs, self.lib.pcg_dense_n_tiles(B))
+        _lib.check(self.lib.pcg_adam_step(
+            _p(self.theta), _p(self.m), _p(self.v), _p(slabs), n_slabs, self.n_params,
+            _p(self.step_counter), self.lr, b1, b2, self.eps, self.wd, _p(self.grad) if want_grad else None,
+            1 if apply else 0, self._stream()), "pcg_adam_step")
+
+    # ------------------------------------------------------------------
+    def train_step(self, ids: torch.Tensor, labels: torch.Tensor, allreduce=None):
+        """zero_grad + loss + backward + Adam step for one batch (model_handler.py:149-153).
+        ids / labels: int32 device tensors.  Nothing is returned and nothing syncs;
+        ``last_loss()`` reads the batch loss afterwards.  ``allreduce(flat_grad)`` (data-parallel
+        ranks) is called between the gradient reduction and the Adam update."""
+        B = ids.numel()
+        if B == 0:
+            return
+        if B > self.maxB:
+            self._alloc(B)
+            self._graphs.clear()
+        self._lastB = B
+        agg, _ = self._enqueue_sample(ids, labels, B, True)
+        self._enqueue_dense(ids, labels, B, agg, True)
+        if allreduce is None:
+            self._enqueue_adam(B, apply=True)
+        else:
+            self._enqueue_adam(B, apply=False, want_grad=True)
+            allreduce(self.grad)
+            self._enqueue_adam(B, apply=True, from_grad=True)
+
+    def train_step_graph(self, ids: torch.Tensor, labels: torch.Tensor, timed: bool = False):
+        """Same as train_step through captured hipGraphs (one set per batch size): one graph launch
+        per step.  timed=True (bench.py, every Nth step) replays the step as [scores graph] ->
+        eager choose+aggregate bracketed by HIP events -> [dense+Adam graph]; same kernels, same order."""
+        B = ids.numel()
+        if B == 0:
+            return
+        if B > self.maxB:
+            self._alloc(B)
+            self._graphs.clear()
+        self._lastB = B
+        gr = self._graphs.get(B)
+        if gr is None:
+            gr = self._capture(B)
+        self.ids_buf[:B].copy_(ids)
+        self.lab_buf[:B].copy_(labels)
+        if timed and self._prof is not None:
+            gr["pre"].replay()
+            self._enqueue_choose(self.ids_buf[:B], self.lab_buf[:B], B, self.keys if self.g.n_pos else None, True)
+            gr["post"].replay()
+        else:
+            gr["full"].replay()
+
+    def _capture(self, B):
+        ids, lab = self.ids_buf[:B], self.lab_buf[:B]
+        keys = self.keys if self.g.n_pos else None
+        g = self.g
+        agg = self.agg.view(-1)[:g.R * B * g.feat_dim].view(g.R, B, g.feat_dim)
+
+        def pre():
+            self._enqueue_scores(True)
+
+        def post():
+            self._enqueue_dense(ids, lab, B, agg, True)
+            self._enqueue_adam(B, apply=True)
+
+        def full():
+            pre()
+            self._enqueue_choose(ids, lab, B, keys, True)
+            post()
+
+        # warm up on a side stream (sets kernel attributes) and put the optimizer state back afterwards
+        state = (self.theta.clone(), self.m.clone(), self.v.clone(), self.step_counter.clone())
+        prof, self._prof = self._prof, None
+        s = torch.cuda.Stream(self.dev)
+        s.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(s):
+            full()
+        torch.cuda.current_stream(self.dev).wait_stream(s)
+        graphs = {}
+        for name, fn in (("full", full), ("pre", pre), ("post", post)):
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                fn()
+            graphs[name] = gr
+        for dst, src in zip((self.theta, self.m, self.v, self.step_counter), state):
+            dst.copy_(src)
+        self._prof = prof
+        self._graphs[B] = graphs
+        return graphs
+
+    def last_loss(self) -> torch.Tensor:
+        B = self._lastB
+        return self.row_loss[:B].sum() / (B * self.scale)
+
+    def gradients(self, ids: torch.Tensor, labels: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """loss.backward() without the optimizer step: per-parameter gradients (parity tests)."""
+        B = ids.numel()
+        agg, _ = self._enqueue_sample(ids, labels, B, True)
+        self._enqueue_dense(ids, labels, B, agg, True)
+        self.step_counter -= 1                   # dense_step counted a step that is not taken
+        self._enqueue_adam(B, apply=False, want_grad=True)
+        self._lastB = B
+        out = {}
+        for name, view in self.views.items():
+            off = view.storage_offset()
+            out[name] = self.grad[off:off + view.numel()].view(view.shape).clone()
+        return out
+
+    def predict(self, ids: torch.Tensor, labels: Optional[torch.Tensor] = None, train_flag: bool = False,
+                want_combined: bool = False):
+        """forward only -> (gnn logits [B,2], label-aware logits [B,2][, combined [B,E]])
+        (PCALayer.forward, model.py:34-39; utils.py:305 calls it with train_flag=False)."""
+        B = ids.numel()
+        if B > self.maxB:
+            self._alloc(B)
+            self._graphs.clear()
+        agg, _ = self._enqueue_sample(ids, labels, B, train_flag)
+        comb = torch.empty(B, self.E, dtype=torch.float32, device=self.dev) if want_combined else None
+        self._enqueue_dense(ids, None, B, agg, False, combined=comb)
+        res = (self.logits[:B].clone(), self.center[:B].clone())
+        return res + (comb,) if want_combined else res

@@ -21,7 +21,7 @@ from .model import PCALayer
 from .sampler import PickSampler
 
 DEFAULTS = dict(model="PCGNN", emb_size=64, rho=0.5, alpha=2.0, lr=0.01, weight_decay=0.001, batch_size=1024,
-                epochs=1, seed=0)
+                epochs=1, seed=0, engine="graph")   # engine: "graph" (fused kernels in a hipGraph) | "fused" | "torch"
 
 
 class PCGNNTrainer:
@@ -40,9 +40,18 @@ class PCGNNTrainer:
         intras = [IntraAgg(feats, f, cfg["emb_size"], w.train_pos, cfg["rho"], cuda=True) for _ in w.csr]
         inter = InterAgg(feats, f, cfg["emb_size"], w.train_pos, self.graph, intras, cuda=True)   # :103-113
         self.model = PCALayer(2, inter, cfg["alpha"]).to(self.device)                 # :114,:122
-        self.opt = torch.optim.Adam([p for p in self.model.parameters() if p.requires_grad], lr=cfg["lr"],
-                                    weight_decay=cfg["weight_decay"])                 # :124
+        self.engine = cfg["engine"]
+        self.fused = None
+        self.opt = None
+        if self.engine == "torch":      # dense tail + Adam through torch autograd (generic, slower)
+            self.opt = torch.optim.Adam([p for p in self.model.parameters() if p.requires_grad], lr=cfg["lr"],
+                                        weight_decay=cfg["weight_decay"])             # :124
+        else:
+            from .fused import FusedPCGNN
+            self.fused = FusedPCGNN(self.model, cfg["lr"], cfg["weight_decay"], max_batch=cfg["batch_size"],
+                                    global_batch_scale=cfg.get("world_size", 1))
         self.labels_dev = torch.from_numpy(w.labels).to(self.device)
+        self.labels_i32 = self.labels_dev.to(torch.int32)
         self.sampler = PickSampler(w.idx_train, w.labels[w.idx_train], w.homo_deg[w.idx_train], self.device,
                                    seed=cfg["seed"])
         self.pick_size = 2 * len(w.train_pos)                                          # :130
@@ -60,8 +69,15 @@ class PCGNNTrainer:
         perm = torch.randperm(self.pick_size, device=self.device, generator=self._gen)
         return picked[perm]
 
-    def step(self, batch_ids: torch.Tensor) -> torch.Tensor:
+    def step(self, batch_ids: torch.Tensor, timed: bool = False) -> torch.Tensor:
         """One iteration of the batch loop (model_handler.py:147-153)."""
+        if self.fused is not None:
+            labels = self.labels_i32[batch_ids.long()]
+            if self.engine == "graph":
+                self.fused.train_step_graph(batch_ids, labels, timed)
+            else:
+                self.fused.train_step(batch_ids, labels)
+            return None
         labels = self.labels_dev[batch_ids.long()]
         self.opt.zero_grad(set_to_none=True)
         loss = self.model.loss(batch_ids, labels)

@@ -80,7 +80,7 @@ class ChooseWorkspace:
         lib = _lib.load()
         self.B = B
         nbytes = lib.pcg_choose_workspace_bytes(g.desc_ref(), B)
-        self.buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=g.device)
+        self.buf = torch.zeros(max(int(nbytes), 256), dtype=torch.uint8, device=g.device)   # counters start at zero
         self.status = torch.zeros(1, dtype=torch.int32, device=g.device)
 
 

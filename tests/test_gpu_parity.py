@@ -219,7 +219,7 @@ def oracle_sets(csr, n, nodes, labels, s0, train_pos, thr, rho, train):
 
 def hub_graph(seed, n, hub_degs, base_deg=6.0, feat=32):
     """Graph with explicit hub rows (node i gets hub_degs[i] neighbours) to drive the
-    block path (deg > 2048) and the global-scratch path (deg > 24576)."""
+    4-wave / 16-wave tiers (deg > 512 / > 8192) and the global-scratch path (deg > 12288)."""
     X, labels, csrs = synth_graph(seed, n, feat, (base_deg,), 0.1, hub=False)
     indptr, idx = csrs[0]
     rs = np.random.RandomState(seed + 1)
@@ -235,7 +235,7 @@ def hub_graph(seed, n, hub_degs, base_deg=6.0, feat=32):
 def test_hub_rows_block_and_scratch_paths(P, quantize):
     ops = P.ops
     n = 60000
-    hub_degs = [30000, 9000, 2500, 2049, 2048, 2047, 1000, 65, 64, 63]
+    hub_degs = [30000, 13000, 12289, 12288, 12287, 9000, 8193, 8192, 8191, 2500, 513, 512, 511, 65, 64, 63]
     X, labels, csr = hub_graph(11, n, hub_degs)
     if quantize:   # many exact distance ties: the positional tie-break must match the oracle
         X = np.round(X * 2) / 2
@@ -248,7 +248,7 @@ def test_hub_rows_block_and_scratch_paths(P, quantize):
     s0 = ops.score_table(g, W, b)
     keys = ops.pos_sort(g, s0)
     nodes = list(range(len(hub_degs))) + [0, 1, 777, 778]
-    lab = [1, 0, 1, 1, 0, 1, 1, 1, 0, 1, 1, 0, 1, 0]
+    lab = ([1, 0, 1, 1, 0, 1, 1, 1, 0, 1, 1, 0, 1, 0] * 2)[:len(nodes)]
     for rho in (0.5, 2.0):
         sets, agg, cnt = ops.chosen_sets(g, torch.tensor(nodes, dtype=torch.int32, device=dev()),
                                          torch.tensor(lab, dtype=torch.int32, device=dev()), s0, keys, [0.5], rho, True)
@@ -357,3 +357,87 @@ def test_intra_agg_reference_signature(P, case):
     pos_scores = table[torch.as_tensor(c.train_pos)]
     feats, _ = m.inter1.intra_agg1.forward(c.nodes, c.batch_labels, lists, center, nscores, pos_scores, samples, False)
     np.testing.assert_allclose(feats.detach().cpu().numpy(), c.z["test_feats0"], rtol=0, atol=FEAT_TOL)
+
+
+@pytest.mark.parametrize("n_pos", [1, 63, 64, 65, 4096, 16384, 16385, 40000])
+def test_pos_sort_sizes(P, n_pos):
+    """rank sort (<= 16384) and bitonic (> 16384) paths, incl. duplicate scores."""
+    ops = P.ops
+    n = 50000
+    rs = np.random.RandomState(n_pos)
+    X = np.zeros((n, 4), np.float32)
+    indptr = np.arange(n + 1, dtype=np.int64)
+    g = P.DeviceGraph(X, [(indptr, np.arange(n, dtype=np.int32))], rs.choice(n, size=n_pos, replace=False).tolist(), dev())
+    s0h = np.round(rs.randn(n).astype(np.float32), 2)          # many equal scores, both signs, +-0
+    s0h[rs.randint(0, n, 50)] = -0.0
+    keys = ops.pos_sort(g, torch.from_numpy(s0h).cuda()).cpu().numpy().view(np.uint64)
+    pos = (keys[:n_pos] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    sc = s0h[g.train_pos_host]
+    # order: by score (with -0.0 < +0.0 as the orderable bit pattern has it), then by position
+    bits = sc.view(np.uint32).astype(np.int64)
+    ordk = np.where(bits & 0x80000000, (~bits) & 0xFFFFFFFF, bits | 0x80000000)
+    assert np.array_equal(pos, np.lexsort((np.arange(n_pos), ordk)))
+    assert np.all(keys[n_pos:] == np.uint64(0xFFFFFFFFFFFFFFFF))
+
+
+# ---------------------------------------------------------------------------
+# fused dense step + Adam (hand-written MFMA kernels) and the hipGraph-captured step
+# ---------------------------------------------------------------------------
+def fused_of(P, c, rho, **kw):
+    from pcgnn_amd.fused import FusedPCGNN
+    m = build_model(P, c, rho, graph=graph_of(P, c))
+    return m, FusedPCGNN(m, c.lr, c.wd, max_batch=len(c.nodes), **kw)
+
+
+def test_fused_forward_grads_adam_golden(P, case):
+    c = case
+    rho = c.rhos[0]
+    tag = f"rho{rho}"
+    m, fz = fused_of(P, c, rho)
+    ids = torch.tensor(c.nodes, dtype=torch.int32, device=dev())
+    lab = torch.from_numpy(c.batch_labels.astype(np.int32)).cuda()
+    # inference and training forward
+    lg, cs, comb = fz.predict(ids, None, False, want_combined=True)
+    np.testing.assert_allclose(torch.sigmoid(lg).cpu().numpy(), c.z["test_gnn_prob"], rtol=0, atol=LOGIT_TOL)
+    np.testing.assert_allclose(comb.cpu().numpy().T, c.z["test_combined"], rtol=0, atol=FEAT_TOL)
+    lg, cs = fz.predict(ids, lab, True)
+    np.testing.assert_allclose(lg.cpu().numpy(), c.z[f"{tag}_train_logits"], rtol=0, atol=LOGIT_TOL)
+    np.testing.assert_allclose(cs.cpu().numpy(), c.z[f"{tag}_train_center_scores"], rtol=0, atol=1e-5)
+    # gradients of every parameter
+    grads = fz.gradients(ids, lab)
+    assert abs(float(fz.last_loss()) - float(c.z[tag + "_loss"])) < LOGIT_TOL
+    for k in PARAM_KEYS(c.R):
+        np.testing.assert_allclose(grads[k].cpu().numpy(), c.z[f"{tag}_grad_{k}"], rtol=0, atol=2e-5, err_msg=k)
+    # one Adam step
+    fz.train_step(ids, lab)
+    sd = m.state_dict()
+    for k in PARAM_KEYS(c.R):
+        np.testing.assert_allclose(sd[k].cpu().numpy(), c.z[f"{tag}_step_{k}"], rtol=0, atol=c.lr * 5e-2, err_msg=k)
+    assert int(fz.step_counter.item()) == 1
+
+
+def test_fused_graph_equals_eager_and_torch(P, case):
+    """Five steps: hipGraph replay == eager fused launches bit for bit; both track the
+    torch-autograd + torch.optim.Adam path."""
+    c = case
+    rho = c.rhos[0]
+    ids = torch.tensor(c.nodes, dtype=torch.int32, device=dev())
+    lab = torch.from_numpy(c.batch_labels.astype(np.int32)).cuda()
+    m1, f1 = fused_of(P, c, rho)
+    m2, f2 = fused_of(P, c, rho)
+    m3 = build_model(P, c, rho, graph=graph_of(P, c))
+    opt = torch.optim.Adam([p for p in m3.parameters() if p.requires_grad], lr=c.lr, weight_decay=c.wd)
+    half = len(c.nodes) // 2
+    for step in range(5):
+        sl = slice(0, None) if step % 2 == 0 else slice(0, half)     # two batch sizes -> two graphs
+        f1.train_step(ids[sl], lab[sl])
+        f2.train_step_graph(ids[sl], lab[sl])
+        opt.zero_grad()
+        m3.loss(ids[sl], lab[sl].long()).backward()
+        opt.step()
+    torch.cuda.synchronize()
+    assert torch.equal(f1.theta, f2.theta), "graph replay must reproduce the eager fused step exactly"
+    sd1, sd3 = m1.state_dict(), m3.state_dict()
+    for k in PARAM_KEYS(c.R):
+        np.testing.assert_allclose(sd1[k].cpu().numpy(), sd3[k].cpu().numpy(), rtol=0, atol=c.lr * 0.25, err_msg=k)
+    assert abs(float(f1.last_loss()) - float(f2.last_loss())) == 0.0
