@@ -91,7 +91,7 @@ int pcg_score_rows(const pcg_graph_desc *g, const float *W, const float *b,
 int64_t pcg_pos_sort_capacity(int32_t n_pos);
 int pcg_pos_sort(const pcg_graph_desc *g, const float *s0, uint64_t *keys, void *stream);
 
-/* ---- choose + aggregate (the hot kernel) ---------------------------------------
+/* ---- choose + aggregate (the hot path) ----------------------------------------------
  * Replaces, for every relation r and batch centre b:
  *   neighbour lookup + score slicing            layers.py:217-219, 246-253
  *   num_sample = ceil(deg * threshold[r])        layers.py:260-262
@@ -103,33 +103,51 @@ int pcg_pos_sort(const pcg_graph_desc *g, const float *s0, uint64_t *keys, void 
  * m = min(int(k*rho[r]), n_pos) training positives nearest in the same metric, ties
  * by position in train_pos; the union is de-duplicated (set(), layers.py:694).
  *
+ * pcg_choose_select writes every row's chosen ids into the workspace's selection list
+ * (row = r * B + b; region [row_begin[row], row_begin[row] + len[row]); -1 marks a slot
+ * whose candidate was a duplicate) and |set| into cnt; pcg_aggregate_lists gathers and
+ * averages those lists from a feature table (the graph's X, or on a multi-GPU run a
+ * table extended by the rows fetched from other ranks after the list was re-indexed);
+ * pcg_choose_aggregate = both, for one GPU.
+ *
  *   nodes   int32 [B]   batch centre ids (duplicates allowed)
  *   labels  int32 [B]   batch labels; may be NULL when train_flag == 0
  *   s0      float [n_nodes] from pcg_score_table;  pos_keys from pcg_pos_sort
  *   center_s0 float [B] or NULL: the centres' class-0 logits if they are not to be
  *           read from s0[nodes[b]] (IntraAgg.forward called with explicit
  *           batch_scores, layers.py:562)
- *   agg     float [n_rel, B, agg_stride]  mean of the chosen rows (cols < feat_dim)
- *   cnt     int32 [n_rel, B] or NULL      |chosen set|
- * Optional materialisation of the chosen index sets (parity tests, callers that
- * want samp_neighs): sel_begin int64 [n_rel*B] (start of row (r,b) inside
- * sel_indices, caller-computed upper-bound layout, see pcg_sel_capacity_row),
- * sel_indices int32 [sel_capacity]; pass NULL/NULL/0 to skip.
- *   workspace: pcg_choose_workspace_bytes(g, B) bytes, 256-byte aligned; its first 256
- *              bytes must be ZERO before the first call (every call leaves them zero).
- *   status   : uint32 device word, OR-ed with PCG_ST_* bits (zero it yourself). */
-int64_t pcg_choose_workspace_bytes(const pcg_graph_desc *g, int32_t B);
+ *   thresholds, rho  HOST double [n_rel]
+ *   add_self 1: the centre joins its own set (GCN / SAGE-gcn, graphsage.py:78-79, 214)
+ *   cnt     int32 [n_rel * B]             |chosen set|
+ *   agg     float [n_rel * B, agg_stride] mean of the chosen rows (cols < feat_dim);
+ *           norm = PCG_NORM_COUNT | PCG_NORM_SQRT_COUNT (graphsage.py:224-226)
+ *   workspace: pcg_choose_workspace_bytes(g, B, list_capacity) bytes, 256-byte aligned;
+ *           list_capacity (< 2^31 entries) bounds sum over rows of
+ *           pcg_sel_capacity_row(...); if a batch needs more, nothing is selected and
+ *           PCG_ST_SEL_OVERFLOW is OR-ed into *status (uint32 device word; zero it yourself).
+ *   pcg_choose_workspace_offset(..., which): byte offset inside the workspace of
+ *           0 row_begin int64 [rows+1] | 1 len int32 [rows] | 2 list int32 [list_capacity]
+ *           (3 chunk_begin, 4 chunk_row, 5 counters, 6 partial: internal, exposed for tests). */
+int64_t pcg_choose_workspace_bytes(const pcg_graph_desc *g, int32_t B, int64_t list_capacity);
+int64_t pcg_choose_workspace_offset(const pcg_graph_desc *g, int32_t B, int64_t list_capacity, int32_t which);
+int pcg_choose_select(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B,
+                      const float *s0, const float *center_s0, const uint64_t *pos_keys,
+                      const double *thresholds, const double *rho, int32_t train_flag, int32_t add_self,
+                      int32_t *cnt, void *workspace, int64_t list_capacity, uint32_t *status, void *stream);
+int pcg_aggregate_lists(const float *X, int32_t feat_dim, int32_t feat_stride, int32_t n_rows, const int32_t *cnt,
+                        const pcg_graph_desc *g, int32_t B, void *workspace, int64_t list_capacity,
+                        int32_t norm, float *agg, int32_t agg_stride, void *stream);
 int pcg_choose_aggregate(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B,
                          const float *s0, const float *center_s0, const uint64_t *pos_keys,
-                         const double *thresholds /* host [n_rel] */, const double *rho /* host [n_rel] */,
-                         int32_t train_flag,
-                         int32_t norm, int32_t add_self,
-                         float *agg, int32_t agg_stride, int32_t *cnt,
-                         const int64_t *sel_begin, int32_t *sel_indices, int64_t sel_capacity,
-                         void *workspace, uint32_t *status, void *stream);
+                         const double *thresholds, const double *rho, int32_t train_flag,
+                         int32_t norm, int32_t add_self, float *agg, int32_t agg_stride, int32_t *cnt,
+                         void *workspace, int64_t list_capacity, uint32_t *status, void *stream);
 
-/* Upper bound on |chosen set| of one row, what the caller lays sel_begin out with
- * (host helper, pure arithmetic): (deg > k+1 ? k : deg) + m [+1 if add_self]. */
+/* diagnostic only: per-row phase timestamps of the select kernels ([rows][8] uint64, 10-ns ticks); NULL = off */
+void pcg_debug_set_stamps(void *ptr);
+
+/* Upper bound on |chosen set| of one row (host helper, pure arithmetic):
+ * (deg > k+1 ? k : deg) + m [+1 if add_self]. */
 int64_t pcg_sel_capacity_row(int64_t deg, double threshold, double rho, int32_t positive_train,
                              int32_t n_pos, int32_t add_self);
 

@@ -43,9 +43,14 @@ PROTOTYPES = {
     "pcg_score_rows": (C.c_int, [_G, _P, _P, _P, _I32, _P, _P]),
     "pcg_pos_sort_capacity": (_I64, [_I32]),
     "pcg_pos_sort": (C.c_int, [_G, _P, _P, _P]),
-    "pcg_choose_workspace_bytes": (_I64, [_G, _I32]),
-    "pcg_choose_aggregate": (C.c_int, [_G, _P, _P, _I32, _P, _P, _P, C.POINTER(_F64), C.POINTER(_F64), _I32, _I32, _I32,
-                                       _P, _I32, _P, _P, _P, _I64, _P, _P, _P]),
+    "pcg_choose_workspace_bytes": (_I64, [_G, _I32, _I64]),
+    "pcg_choose_workspace_offset": (_I64, [_G, _I32, _I64, _I32]),
+    "pcg_choose_select": (C.c_int, [_G, _P, _P, _I32, _P, _P, _P, C.POINTER(_F64), C.POINTER(_F64), _I32, _I32,
+                                    _P, _P, _I64, _P, _P]),
+    "pcg_aggregate_lists": (C.c_int, [_P, _I32, _I32, _I32, _P, _G, _I32, _P, _I64, _I32, _P, _I32, _P]),
+    "pcg_choose_aggregate": (C.c_int, [_G, _P, _P, _I32, _P, _P, _P, C.POINTER(_F64), C.POINTER(_F64), _I32, _I32,
+                                       _I32, _P, _I32, _P, _P, _I64, _P, _P]),
+    "pcg_debug_set_stamps": (None, [_P]),
     "pcg_sel_capacity_row": (_I64, [_I64, _F64, _F64, _I32, _I32, _I32]),
     "pcg_segment_mean": (C.c_int, [_G, _P, _P, _P, _I32, _I32, _P, _I32, _P]),
     "pcg_pick": (C.c_int, [_P, _P, _I32, _P, _U64, _U64, _I32, _P, _P]),

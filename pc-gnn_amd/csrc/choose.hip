@@ -1,0 +1,1136 @@
+// choose + aggregate for gfx950: the PC-GNN hot path in four kinds of launches.
+//
+//   plan     one workgroup: per (relation r, centre b) row the kept-count bound
+//            cap = (deg > k+1 ? k : deg) + m (+1), exclusive offsets into the selection
+//            list, the degree-tier queues and the 256-entry chunk table of the gather.
+//   select   one group per row, group size by row length (<=512: one wave, <=4096: a
+//            256-thread workgroup, longer: 1024 threads; > 12288 via global scratch):
+//              1. neighbour ids + distance keys |s0[c] - s0[j]| -> LDS (4 gathers in flight)
+//              2. exact k-th smallest key by a bracketed counting search (interpolation in
+//                 value space alternating with bit-space bisection; <= 64 survivors are
+//                 ranked on registers); ties by row position via ballot prefix counts
+//              3. kept ids compacted (ascending) in LDS and written to the row's list
+//              4. minority over-sampling for positive centres: 64-ary window search in the
+//                 per-step sorted train-pos keys; de-duplicated against (3) by LDS binary
+//                 search; a duplicate leaves a hole (-1) so slots - and sums - keep a fixed order
+//   gather   chip-wide balanced: one wave per 256-entry chunk of a row's list, feature rows
+//            gathered 64/lpr per wave-instruction (128-B rows: 8 rows = 1 KiB), 8 in flight,
+//            f32 segmented sum; single-chunk rows are finished here
+//   combine  rows longer than one chunk: partial sums added in chunk order (bitwise
+//            reproducible), divided by |set| (or its sqrt)
+//
+// Reference lines replaced: src/layers.py:217-219, 246-262, 587-624, 633-738;
+// src/graphsage.py:62-96, 200-232 (keep-all + add_self + sqrt normalisation).
+#include <limits.h>
+
+#include "common.h"
+
+namespace pcg {
+
+constexpr int T1_CAP = 512;      // row length handled by a single wave
+constexpr int T4_CAP = 4096;     // ... by a 4-wave workgroup
+constexpr int T16_CAP = 12288;   // ... by a 16-wave workgroup with ids+keys in LDS; longer rows: global scratch
+constexpr int T1_WAVES_PER_BLOCK = 4;
+constexpr int N_T4_BLOCKS = 1024;
+constexpr int N_T16_BLOCKS = 256;
+constexpr int CHUNK = 256;       // list entries per gather work item
+constexpr int UNROLL = 8;        // row-gather instructions in flight per wave
+constexpr int KEY_UNROLL = 4;    // neighbour-score gathers in flight per lane
+constexpr int PLAN_THREADS = 1024;
+constexpr int GATHER_BLOCKS = 2048;
+
+// counters (uint32) at the head of the workspace
+enum { C_N1 = 0, C_N4 = 1, C_N16 = 2, C_HEAD4 = 3, C_HEAD16 = 4, C_NCHUNK = 5, C_TOTAL_LO = 6, C_TOTAL_HI = 7 };
+
+struct RowRec {            // 32 bytes, written by plan, read by select (one 32-B load instead of a 3-deep chain)
+    int64_t start;         // offset of the row in indices[r]
+    int32_t node, d, k, m;
+    float c;               // the centre's class-0 logit
+    int32_t keep_all;
+};
+
+struct Workspace {
+    uint32_t *counters;    // [64]
+    int64_t *row_begin;    // [rows + 1] start of every row's region in list
+    int32_t *chunk_begin;  // [rows + 1]
+    int32_t *len;          // [rows]     entries (holes included) actually written
+    int32_t *q1, *q4, *q16;  // [rows] each
+    struct RowRec *recs;   // [rows] what plan worked out per row
+    int32_t *chunk_row;    // [chunk_cap]
+    float *partial;        // [chunk_cap, feat_stride]
+    int32_t *list;         // [list_capacity]  chosen ids; -1 = hole
+    uint32_t *scratch;     // [N_T16_BLOCKS * 3 * max_degree] when max_degree > T16_CAP
+    int64_t list_capacity, chunk_cap;
+};
+
+static int64_t align256(int64_t x) { return (x + 255) / 256 * 256; }
+
+static int64_t carve(const pcg_graph_desc *g, int32_t B, int64_t list_capacity, unsigned char *base, Workspace *w) {
+    const int64_t rows = (int64_t)g->n_rel * B;
+    const int64_t chunk_cap = list_capacity / CHUNK + rows + 1;
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) {
+        const int64_t o = off;
+        off += align256(bytes);
+        return base ? base + o : nullptr;
+    };
+    unsigned char *p;
+    p = take(256);                                 if (w) w->counters = reinterpret_cast<uint32_t *>(p);
+    p = take(8 * (rows + 1));                      if (w) w->row_begin = reinterpret_cast<int64_t *>(p);
+    p = take(4 * (rows + 1));                      if (w) w->chunk_begin = reinterpret_cast<int32_t *>(p);
+    p = take(4 * rows);                            if (w) w->len = reinterpret_cast<int32_t *>(p);
+    p = take(4 * rows);                            if (w) w->q1 = reinterpret_cast<int32_t *>(p);
+    p = take(4 * rows);                            if (w) w->q4 = reinterpret_cast<int32_t *>(p);
+    p = take(4 * rows);                            if (w) w->q16 = reinterpret_cast<int32_t *>(p);
+    p = take(32 * rows);                           if (w) w->recs = reinterpret_cast<RowRec *>(p);
+    p = take(4 * chunk_cap);                       if (w) w->chunk_row = reinterpret_cast<int32_t *>(p);
+    p = take(4 * chunk_cap * g->feat_stride);      if (w) w->partial = reinterpret_cast<float *>(p);
+    p = take(4 * list_capacity);                   if (w) w->list = reinterpret_cast<int32_t *>(p);
+    p = take(g->max_degree > T16_CAP ? (int64_t)N_T16_BLOCKS * 3 * g->max_degree * 4 : 0);
+    if (w) {
+        w->scratch = reinterpret_cast<uint32_t *>(p);
+        w->list_capacity = list_capacity;
+        w->chunk_cap = chunk_cap;
+    }
+    return off;
+}
+
+struct ChooseArgs {
+    pcg_graph_desc g;
+    const int32_t *nodes;
+    const int32_t *labels;
+    int32_t B;
+    const float *s0;
+    const float *center_s0;
+    const uint64_t *pos_keys;
+    double thr[PCG_MAX_REL];
+    double rho[PCG_MAX_REL];
+    int32_t train_flag, add_self;
+    int32_t *cnt;          // [rows] |chosen set|
+    uint32_t *status;
+    unsigned long long *stamps;   // diagnostic only (pcg_debug_set_stamps): [rows][8] wall-clock ticks per phase, else null
+    Workspace w;
+};
+
+#define PCG_STAMP(slot)                                                               \
+    do {                                                                              \
+        if (a.stamps && tid == 0) a.stamps[(size_t)row * 8 + (slot)] = wall_clock64(); \
+    } while (0)
+
+__device__ __forceinline__ RowRec row_plan(const ChooseArgs &a, int row) {
+    RowRec p;
+    const int r = row / a.B, b = row - r * a.B;
+    p.node = a.nodes[b];
+    p.start = a.g.indptr[r][p.node];
+    p.d = (int)(a.g.indptr[r][p.node + 1] - p.start);
+    p.k = (int)ceil((double)p.d * a.thr[r]);             // layers.py:260
+    p.keep_all = !(p.d > p.k + 1);                       // layers.py:662
+    p.m = 0;
+    if (a.train_flag && a.labels[b] == 1) {              // layers.py:675
+        p.m = (int)((double)p.k * a.rho[r]);             // layers.py:681
+        if (p.m > a.g.n_pos) p.m = a.g.n_pos;
+        if (p.m < 0) p.m = 0;
+    }
+    p.c = a.center_s0 ? a.center_s0[b] : a.s0[p.node];
+    return p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// plan
+// ---------------------------------------------------------------------------------------------
+// exclusive scan of one value per thread over the block; returns the block total through `total`
+template <typename T>
+__device__ __forceinline__ T block_excl_scan(T v, T *lds /* >= waves */, T &total) {
+    const int lane = lane_id(), wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    T inc = v;
+    for (int o = 1; o < PCG_WAVE; o <<= 1) {
+        const T t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    if (lane == PCG_WAVE - 1) lds[wave] = inc;
+    __syncthreads();
+    T pre = 0, tot = 0;
+    for (int w = 0; w < nw; ++w) {
+        const T x = lds[w];
+        if (w < wave) pre += x;
+        tot += x;
+    }
+    __syncthreads();
+    total = tot;
+    return pre + inc - v;
+}
+
+constexpr int PLAN_PER = 4;     // rows per thread per tile
+
+__global__ void __launch_bounds__(PLAN_THREADS) plan_kernel(const ChooseArgs a) {
+    __shared__ int lds[PLAN_THREADS / PCG_WAVE];
+    __shared__ long long lds64[PLAN_THREADS / PCG_WAVE];
+    const int rows = a.g.n_rel * a.B;
+    long long run_cap = 0;
+    int run_chunk = 0, run1 = 0, run4 = 0, run16 = 0;
+    bool overflow = false;
+    for (int tile0 = 0; tile0 < rows; tile0 += PLAN_THREADS * PLAN_PER) {
+        const int r0 = tile0 + threadIdx.x * PLAN_PER;
+        RowRec rec[PLAN_PER];
+        int cap[PLAN_PER];
+        long long cap_sum = 0;
+        int chunk_sum = 0, n1 = 0, n4 = 0, n16 = 0;
+#pragma unroll
+        for (int i = 0; i < PLAN_PER; ++i) {
+            const int row = r0 + i;
+            cap[i] = 0;
+            if (row < rows) {
+                rec[i] = row_plan(a, row);
+                cap[i] = (rec[i].keep_all ? rec[i].d : rec[i].k) + rec[i].m + (a.add_self ? 1 : 0);
+                cap_sum += cap[i];
+                chunk_sum += (cap[i] + CHUNK - 1) / CHUNK;
+                n1 += rec[i].d <= T1_CAP;
+                n4 += rec[i].d > T1_CAP && rec[i].d <= T4_CAP;
+                n16 += rec[i].d > T4_CAP;
+            }
+        }
+        long long t_cap;
+        int t_chunk, t1, t4, t16;
+        long long o_cap = run_cap + block_excl_scan<long long>(cap_sum, lds64, t_cap);
+        int o_chunk = run_chunk + block_excl_scan(chunk_sum, lds, t_chunk);
+        int o1 = run1 + block_excl_scan(n1, lds, t1);
+        int o4 = run4 + block_excl_scan(n4, lds, t4);
+        int o16 = run16 + block_excl_scan(n16, lds, t16);
+        run_cap += t_cap; run_chunk += t_chunk; run1 += t1; run4 += t4; run16 += t16;
+        overflow = overflow || run_cap > a.w.list_capacity || (long long)run_chunk > a.w.chunk_cap;
+#pragma unroll
+        for (int i = 0; i < PLAN_PER; ++i) {
+            const int row = r0 + i;
+            if (row >= rows) continue;
+            const int nch = (cap[i] + CHUNK - 1) / CHUNK;
+            a.w.row_begin[row] = o_cap;
+            a.w.chunk_begin[row] = o_chunk;
+            a.w.recs[row] = rec[i];
+            if (!overflow) {
+                for (int j = 0; j < nch; ++j) a.w.chunk_row[o_chunk + j] = row;
+                if (rec[i].d <= T1_CAP) a.w.q1[o1++] = row;
+                else if (rec[i].d <= T4_CAP) a.w.q4[o4++] = row;
+                else a.w.q16[o16++] = row;
+            }
+            o_cap += cap[i];
+            o_chunk += nch;
+        }
+    }
+    if (threadIdx.x == 0) {
+        a.w.row_begin[rows] = run_cap;
+        a.w.chunk_begin[rows] = run_chunk;
+        a.w.counters[C_N1] = overflow ? 0 : run1;
+        a.w.counters[C_N4] = overflow ? 0 : run4;
+        a.w.counters[C_N16] = overflow ? 0 : run16;
+        a.w.counters[C_HEAD4] = 0;
+        a.w.counters[C_HEAD16] = 0;
+        a.w.counters[C_NCHUNK] = overflow ? 0 : run_chunk;
+        if (overflow && a.status) atomicOr(a.status, (uint32_t)PCG_ST_SEL_OVERFLOW);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// select
+// ---------------------------------------------------------------------------------------------
+template <int NW>
+__device__ __forceinline__ void grp_sync() {
+    if constexpr (NW > 1) __syncthreads();
+}
+
+// exclusive prefix of a wave-uniform value over the group's waves, and the total
+template <int NW>
+__device__ __forceinline__ void grp_scan(int v, int wave, int lane, int *red, int &prefix, int &total) {
+    if constexpr (NW == 1) {
+        prefix = 0;
+        total = v;
+    } else {
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        int p = 0, t = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const int x = red[w];
+            if (w < wave) p += x;
+            t += x;
+        }
+        __syncthreads();
+        prefix = p;
+        total = t;
+    }
+}
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    for (int o = 1; o < PCG_WAVE; o <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_xor((int)v, o);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    for (int o = 1; o < PCG_WAVE; o <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_xor((int)v, o);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ bool sorted_contains(const uint32_t *list, int n, uint32_t x) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (list[mid] < x) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo < n && list[lo] == x;
+}
+
+__device__ __forceinline__ float pos_score(const uint64_t *pk, int i) { return from_orderable((uint32_t)(pk[i] >> 32)); }
+__device__ __forceinline__ uint32_t pos_dkey(const uint64_t *pk, int i, float c) { return dist_key(c, pos_score(pk, i)); }
+
+// First x in [lo, hi] with pred(x) false, pred being true on a prefix of [lo, hi).
+// 64 probes per step (one memory latency each) instead of one.
+template <class Pred>
+__device__ __forceinline__ int wave_partition_point(int lo, int hi, int lane, Pred pred) {
+    for (;;) {
+        const int n = hi - lo;
+        if (n <= 0) return lo;
+        if (n <= PCG_WAVE) {
+            const int idx = lo + lane;
+            return lo + wave_count(idx < hi && pred(idx));
+        }
+        const int step = (n + PCG_WAVE - 1) >> 6;
+        int q = lo + (lane + 1) * step - 1;
+        if (q > hi - 1) q = hi - 1;
+        const int c = wave_count(pred(q));
+        if (c == PCG_WAVE) return hi;
+        int qc = lo + (c + 1) * step - 1;   // first probe that answered false
+        if (qc > hi - 1) qc = hi - 1;
+        if (c > 0) {
+            int ql = lo + c * step - 1;
+            if (ql > hi - 1) ql = hi - 1;
+            lo = ql + 1;
+        }
+        hi = qc;
+    }
+}
+
+// first index in [i0, end) whose distance key != kstar (or end); all lanes take part
+__device__ __forceinline__ int run_end_fwd(const uint64_t *pk, float c, uint32_t kstar, int i0, int end, int lane) {
+    for (int i = i0; i < end; i += PCG_WAVE) {
+        const int j = i + lane;
+        const bool same = j < end && pos_dkey(pk, j, c) == kstar;
+        const uint64_t bad = ~__ballot(same);
+        if (bad) {
+            const int f = i + (__ffsll((unsigned long long)bad) - 1);
+            return f < end ? f : end;
+        }
+    }
+    return end;
+}
+// smallest x in [low, i0+1] such that every index in [x, i0] has key == kstar (i0+1 if none)
+__device__ __forceinline__ int run_begin_bwd(const uint64_t *pk, float c, uint32_t kstar, int i0, int low, int lane) {
+    for (int i = i0; i >= low; i -= PCG_WAVE) {
+        const int j = i - lane;
+        const bool same = j >= low && pos_dkey(pk, j, c) == kstar;
+        const uint64_t bad = ~__ballot(same);
+        if (bad) {
+            const int f = i - (__ffsll((unsigned long long)bad) - 1);  // first non-matching going down
+            return (f >= low ? f : low - 1) + 1;
+        }
+    }
+    return low;
+}
+
+// rank of this lane's value among the valid lanes' values: lt = #smaller, eq = #equal (itself included)
+__device__ __forceinline__ void wave_rank(uint32_t v, bool valid, int &lt, int &eq) {
+    const uint64_t vm = __ballot(valid);
+    lt = 0;
+    eq = 0;
+    for (int j = 0; j < PCG_WAVE; ++j) {
+        if (!((vm >> j) & 1ull)) continue;                                   // wave-uniform
+        const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)v, j);    // j is wave-uniform: v_readlane
+        lt += o < v;
+        eq += o == v;
+    }
+}
+// r-th smallest (0-based) value among the valid lanes, given their (lt, eq)
+__device__ __forceinline__ uint32_t wave_order_stat(uint32_t v, bool valid, int lt, int eq, int r) {
+    const uint64_t hit = __ballot(valid && lt <= r && r < lt + eq);
+    const int src = __ffsll((unsigned long long)hit) - 1;
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, src < 0 ? 0 : src);
+}
+
+// One counting pass over cur[0..n): c1 = #keys in [lo, p1), c2 = #keys in [lo, p2) (p1 <= p2 <= hi+1);
+// if `mid` is given, the keys in [p1, p2) are also copied there (any order) - the survivors if the
+// wanted rank falls between the pivots.  cnts: 3 LDS ints (NW > 1).
+template <int NW>
+__device__ __forceinline__ void count_pass(const uint32_t *cur, int n, uint32_t lo, uint32_t hi, uint32_t p1,
+                                           uint32_t p2, uint32_t *mid, int wave, int lane, int *cnts, int &c1,
+                                           int &c2) {
+    constexpr int NT = NW * PCG_WAVE;
+    if constexpr (NW > 1) {
+        if (threadIdx.x < 3) cnts[threadIdx.x] = 0;
+        __syncthreads();
+    }
+    int a1 = 0, a2 = 0, nm = 0;
+    for (int base = wave * PCG_WAVE; base < n; base += NT) {   // wave-uniform trip count
+        const int i = base + lane;
+        const uint32_t key = i < n ? cur[i] : 0xFFFFFFFFu;
+        const bool in = i < n && key >= lo && key <= hi;
+        const bool b1 = in && key < p1, b2 = in && key < p2;
+        a1 += wave_count(b1);
+        const uint64_t m2 = __ballot(b2);
+        a2 += __popcll(m2);
+        if (mid) {
+            const uint64_t mm = __ballot(b2 && !b1);
+            const int c = __popcll(mm);
+            int at = nm;
+            if constexpr (NW > 1) {
+                int o = 0;
+                if (lane == 0 && c) o = atomicAdd(&cnts[2], c);
+                at = __builtin_amdgcn_readfirstlane(o);
+            }
+            if (b2 && !b1) mid[at + __popcll(mm & lanemask_lt())] = key;
+            nm += c;
+        }
+    }
+    if constexpr (NW == 1) {
+        c1 = a1;
+        c2 = a2;
+    } else {
+        if (lane == 0) {
+            atomicAdd(&cnts[0], a1);
+            atomicAdd(&cnts[1], a2);
+        }
+        __syncthreads();
+        c1 = cnts[0];
+        c2 = cnts[1];
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// One (relation, centre) row: choose; write the row's region of the list.
+// ---------------------------------------------------------------------------
+// keys: >= deg uint32, distance keys, later the kept ids (compacted, ascending); ids: >= deg, the row's
+// neighbour ids; ckeys: >= deg, survivors of the first counting pass; cand: 64; red: 2*NW+2 ints (NW > 1).  All LDS, except keys/ids of an over-long hub row
+// (global scratch) - a separate instantiation, so that the LDS ones compile to ds_* instructions.
+template <int NW>
+__device__ __forceinline__ void select_row(const ChooseArgs &a, int row, uint32_t *keys, uint32_t *ids, uint32_t *ckeys,
+                                           uint32_t *cand, int *red) {
+    const int lane = lane_id();
+    const int wave = (NW > 1) ? (int)(threadIdx.x >> 6) : 0;
+    const int tid = wave * PCG_WAVE + lane;
+    constexpr int NT = NW * PCG_WAVE;
+
+    PCG_STAMP(0);
+    const RowRec p = a.w.recs[row];
+    const int d = p.d, k = p.k, m = p.m, node = p.node;
+    const bool keep_all = p.keep_all != 0;
+    const int r = row / a.B;
+    const int32_t *__restrict__ nbr = a.g.indices[r] + p.start;
+    const float c = p.c;
+    int32_t *__restrict__ out = a.w.list + a.w.row_begin[row];
+
+    // ---- 1. neighbour ids and distance keys -> LDS ----------------------------
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+    for (int base = tid; base < d; base += NT * KEY_UNROLL) {
+        uint32_t id[KEY_UNROLL];
+        float sc[KEY_UNROLL];
+#pragma unroll
+        for (int u = 0; u < KEY_UNROLL; ++u) {
+            const int i = base + u * NT;
+            id[u] = i < d ? (uint32_t)nbr[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < KEY_UNROLL; ++u) sc[u] = keep_all ? 0.f : a.s0[id[u]];
+#pragma unroll
+        for (int u = 0; u < KEY_UNROLL; ++u) {
+            const int i = base + u * NT;
+            if (i < d) {
+                ids[i] = id[u];
+                if (!keep_all) {
+                    const uint32_t key = dist_key(c, sc[u]);
+                    keys[i] = key;
+                    kmin = key < kmin ? key : kmin;
+                    kmax = key > kmax ? key : kmax;
+                }
+            }
+        }
+    }
+    grp_sync<NW>();
+    PCG_STAMP(1);
+
+    // ---- 2. k-th smallest key: bracketed counting search ------------------------
+    // invariant: the k-th smallest key lies in [lo, hi]; below = #keys < lo; ncand = #keys in [lo, hi]
+    uint32_t kstar = 0xFFFFFFFFu;
+    int need = 0;          // how many of the keys == kstar are kept (in position order)
+    int n_equal = 0;       // how many keys == kstar there are
+    if (!keep_all) {
+        kmin = wave_min_u32(kmin);
+        kmax = wave_max_u32(kmax);
+        if constexpr (NW > 1) {
+            if (lane == 0) {
+                red[wave] = (int)kmin;
+                red[NW + wave] = (int)kmax;
+            }
+            __syncthreads();
+            for (int w = 0; w < NW; ++w) {
+                const uint32_t x = (uint32_t)red[w], y = (uint32_t)red[NW + w];
+                kmin = x < kmin ? x : kmin;
+                kmax = y > kmax ? y : kmax;
+            }
+            __syncthreads();
+        }
+        uint32_t lo = kmin, hi = kmax;
+        int below = 0, ncand = d, round = 0;
+        const uint32_t *cur = keys;      // where the candidates live: the row's keys, or the compacted survivors
+        int n_cur = d;
+        while (ncand > PCG_WAVE && lo < hi) {
+            // two pivots p1 <= p2 in (lo, hi] bracket the wanted rank: interpolation in value space, the
+            // bracket sized to hold ~48 candidates if they were uniform (never narrower than 16 % of the
+            // interval); every 4th round is a bit-space midpoint, which bounds the rounds for any input
+            const uint32_t span = hi - lo;
+            uint32_t p1 = lo + (span >> 1) + (span & 1u), p2 = p1;           // bit-space midpoint, in (lo, hi]
+            if ((round & 3) != 3) {
+                const float lv = __uint_as_float(lo), hv = __uint_as_float(hi);
+                const float inv = 1.f / (float)ncand;
+                const float f = ((float)(k - below) - 0.5f) * inv;
+                const float w = fmaxf(0.08f, 24.f * inv);
+                const float g1 = lv + (f - w) * (hv - lv), g2 = lv + (f + w) * (hv - lv);
+                p1 = (g1 > lv && g1 <= hv) ? __float_as_uint(g1) : lo + 1;
+                p2 = (g2 > lv && g2 <= hv) ? __float_as_uint(g2) : hi + 1;    // hi + 1: no upper cut (keys < 2^31: no wrap)
+                if (p2 < p1) p2 = p1;
+            }
+            const bool first = cur == keys;
+            int c1, c2;
+            count_pass<NW>(cur, n_cur, lo, hi, p1, p2, first ? ckeys : nullptr, wave, lane, red, c1, c2);
+            if (below + c1 >= k) {              // k-th < p1
+                hi = p1 - 1;
+                ncand = c1;
+            } else if (below + c2 >= k) {       // p1 <= k-th < p2
+                lo = p1;
+                hi = p2 - 1;
+                below += c1;
+                ncand = c2 - c1;
+                if (first) {                    // the survivors were compacted on the way: later passes are short
+                    cur = ckeys;
+                    n_cur = ncand;
+                }
+            } else {                            // k-th >= p2
+                lo = p2;
+                below += c2;
+                ncand -= c2;
+            }
+            ++round;
+        }
+        if (a.stamps && tid == 0) a.stamps[(size_t)row * 8 + 7] = (unsigned long long)round | ((unsigned long long)ncand << 32);
+        if (lo == hi) {
+            kstar = lo;
+            need = k - below;
+            n_equal = ncand;
+        } else {
+            // <= 64 survivors: one per lane, ranked in-wave
+            if constexpr (NW > 1) {
+                if (threadIdx.x == 0) red[2] = 0;
+                __syncthreads();
+            }
+            int seen = 0;
+            for (int base = wave * PCG_WAVE; base < n_cur; base += NT) {
+                const int i = base + lane;
+                const uint32_t key = i < n_cur ? cur[i] : 0u;
+                const bool isc = i < n_cur && key >= lo && key <= hi;
+                const uint64_t bm = __ballot(isc);
+                const int cn = __popcll(bm);
+                int at = seen;
+                if constexpr (NW > 1) {
+                    int o = 0;
+                    if (lane == 0 && cn) o = atomicAdd(&red[2], cn);
+                    at = __builtin_amdgcn_readfirstlane(o);
+                }
+                if (isc) cand[at + __popcll(bm & lanemask_lt())] = key;
+                seen += cn;
+            }
+            grp_sync<NW>();
+            const bool have = lane < ncand;
+            const uint32_t ck = have ? cand[lane] : 0xFFFFFFFFu;
+            // MSB-first bisection on one register per lane, from the first bit in which lo and hi differ
+            int remaining = k - below, nc = ncand;
+            int bit = 31 - __clz((int)(lo ^ hi));
+            uint32_t prefix = (bit == 31) ? 0u : (lo & (0xFFFFFFFFu << (bit + 1)));
+            for (; bit >= 0; --bit) {
+                const uint32_t hm = (bit == 31) ? 0u : (0xFFFFFFFFu << (bit + 1));
+                const int c0 = wave_count(have && ((ck & hm) == prefix) && !((ck >> bit) & 1u));
+                if (remaining > c0) {
+                    remaining -= c0;
+                    prefix |= 1u << bit;
+                    nc -= c0;
+                } else {
+                    nc = c0;
+                }
+            }
+            kstar = prefix;
+            need = remaining;
+            n_equal = nc;
+            grp_sync<NW>();
+        }
+    }
+
+    PCG_STAMP(2);
+    // ---- 3. compaction of kept ids, ascending, into keys[] --------------------------
+    int ns = 0;
+    if (keep_all) {
+        ns = d;
+        for (int i = tid; i < d; i += NT) keys[i] = ids[i];
+    } else {
+        const bool ranked_ties = n_equal != need;   // some, not all, of the equal keys are kept
+        int ties_seen = 0;
+        for (int base = 0; base < d; base += NT) {
+            const int i = base + tid;
+            const bool in = i < d;
+            const uint32_t key = in ? keys[i] : 0u;
+            const uint32_t id = in ? ids[i] : 0u;
+            bool sel = in && key <= kstar;
+            if (ranked_ties) {
+                const bool tie = in && key == kstar;
+                const uint64_t tm = __ballot(tie);
+                int tpre, ttot;
+                grp_scan<NW>(__popcll(tm), wave, lane, red, tpre, ttot);
+                const int trank = ties_seen + tpre + __popcll(tm & lanemask_lt());
+                sel = in && (key < kstar || (tie && trank < need));
+                ties_seen += ttot;
+            }
+            const uint64_t sm = __ballot(sel);
+            int spre, stot;
+            grp_scan<NW>(__popcll(sm), wave, lane, red, spre, stot);   // its barriers order the reads above before the writes below
+            if (sel) keys[ns + spre + __popcll(sm & lanemask_lt())] = id;
+            ns += stot;
+        }
+    }
+    grp_sync<NW>();
+    const uint32_t *sel = keys;
+    for (int i = tid; i < ns; i += NT) out[i] = (int32_t)sel[i];
+    PCG_STAMP(3);
+
+    // ---- 4. minority over-sampling (layers.py:675-691): slots out[ns .. ns + mt) -----------
+    int mt = 0;        // slots used
+    int valid = 0;     // per-thread count of non-duplicate minority picks
+    if (m > 0) {
+        const uint64_t *__restrict__ pk = a.pos_keys;
+        const int P = a.g.n_pos;
+        int L, R, L2, R2, tau = INT_MAX, need_t = 0;
+        if (m >= P) {
+            L = L2 = 0;
+            R = R2 = P;
+        } else {
+            // window [lo, lo+m) of the m nearest: first lo whose left end is not farther than the element right of the window
+            const int lo = wave_partition_point(0, P - m, lane, [&](int x) {
+                return (c - pos_score(pk, x)) > (pos_score(pk, x + m) - c);
+            });
+            // one batch of six independent loads decides the usual tie-free case
+            const uint32_t NOKEY = 0xFFFFFFFEu;    // never equals a distance key (keys have bit 31 clear)
+            const uint32_t ka = pos_dkey(pk, lo, c), kb = pos_dkey(pk, lo + m - 1, c);
+            const uint32_t ka1 = m > 1 ? pos_dkey(pk, lo + 1, c) : NOKEY;
+            const uint32_t kb1 = m > 1 ? pos_dkey(pk, lo + m - 2, c) : NOKEY;
+            const uint32_t kl = lo > 0 ? pos_dkey(pk, lo - 1, c) : NOKEY;
+            const uint32_t kr = lo + m < P ? pos_dkey(pk, lo + m, c) : NOKEY;
+            const uint32_t ks = ka > kb ? ka : kb;  // m-th smallest distance
+            const bool tie_l = ka == ks, tie_r = kb == ks;
+            const bool none_outside = kl != ks && kr != ks;
+            if (none_outside && m == 1) {                  // the window is one element; it is the single tie
+                L2 = lo;
+                L = R = R2 = lo + 1;
+            } else if (none_outside && !(tie_l && tie_r) && (tie_l ? ka1 != ks : kb1 != ks)) {
+                // exactly one element at distance ks, at one end of the window; no tie outside it
+                L2 = L = tie_l ? lo + 1 : lo;
+                R = R2 = tie_l ? lo + m : lo + m - 1;
+                if (tie_l) L2 = lo; else R2 = lo + m;      // that one element is the (single) tie, and it is taken
+            } else {
+                L = run_end_fwd(pk, c, ks, lo, lo + m, lane);
+                R = (L == lo + m) ? L : run_begin_bwd(pk, c, ks, lo + m - 1, L, lane);
+                L2 = run_begin_bwd(pk, c, ks, lo - 1, 0, lane);
+                R2 = run_end_fwd(pk, c, ks, lo + m, P, lane);
+            }
+            // ties are [L2, L) and [R, R2); strictly nearer ones are [L, R)
+            need_t = m - (R - L);
+            const int T = (L - L2) + (R2 - R);
+            if (T > need_t) {  // take the need_t ties with the smallest train_pos position
+                int plo = 0, phi = P - 1;
+                while (plo < phi) {
+                    const int mid = (plo + phi) >> 1;
+                    int cn = 0;
+                    for (int i0 = L2; i0 < L; i0 += PCG_WAVE) {
+                        const int i = i0 + lane;
+                        cn += wave_count(i < L && (int)(uint32_t)pk[i] <= mid);
+                    }
+                    for (int i0 = R; i0 < R2; i0 += PCG_WAVE) {
+                        const int i = i0 + lane;
+                        cn += wave_count(i < R2 && (int)(uint32_t)pk[i] <= mid);
+                    }
+                    if (cn >= need_t) phi = mid;
+                    else plo = mid + 1;
+                }
+                tau = plo;
+            }
+        }
+        PCG_STAMP(4);
+        // strictly nearer ones: slot = i - L, every thread of the group strides over them
+        const int n_strict = R - L;
+        for (int base = tid; base < n_strict; base += NT * KEY_UNROLL) {
+            uint32_t pos[KEY_UNROLL], u[KEY_UNROLL];
+#pragma unroll
+            for (int x = 0; x < KEY_UNROLL; ++x) {
+                const int j = base + x * NT;
+                pos[x] = j < n_strict ? (uint32_t)pk[L + j] : 0u;
+            }
+#pragma unroll
+            for (int x = 0; x < KEY_UNROLL; ++x) u[x] = (uint32_t)a.g.train_pos[pos[x]];
+#pragma unroll
+            for (int x = 0; x < KEY_UNROLL; ++x) {
+                const int j = base + x * NT;
+                if (j < n_strict) {
+                    const bool dup = sorted_contains(sel, ns, u[x]) || (a.add_self && u[x] == (uint32_t)node);  // set(), :694
+                    out[ns + j] = dup ? -1 : (int32_t)u[x];
+                    valid += !dup;
+                }
+            }
+        }
+        mt = n_strict;
+        // the (rare) ties at the m-th distance: first wave, in window order
+        if (need_t > 0) {
+            int taken = 0;
+            for (int part = 0; part < 2; ++part) {
+                const int s0i = part == 0 ? L2 : R, e0i = part == 0 ? L : R2;
+                for (int i0 = s0i; i0 < e0i; i0 += PCG_WAVE) {
+                    const int i = i0 + lane;
+                    bool take = false;
+                    uint32_t u = 0;
+                    if (i < e0i) {
+                        const uint32_t pos = (uint32_t)pk[i];
+                        take = (int)pos <= tau;
+                        if (take) u = (uint32_t)a.g.train_pos[pos];
+                    }
+                    const uint64_t tmk = __ballot(take);
+                    if (take && wave == 0) {
+                        const bool dup = sorted_contains(sel, ns, u) || (a.add_self && u == (uint32_t)node);
+                        out[ns + n_strict + taken + __popcll(tmk & lanemask_lt())] = dup ? -1 : (int32_t)u;
+                        valid += !dup;
+                    }
+                    taken += __popcll(tmk);
+                }
+            }
+            mt += taken;
+        }
+    }
+    PCG_STAMP(5);
+    // GCN-style self union (graphsage.py:78-79, 214): the centre joins its own set
+    int n_self = 0;
+    if (a.add_self && !sorted_contains(sel, ns, (uint32_t)node)) {
+        n_self = 1;
+        if (tid == 0) out[ns + mt] = node;
+    }
+    // |set| = kept + non-duplicate minority picks + self
+    int vsum = valid;
+    for (int o = 1; o < PCG_WAVE; o <<= 1) vsum += __shfl_xor(vsum, o);
+    int vpre, vtot;
+    grp_scan<NW>(vsum, wave, lane, red, vpre, vtot);
+    if (tid == 0) {
+        a.w.len[row] = ns + mt + n_self;
+        a.cnt[row] = ns + vtot + n_self;
+    }
+    grp_sync<NW>();
+    PCG_STAMP(6);
+}
+
+// tier 1: one wave per row, 4 rows per block
+__global__ void __launch_bounds__(T1_WAVES_PER_BLOCK *PCG_WAVE) select_t1(const ChooseArgs a) {
+    __shared__ uint32_t keys[T1_WAVES_PER_BLOCK][T1_CAP];
+    __shared__ uint32_t ids[T1_WAVES_PER_BLOCK][T1_CAP];
+    __shared__ uint32_t ckeys[T1_WAVES_PER_BLOCK][T1_CAP];
+    __shared__ uint32_t cand[T1_WAVES_PER_BLOCK][PCG_WAVE];
+    const int w = threadIdx.x >> 6;
+    const uint32_t qi = blockIdx.x * T1_WAVES_PER_BLOCK + w;
+    if (qi >= a.w.counters[C_N1]) return;
+    select_row<1>(a, a.w.q1[qi], keys[w], ids[w], ckeys[w], cand[w], nullptr);
+}
+
+// tiers 4 / 16: one workgroup per row, rows pulled from the tier's queue
+template <int NW, int CAP>
+__global__ void __launch_bounds__(NW *PCG_WAVE) select_wide(const ChooseArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t *keys_lds = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *ids_lds = keys_lds + CAP;
+    uint32_t *ckeys_lds = ids_lds + CAP;
+    uint32_t *cand = ckeys_lds + CAP;
+    int *red = reinterpret_cast<int *>(cand + PCG_WAVE);
+    int *qslot = red + 2 * NW + 2;
+    const int32_t *queue = (NW == 4) ? a.w.q4 : a.w.q16;
+    const uint32_t nq = a.w.counters[(NW == 4) ? C_N4 : C_N16];
+    uint32_t *head = &a.w.counters[(NW == 4) ? C_HEAD4 : C_HEAD16];
+    for (;;) {
+        if (threadIdx.x == 0) *qslot = (int)atomicAdd(head, 1u);
+        __syncthreads();
+        const uint32_t qi = (uint32_t)*qslot;
+        __syncthreads();
+        if (qi >= nq) break;
+        const int row = queue[qi];
+        if (NW == 16 && a.w.recs[row].d > CAP) {   // over-long hub row: ids + keys in global scratch
+            uint32_t *gk = a.w.scratch + (size_t)blockIdx.x * 3 * a.g.max_degree;
+            select_row<NW>(a, row, gk, gk + a.g.max_degree, gk + 2 * (size_t)a.g.max_degree, cand, red);
+        } else {
+            select_row<NW>(a, row, keys_lds, ids_lds, ckeys_lds, cand, red);
+        }
+    }
+}
+
+static size_t wide_smem_bytes(int nw, int cap) {
+    return sizeof(uint32_t) * (3 * cap + PCG_WAVE) + sizeof(int) * (2 * nw + 2 + 2);
+}
+
+// ---------------------------------------------------------------------------------------------
+// gather + combine
+// ---------------------------------------------------------------------------------------------
+struct AggArgs {
+    const float *X;
+    int32_t feat_dim, feat_stride;
+    int32_t n_rows;             // n_rel * B
+    const int64_t *row_begin;
+    const int32_t *chunk_begin;
+    const int32_t *len;
+    const int32_t *cnt;
+    const int32_t *chunk_row;
+    const int32_t *list;
+    const uint32_t *n_chunks;   // device word
+    float *partial;
+    float *agg;                 // [n_rows, agg_stride]
+    int32_t agg_stride, norm;
+};
+
+struct RowGeom {  // how one wave-instruction covers feature rows
+    int lpr, rpw, slot, sub, nch;
+};
+
+__device__ __forceinline__ RowGeom row_geom(int stride, int lane) {
+    RowGeom q;
+    q.lpr = lanes_per_row(stride);
+    q.rpw = PCG_WAVE / q.lpr;
+    q.slot = lane / q.lpr;
+    q.sub = lane % q.lpr;
+    q.nch = stride >> 2;
+    return q;
+}
+
+template <int NACC>
+__device__ __forceinline__ void store_row(float *out, const float4 (&acc)[NACC], const RowGeom &q, int feat_dim,
+                                          float den) {
+#pragma unroll
+    for (int x = 0; x < NACC; ++x) {
+        const int ch = x * q.lpr + q.sub;
+        if (ch >= q.nch) continue;
+        const int f = 4 * ch;
+        if (f + 0 < feat_dim) out[f + 0] = acc[x].x / den;
+        if (f + 1 < feat_dim) out[f + 1] = acc[x].y / den;
+        if (f + 2 < feat_dim) out[f + 2] = acc[x].z / den;
+        if (f + 3 < feat_dim) out[f + 3] = acc[x].w / den;
+    }
+}
+
+template <int NACC>
+__global__ void __launch_bounds__(256) gather_chunks(const AggArgs a) {
+    const int lane = lane_id();
+    const RowGeom q = row_geom(a.feat_stride, lane);
+    const uint32_t total = *a.n_chunks;
+    const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+    for (uint32_t ch = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); ch < total; ch += nwaves) {
+        const int row = a.chunk_row[ch];
+        const int cb = a.chunk_begin[row];
+        const int j0 = ((int)ch - cb) * CHUNK;
+        const int len = a.len[row];
+        const int n = (len - j0 < CHUNK) ? len - j0 : CHUNK;          // may be <= 0 (cap is an upper bound)
+        const int32_t *__restrict__ list = a.list + a.row_begin[row] + j0;
+        float4 acc[NACC];
+#pragma unroll
+        for (int x = 0; x < NACC; ++x) acc[x] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int per_iter = q.rpw * UNROLL;
+        for (int base = 0; base < n; base += per_iter) {
+            float4 v[UNROLL][NACC];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int i = base + u * q.rpw + q.slot;
+                const int id = i < n ? list[i] : -1;                  // -1: hole left by a duplicate
+                const bool ok = id >= 0;
+                const float *rowp = a.X + (size_t)(ok ? id : 0) * a.feat_stride;
+#pragma unroll
+                for (int x = 0; x < NACC; ++x) {
+                    const int c4 = x * q.lpr + q.sub;
+                    v[u][x] = (ok && c4 < q.nch) ? *reinterpret_cast<const float4 *>(rowp + 4 * c4)
+                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+                for (int x = 0; x < NACC; ++x) {
+                    acc[x].x += v[u][x].x;
+                    acc[x].y += v[u][x].y;
+                    acc[x].z += v[u][x].z;
+                    acc[x].w += v[u][x].w;
+                }
+        }
+#pragma unroll
+        for (int x = 0; x < NACC; ++x)
+            for (int o = q.lpr; o < PCG_WAVE; o <<= 1) {
+                acc[x].x += __shfl_xor(acc[x].x, o);
+                acc[x].y += __shfl_xor(acc[x].y, o);
+                acc[x].z += __shfl_xor(acc[x].z, o);
+                acc[x].w += __shfl_xor(acc[x].w, o);
+            }
+        if (lane < q.lpr) {
+            const int nch_row = a.chunk_begin[row + 1] - cb;
+            if (nch_row == 1) {
+                const int cnt = a.cnt[row];
+                const float den = a.norm == PCG_NORM_SQRT_COUNT ? sqrtf((float)cnt) : (float)cnt;
+                store_row<NACC>(a.agg + (size_t)row * a.agg_stride, acc, q, a.feat_dim, den);
+            } else {
+                float *pp = a.partial + (size_t)ch * a.feat_stride;
+#pragma unroll
+                for (int x = 0; x < NACC; ++x) {
+                    const int c4 = x * q.lpr + q.sub;
+                    if (c4 < q.nch) *reinterpret_cast<float4 *>(pp + 4 * c4) = acc[x];
+                }
+            }
+        }
+    }
+}
+
+// rows longer than one chunk: add the partial sums in chunk order
+template <int NACC>
+__global__ void __launch_bounds__(256) combine_rows(const AggArgs a) {
+    const int lane = lane_id();
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= a.n_rows || *a.n_chunks == 0) return;
+    const int cb = a.chunk_begin[row], nch_row = a.chunk_begin[row + 1] - cb;
+    if (nch_row <= 1) {
+        if (nch_row == 0 && lane < a.feat_dim) {   // cap == 0: empty set -> 0/0 like the reference's mask.div
+            for (int f = lane; f < a.feat_dim; f += PCG_WAVE) a.agg[(size_t)row * a.agg_stride + f] = 0.f / 0.f;
+        }
+        return;
+    }
+    const RowGeom q = row_geom(a.feat_stride, lane);
+    if (lane >= q.lpr) return;
+    float4 acc[NACC];
+#pragma unroll
+    for (int x = 0; x < NACC; ++x) acc[x] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < nch_row; ++j) {
+        const float *pp = a.partial + (size_t)(cb + j) * a.feat_stride;
+#pragma unroll
+        for (int x = 0; x < NACC; ++x) {
+            const int c4 = x * q.lpr + q.sub;
+            if (c4 < q.nch) {
+                const float4 t = *reinterpret_cast<const float4 *>(pp + 4 * c4);
+                acc[x].x += t.x; acc[x].y += t.y; acc[x].z += t.z; acc[x].w += t.w;
+            }
+        }
+    }
+    const int cnt = a.cnt[row];
+    const float den = a.norm == PCG_NORM_SQRT_COUNT ? sqrtf((float)cnt) : (float)cnt;
+    store_row<NACC>(a.agg + (size_t)row * a.agg_stride, acc, q, a.feat_dim, den);
+}
+
+// The three tier kernels are independent once plan has run: the two wide tiers are forked
+// onto auxiliary streams (joined back before the gather), so the step's critical path is the
+// slowest tier, not their sum.  The fork/join is a cross-stream dependency pattern that
+// stream capture turns into parallel graph branches.  One process drives one GPU, so the
+// auxiliary streams / events are process-wide and created on first use.
+struct Fork {
+    hipStream_t aux[2];
+    hipEvent_t fork, join[2];
+    bool ok = false;
+};
+static Fork &fork_state() {
+    static Fork f;
+    if (!f.ok) {
+        bool good = true;
+        for (int i = 0; i < 2; ++i) {
+            good = good && hipStreamCreateWithFlags(&f.aux[i], hipStreamNonBlocking) == hipSuccess;
+            good = good && hipEventCreateWithFlags(&f.join[i], hipEventDisableTiming) == hipSuccess;
+        }
+        good = good && hipEventCreateWithFlags(&f.fork, hipEventDisableTiming) == hipSuccess;
+        f.ok = good;
+    }
+    return f;
+}
+
+static int launch_select(const ChooseArgs &a, hipStream_t st) {
+    const pcg_graph_desc &g = a.g;
+    const int rows = g.n_rel * a.B;
+    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(PLAN_THREADS), 0, st, a);
+    PCG_LAUNCH_CHECK();
+    const bool wide16 = g.max_degree > T4_CAP, wide4 = g.max_degree > T1_CAP;
+    Fork &f = fork_state();
+    if (!f.ok) return PCG_E_LAUNCH;
+    if (wide4 || wide16)
+        if (hipEventRecord(f.fork, st) != hipSuccess) return PCG_E_LAUNCH;
+    if (wide16) {
+        const size_t smem = wide_smem_bytes(16, T16_CAP);
+        static bool attr16 = false;
+        if (!attr16) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(select_wide<16, T16_CAP>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return PCG_E_LAUNCH;
+            attr16 = true;
+        }
+        if (hipStreamWaitEvent(f.aux[0], f.fork, 0) != hipSuccess) return PCG_E_LAUNCH;
+        const int nb = rows < N_T16_BLOCKS ? rows : N_T16_BLOCKS;
+        hipLaunchKernelGGL((select_wide<16, T16_CAP>), dim3(nb), dim3(16 * PCG_WAVE), smem, f.aux[0], a);
+        PCG_LAUNCH_CHECK();
+        if (hipEventRecord(f.join[0], f.aux[0]) != hipSuccess) return PCG_E_LAUNCH;
+    }
+    if (wide4) {
+        const size_t smem = wide_smem_bytes(4, T4_CAP);
+        if (hipStreamWaitEvent(f.aux[1], f.fork, 0) != hipSuccess) return PCG_E_LAUNCH;
+        const int nb = rows < N_T4_BLOCKS ? rows : N_T4_BLOCKS;
+        hipLaunchKernelGGL((select_wide<4, T4_CAP>), dim3(nb), dim3(4 * PCG_WAVE), smem, f.aux[1], a);
+        PCG_LAUNCH_CHECK();
+        if (hipEventRecord(f.join[1], f.aux[1]) != hipSuccess) return PCG_E_LAUNCH;
+    }
+    const int blocks = (rows + T1_WAVES_PER_BLOCK - 1) / T1_WAVES_PER_BLOCK;
+    hipLaunchKernelGGL(select_t1, dim3(blocks), dim3(T1_WAVES_PER_BLOCK * PCG_WAVE), 0, st, a);
+    PCG_LAUNCH_CHECK();
+    if (wide16 && hipStreamWaitEvent(st, f.join[0], 0) != hipSuccess) return PCG_E_LAUNCH;
+    if (wide4 && hipStreamWaitEvent(st, f.join[1], 0) != hipSuccess) return PCG_E_LAUNCH;
+    return PCG_OK;
+}
+
+template <int NACC>
+static int launch_aggregate(const AggArgs &g, hipStream_t st) {
+    hipLaunchKernelGGL(gather_chunks<NACC>, dim3(GATHER_BLOCKS), dim3(256), 0, st, g);
+    PCG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(combine_rows<NACC>, dim3((g.n_rows + 3) / 4), dim3(256), 0, st, g);
+    PCG_LAUNCH_CHECK();
+    return PCG_OK;
+}
+
+static unsigned long long *g_stamps = nullptr;
+
+}  // namespace pcg
+
+extern "C" {
+
+/* diagnostic: per-row phase timestamps of the select kernels ([rows][8] uint64, wall_clock64 ticks
+ * = 10 ns); pass NULL to switch off.  Not part of the product path. */
+void pcg_debug_set_stamps(void *ptr) { pcg::g_stamps = static_cast<unsigned long long *>(ptr); }
+
+int64_t pcg_choose_workspace_bytes(const pcg_graph_desc *g, int32_t B, int64_t list_capacity) {
+    if (!g || B < 0 || list_capacity < 0 || list_capacity >= (1ll << 31)) return PCG_E_ARG;
+    return pcg::carve(g, B, list_capacity, nullptr, nullptr);
+}
+
+int64_t pcg_choose_workspace_offset(const pcg_graph_desc *g, int32_t B, int64_t list_capacity, int32_t which) {
+    if (!g || B < 0 || list_capacity < 0) return PCG_E_ARG;
+    pcg::Workspace w;
+    unsigned char *base = reinterpret_cast<unsigned char *>(4096);   // fake base, only differences are used
+    pcg::carve(g, B, list_capacity, base, &w);
+    switch (which) {
+        case 0: return reinterpret_cast<unsigned char *>(w.row_begin) - base;
+        case 1: return reinterpret_cast<unsigned char *>(w.len) - base;
+        case 2: return reinterpret_cast<unsigned char *>(w.list) - base;
+        case 3: return reinterpret_cast<unsigned char *>(w.chunk_begin) - base;
+        case 4: return reinterpret_cast<unsigned char *>(w.chunk_row) - base;
+        case 5: return reinterpret_cast<unsigned char *>(w.counters) - base;
+        case 6: return reinterpret_cast<unsigned char *>(w.partial) - base;
+        default: return PCG_E_ARG;
+    }
+}
+
+int64_t pcg_sel_capacity_row(int64_t deg, double threshold, double rho, int32_t positive_train, int32_t n_pos,
+                             int32_t add_self) {
+    const int64_t k = (int64_t)ceil((double)deg * threshold);
+    int64_t cap = (deg > k + 1) ? k : deg;
+    if (positive_train) {
+        int64_t m = (int64_t)((double)k * rho);
+        if (m > n_pos) m = n_pos;
+        if (m > 0) cap += m;
+    }
+    return cap + (add_self ? 1 : 0);
+}
+
+int pcg_choose_select(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B, const float *s0,
+                      const float *center_s0, const uint64_t *pos_keys, const double *thresholds, const double *rho,
+                      int32_t train_flag, int32_t add_self, int32_t *cnt, void *workspace, int64_t list_capacity,
+                      uint32_t *status, void *stream) {
+    if (!g || B < 0) return PCG_E_ARG;
+    if (B == 0) return PCG_OK;  // empty trailing batch (model_handler.py:134 produces one): nothing to do
+    if (!nodes || !s0 || !thresholds || !cnt || !workspace || !status) return PCG_E_ARG;
+    if (list_capacity < 1 || list_capacity >= (1ll << 31)) return PCG_E_ARG;
+    if (train_flag && !rho) return PCG_E_ARG;
+    if (g->n_rel < 1 || g->n_rel > PCG_MAX_REL) return PCG_E_ARG;
+    if (train_flag && (!labels || (g->n_pos > 0 && (!pos_keys || !g->train_pos)))) return PCG_E_ARG;
+    for (int r = 0; r < g->n_rel; ++r)
+        if (!g->indptr[r] || !g->indices[r]) return PCG_E_ARG;
+
+    pcg::ChooseArgs a;
+    a.g = *g;
+    a.nodes = nodes;
+    a.labels = labels;
+    a.B = B;
+    a.s0 = s0;
+    a.center_s0 = center_s0;
+    a.pos_keys = pos_keys;
+    for (int r = 0; r < PCG_MAX_REL; ++r) a.thr[r] = r < g->n_rel ? thresholds[r] : 0.0;
+    for (int r = 0; r < PCG_MAX_REL; ++r) a.rho[r] = (r < g->n_rel && rho) ? rho[r] : 0.0;
+    a.train_flag = train_flag;
+    a.add_self = add_self;
+    a.cnt = cnt;
+    a.status = status;
+    a.stamps = pcg::g_stamps;
+    pcg::carve(g, B, list_capacity, static_cast<unsigned char *>(workspace), &a.w);
+    return pcg::launch_select(a, static_cast<hipStream_t>(stream));
+}
+
+int pcg_aggregate_lists(const float *X, int32_t feat_dim, int32_t feat_stride, int32_t n_rows, const int32_t *cnt,
+                        const pcg_graph_desc *g, int32_t B, void *workspace, int64_t list_capacity, int32_t norm,
+                        float *agg, int32_t agg_stride, void *stream) {
+    if (!X || !cnt || !g || !workspace || !agg || n_rows < 0 || B < 0) return PCG_E_ARG;
+    if (n_rows == 0) return PCG_OK;
+    if (feat_stride % 4 != 0 || feat_stride < feat_dim || agg_stride < feat_dim) return PCG_E_ARG;
+    if (feat_stride > 512) return PCG_E_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(X) & 15u) != 0) return PCG_E_ARG;
+    pcg::Workspace w;
+    pcg::carve(g, B, list_capacity, static_cast<unsigned char *>(workspace), &w);
+    pcg::AggArgs a;
+    a.X = X;
+    a.feat_dim = feat_dim;
+    a.feat_stride = feat_stride;
+    a.n_rows = n_rows;
+    a.row_begin = w.row_begin;
+    a.chunk_begin = w.chunk_begin;
+    a.len = w.len;
+    a.cnt = cnt;
+    a.chunk_row = w.chunk_row;
+    a.list = w.list;
+    a.n_chunks = w.counters + pcg::C_NCHUNK;
+    a.partial = w.partial;
+    a.agg = agg;
+    a.agg_stride = agg_stride;
+    a.norm = norm;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return feat_stride <= 256 ? pcg::launch_aggregate<1>(a, st) : pcg::launch_aggregate<2>(a, st);
+}
+
+int pcg_choose_aggregate(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B,
+                         const float *s0, const float *center_s0, const uint64_t *pos_keys,
+                         const double *thresholds, const double *rho, int32_t train_flag, int32_t norm,
+                         int32_t add_self, float *agg, int32_t agg_stride, int32_t *cnt, void *workspace,
+                         int64_t list_capacity, uint32_t *status, void *stream) {
+    if (!g || B < 0) return PCG_E_ARG;
+    if (B == 0) return PCG_OK;
+    if (!g->X || !agg) return PCG_E_ARG;
+    const int rc = pcg_choose_select(g, nodes, labels, B, s0, center_s0, pos_keys, thresholds, rho, train_flag,
+                                     add_self, cnt, workspace, list_capacity, status, stream);
+    if (rc != PCG_OK) return rc;
+    return pcg_aggregate_lists(g->X, g->feat_dim, g->feat_stride, g->n_rel * B, cnt, g, B, workspace, list_capacity,
+                               norm, agg, agg_stride, stream);
+}
+
+}  // extern "C"

@@ -75,7 +75,7 @@ class FusedPCGNN:
         self.maxB = B
         self.s0 = torch.empty(g.n_nodes, dtype=torch.float32, device=dev)
         self.keys = torch.empty(self.lib.pcg_pos_sort_capacity(g.n_pos), dtype=torch.int64, device=dev)
-        self.ws = ops.ChooseWorkspace(g, B)
+        self._ws_by_b = {B: ops.ChooseWorkspace(g, B)}
         self.agg = torch.empty(g.R, B, g.feat_dim, dtype=torch.float32, device=dev)
         self.cnt = torch.empty(g.R, B, dtype=torch.int32, device=dev)
         self.logits = torch.empty(B, 2, dtype=torch.float32, device=dev)
@@ -103,8 +103,11 @@ class FusedPCGNN:
         if timed:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
+        ws = self._ws_by_b.get(B)
+        if ws is None:      # the workspace layout depends on the batch size: one per size
+            ws = self._ws_by_b[B] = ops.ChooseWorkspace(g, B)
         ops.choose_aggregate(g, ids, labels if train_flag else None, self.s0, keys, self.thresholds, self.rho,
-                             train_flag, ws=self.ws, agg=agg, cnt=cnt)
+                             train_flag, ws=ws, agg=agg, cnt=cnt)
         if timed:
             ev[1].record()
             self._prof.append(ev)

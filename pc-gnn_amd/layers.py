@@ -135,6 +135,7 @@ class InterAgg(nn.Module):
         self.relation_score_log = []
         self._graph: Optional[DeviceGraph] = adj_lists if isinstance(adj_lists, DeviceGraph) else None
         self._ws = None
+        self._ws_cache = {}
         self._s0 = None
         self._keys = None
         self._prof = None
@@ -169,8 +170,10 @@ class InterAgg(nn.Module):
         if self._s0 is None:
             self._s0 = torch.empty(g.n_nodes, dtype=torch.float32, device=dev)
             self._keys = torch.empty(_lib.load().pcg_pos_sort_capacity(g.n_pos), dtype=torch.int64, device=dev)
-        if self._ws is None or self._ws.B < B:
-            self._ws = ops.ChooseWorkspace(g, B)
+        if self._ws is None or self._ws.B != B:      # the workspace layout depends on the batch size
+            if B not in self._ws_cache:
+                self._ws_cache[B] = ops.ChooseWorkspace(g, B)
+            self._ws = self._ws_cache[B]
 
         s0 = ops.score_table(g, W, b, out=self._s0)                                  # :230-237
         keys = ops.pos_sort(g, s0, self._keys) if (train_flag and g.n_pos) else None   # :683-688

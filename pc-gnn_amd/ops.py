@@ -74,18 +74,40 @@ def gather_rows(g: DeviceGraph, ids: torch.Tensor, out: Optional[torch.Tensor] =
 
 
 class ChooseWorkspace:
-    """Per-(graph, batch size) scratch so the step itself never allocates."""
+    """Per-(graph, batch size) scratch so the step itself never allocates: the tier queues,
+    the selection list every row's chosen ids are written to, the gather's chunk table and
+    partial sums.  ``list_capacity`` (entries) must cover sum over rows of the per-row bound
+    ``(deg > k+1 ? k : deg) + m (+1)``; the default is the worst case for this graph and batch
+    size (every centre being the largest hub), clipped to ``max_list_bytes``."""
 
-    def __init__(self, g: DeviceGraph, B: int):
+    def __init__(self, g: DeviceGraph, B: int, list_capacity: Optional[int] = None, max_list_bytes: int = 8 << 30):
         lib = _lib.load()
         self.B = B
-        nbytes = lib.pcg_choose_workspace_bytes(g.desc_ref(), B)
-        self.buf = torch.zeros(max(int(nbytes), 256), dtype=torch.uint8, device=g.device)   # counters start at zero
+        if list_capacity is None:
+            # kept <= deg, minority m = int(ceil(deg/2) * rho) <= 2 * deg for rho <= 4 (and <= n_pos), +1 self
+            per_row = g.max_degree + min(2 * max(g.max_degree, 1), g.n_pos) + 1
+            list_capacity = min(per_row * g.R * max(B, 1), max_list_bytes // 4, (1 << 31) - 1)
+        self.list_capacity = int(max(list_capacity, 1))
+        nbytes = lib.pcg_choose_workspace_bytes(g.desc_ref(), B, self.list_capacity)
+        if nbytes < 0:
+            raise _lib.PcgnnLibraryError("pcg_choose_workspace_bytes rejected the arguments")
+        self.buf = torch.zeros(int(nbytes), dtype=torch.uint8, device=g.device)
         self.status = torch.zeros(1, dtype=torch.int32, device=g.device)
+        self._g = g
+
+    def view(self, which: int, dtype, count: int) -> torch.Tensor:
+        off = _lib.load().pcg_choose_workspace_offset(self._g.desc_ref(), self.B, self.list_capacity, which)
+        nbytes = count * torch.empty((), dtype=dtype).element_size()
+        return self.buf[off:off + nbytes].view(dtype)
+
+    def check(self):
+        """Raise if a batch did not fit the selection list (reads the status word: synchronises)."""
+        if int(self.status.item()) & _lib.PCG_ST_SEL_OVERFLOW:
+            raise _lib.PcgnnLibraryError("selection list overflow: raise ChooseWorkspace(list_capacity=...)")
 
 
 def sel_capacity(g: DeviceGraph, nodes_host: np.ndarray, labels_host: Optional[np.ndarray],
-                 thresholds: Sequence[float], rho: float, train_flag: bool, add_self: bool = False) -> np.ndarray:
+                 thresholds: Sequence[float], rho, train_flag: bool, add_self: bool = False) -> np.ndarray:
     """Host-side upper bound of every row's chosen-set size, [R, B] (pcg_sel_capacity_row, vectorised)."""
     caps = []
     for r in range(g.R):
@@ -100,58 +122,86 @@ def sel_capacity(g: DeviceGraph, nodes_host: np.ndarray, labels_host: Optional[n
     return np.stack(caps)
 
 
+def _host_arrays(g, thresholds, rho):
+    thr = (C.c_double * g.R)(*[float(t) for t in thresholds])
+    rhos = (C.c_double * g.R)(*([float(rho)] * g.R if np.isscalar(rho) else [float(x) for x in rho]))
+    return thr, rhos
+
+
+def choose_select(g: DeviceGraph, nodes, labels, s0, pos_keys, thresholds, rho, train_flag: bool, ws: ChooseWorkspace,
+                  cnt: torch.Tensor, add_self: bool = False, center_s0=None):
+    """plan + select only: every row's chosen ids into ws's selection list, |set| into cnt [R*B]."""
+    lib = _lib.load()
+    thr, rhos = _host_arrays(g, thresholds, rho)
+    _lib.check(lib.pcg_choose_select(
+        g.desc_ref(), _p(nodes), _p(labels), nodes.numel(), _p(s0), _p(center_s0), _p(pos_keys), thr, rhos,
+        1 if train_flag else 0, 1 if add_self else 0, _p(cnt), _p(ws.buf), ws.list_capacity, _p(ws.status),
+        _stream(g.device)), "pcg_choose_select")
+
+
+def aggregate_lists(g: DeviceGraph, X: torch.Tensor, B: int, ws: ChooseWorkspace, cnt: torch.Tensor, agg: torch.Tensor,
+                    norm: int = _lib.PCG_NORM_COUNT):
+    """gather + mean of the lists ws holds, from feature table X [*, feat_stride] (g.X or an extended table)."""
+    lib = _lib.load()
+    _lib.check(lib.pcg_aggregate_lists(_p(X), g.feat_dim, X.stride(0), g.R * B, _p(cnt), g.desc_ref(), B, _p(ws.buf),
+                                       ws.list_capacity, norm, _p(agg), agg.stride(-2), _stream(g.device)),
+               "pcg_aggregate_lists")
+
+
 def choose_aggregate(g: DeviceGraph, nodes: torch.Tensor, labels: Optional[torch.Tensor], s0: torch.Tensor,
-                     pos_keys: Optional[torch.Tensor], thresholds: Sequence[float], rho: float, train_flag: bool,
+                     pos_keys: Optional[torch.Tensor], thresholds: Sequence[float], rho, train_flag: bool,
                      norm: int = _lib.PCG_NORM_COUNT, add_self: bool = False,
                      center_s0: Optional[torch.Tensor] = None, ws: Optional[ChooseWorkspace] = None,
-                     agg: Optional[torch.Tensor] = None, cnt: Optional[torch.Tensor] = None,
-                     sel_begin: Optional[torch.Tensor] = None, sel_indices: Optional[torch.Tensor] = None):
-    """Fused choose + mean for all relations of a batch -> agg [R, B, F] (and |set| [R, B])."""
+                     agg: Optional[torch.Tensor] = None, cnt: Optional[torch.Tensor] = None):
+    """choose + mean for all relations of a batch -> agg [R, B, F] (and |set| [R, B])."""
     lib = _lib.load()
     B = nodes.numel()
-    if ws is None or ws.B < B:
+    if ws is None or ws.B != B:
         ws = ChooseWorkspace(g, B)
     if agg is None:
         agg = torch.empty(g.R, B, g.feat_dim, dtype=torch.float32, device=g.device)
     if cnt is None:
         cnt = torch.empty(g.R, B, dtype=torch.int32, device=g.device)
-    thr = (C.c_double * g.R)(*[float(t) for t in thresholds])
-    rhos = (C.c_double * g.R)(*([float(rho)] * g.R if np.isscalar(rho) else [float(x) for x in rho]))
-    cap = 0 if sel_indices is None else sel_indices.numel()
+    thr, rhos = _host_arrays(g, thresholds, rho)
     _lib.check(lib.pcg_choose_aggregate(
         g.desc_ref(), _p(nodes), _p(labels), B, _p(s0), _p(center_s0), _p(pos_keys), thr, rhos,
-        1 if train_flag else 0, norm, 1 if add_self else 0, _p(agg), agg.stride(1), _p(cnt),
-        _p(sel_begin), _p(sel_indices), cap, _p(ws.buf), _p(ws.status), _stream(g.device)), "pcg_choose_aggregate")
+        1 if train_flag else 0, norm, 1 if add_self else 0, _p(agg), agg.stride(-2), _p(cnt),
+        _p(ws.buf), ws.list_capacity, _p(ws.status), _stream(g.device)), "pcg_choose_aggregate")
     return agg, cnt
 
 
-def chosen_sets(g: DeviceGraph, nodes, labels, s0, pos_keys, thresholds, rho, train_flag,
-                norm=_lib.PCG_NORM_COUNT, add_self=False, center_s0=None):
-    """Debug / parity helper: run the hot kernel with materialisation on and copy the
-    chosen index sets to the host.  Returns (sets[r][b], agg, cnt)."""
-    nodes_h = nodes.cpu().numpy()
-    labels_h = None if labels is None else labels.cpu().numpy()
-    caps = sel_capacity(g, nodes_h, labels_h, thresholds, rho, train_flag, add_self)
-    begin = np.zeros(caps.size, dtype=np.int64)
-    np.cumsum(caps.reshape(-1)[:-1], out=begin[1:])
-    total = int(caps.sum())
-    sel_begin = torch.from_numpy(begin).to(g.device)
-    sel_idx = torch.full((max(total, 1),), -1, dtype=torch.int32, device=g.device)
-    ws = ChooseWorkspace(g, nodes.numel())
-    agg, cnt = choose_aggregate(g, nodes, labels, s0, pos_keys, thresholds, rho, train_flag, norm, add_self,
-                                center_s0, ws, sel_begin=sel_begin, sel_indices=sel_idx)
+def read_sets(g: DeviceGraph, B: int, ws: ChooseWorkspace):
+    """Copy the selection list of the last call to the host -> sets[r][b] (synchronises)."""
+    rows = g.R * B
     torch.cuda.synchronize(g.device)
-    if int(ws.status.item()) & _lib.PCG_ST_SEL_OVERFLOW:
-        raise _lib.PcgnnLibraryError("selection buffer overflow (capacity bound is wrong)")
-    idx_h, cnt_h = sel_idx.cpu().numpy(), cnt.cpu().numpy()
-    B = nodes.numel()
+    ws.check()
+    begin = ws.view(0, torch.int64, rows + 1).cpu().numpy()
+    length = ws.view(1, torch.int32, rows).cpu().numpy()
+    total = int(begin[-1])
+    lst = ws.view(2, torch.int32, max(total, 1)).cpu().numpy()
     sets: List[List[Set[int]]] = []
     for r in range(g.R):
         row_sets = []
         for b in range(B):
-            s = begin[r * B + b]
-            row_sets.append(set(idx_h[s:s + cnt_h[r, b]].tolist()))
+            row = r * B + b
+            seg = lst[begin[row]:begin[row] + length[row]]
+            row_sets.append(set(seg[seg >= 0].tolist()))
         sets.append(row_sets)
+    return sets
+
+
+def chosen_sets(g: DeviceGraph, nodes, labels, s0, pos_keys, thresholds, rho, train_flag,
+                norm=_lib.PCG_NORM_COUNT, add_self=False, center_s0=None, list_capacity=None):
+    """Debug / parity helper: run the hot path and copy the chosen index sets to the host.
+    Returns (sets[r][b], agg, cnt)."""
+    B = nodes.numel()
+    if list_capacity is None:     # exact requirement of this batch (host arithmetic)
+        labels_h = None if labels is None else labels.cpu().numpy()
+        list_capacity = int(sel_capacity(g, nodes.cpu().numpy(), labels_h, thresholds, rho, train_flag, add_self).sum())
+    ws = ChooseWorkspace(g, B, list_capacity=max(list_capacity, 1))
+    agg, cnt = choose_aggregate(g, nodes, labels, s0, pos_keys, thresholds, rho, train_flag, norm, add_self,
+                                center_s0, ws)
+    sets = read_sets(g, B, ws)
     return sets, agg, cnt
 
 

@@ -1,0 +1,45 @@
+"""Diagnostic: per-phase time of the select kernels on one YelpChi-like batch (in-kernel stamps)."""
+import sys, os, ctypes as C, torch, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import pcgnn_amd
+from pcgnn_amd import synth, ops, _lib
+from pcgnn_amd.handler import PCGNNTrainer
+w = synth.yelp_like(0)
+tr = PCGNNTrainer(w, dict(engine="fused", batch_size=1024), torch.device("cuda", 0))
+fz = tr.fused; g = fz.g; lib = _lib.load()
+ids_all = tr.start_epoch(0)
+B = 1024; ids = ids_all[:B].contiguous(); lab = tr.labels_i32[ids.long()]
+rows = g.R * B
+stamps = torch.zeros(rows, 8, dtype=torch.int64, device="cuda")
+for it in range(3):
+    keys = fz._enqueue_scores(True)
+    if it == 2: lib.pcg_debug_set_stamps(C.c_void_p(stamps.data_ptr()))
+    fz._enqueue_choose(ids, lab, B, keys, True)
+    torch.cuda.synchronize()
+lib.pcg_debug_set_stamps(None)
+st = stamps.cpu().numpy().astype(np.float64) * 0.01   # us
+deg = np.stack([g.deg_host[r][ids.cpu().numpy()] for r in range(g.R)]).reshape(-1)
+t0 = st[:, 0].min()
+names = ["rec+keys(1)", "kth(2)", "compact+list(3)", "min-search(4)", "min-resolve(5)", "tail(6)"]
+for lo, hi, tier in ((0, 512, "T1"), (512, 4096, "T4"), (4096, 1 << 30, "T16")):
+    sel = (deg > lo) & (deg <= hi)
+    if not sel.any(): continue
+    s = st[sel]
+    print(f"{tier}: rows {sel.sum()}, deg mean {deg[sel].mean():.0f} max {deg[sel].max()}, start skew {s[:,0].min()-t0:.1f}..{s[:,0].max()-t0:.1f} us, end {s[:,6].max()-t0:.1f} us")
+    prev = s[:, 0]
+    for i, n in enumerate(names, start=1):
+        cur = np.where(s[:, i] > 0, s[:, i], prev)
+        dt = cur - prev
+        print(f"   {n:18s} mean {dt.mean():7.2f} us  p95 {np.percentile(dt,95):7.2f}  max {dt.max():7.2f}")
+        prev = cur
+    tot = s[:, 6] - s[:, 0]
+    print(f"   total per row      mean {tot.mean():7.2f} us  max {tot.max():7.2f}")
+
+rounds = (stamps.cpu().numpy()[:, 7] & 0xFFFFFFFF).astype(np.int64)
+ncand = (stamps.cpu().numpy()[:, 7] >> 32).astype(np.int64)
+kth = st[:, 2] - st[:, 1]
+print("kth phase by degree bucket: rows, mean us, max us, mean rounds, max rounds, mean ncand at exit")
+for lo, hi in ((0, 3), (3, 64), (64, 128), (128, 256), (256, 512), (512, 1024), (1024, 4096), (4096, 1 << 30)):
+    sel = (deg > lo) & (deg <= hi)
+    if sel.any():
+        print(f"  deg ({lo},{hi}]: {sel.sum():5d} rows  kth {kth[sel].mean():6.2f} / {kth[sel].max():6.2f} us   rounds {rounds[sel].mean():5.1f} / {rounds[sel].max():3d}   ncand {ncand[sel].mean():6.1f}")

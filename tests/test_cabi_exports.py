@@ -46,7 +46,7 @@ def test_host_helpers_and_argument_checks():
     # null / inconsistent arguments are rejected before any launch
     assert lib.pcg_score_table(None, None, None, 0, 0, None, None) == _lib.PCG_E_ARG
     assert lib.pcg_pick(None, None, 0, None, 0, 0, 1, None, None) == _lib.PCG_E_ARG
-    assert lib.pcg_choose_workspace_bytes(None, 4) == _lib.PCG_E_ARG
+    assert lib.pcg_choose_workspace_bytes(None, 4, 10) == _lib.PCG_E_ARG
 
 
 def test_product_path_refuses_cpu():
