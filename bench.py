@@ -47,9 +47,11 @@ def parse():
     ap.add_argument("--edges", type=int, default=40_000_000, help="powerlaw only")
     ap.add_argument("--cpu-batches", type=int, default=2, help="oracle batches timed for cpu_baseline (0 = skip)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--force-partitioned", action="store_true",
+                    help="run the node-partitioned RCCL path even at world size 1 (rehearsal of the N>1 code)")
     ap.add_argument("--event-every", type=int, default=4,
                     help="graph engine: bracket the choose+aggregate launch with HIP events on every Nth timed step")
-    ap.add_argument("--engine", default=None, choices=["graph", "fused", "torch"],
+    ap.add_argument("--engine", default=None, choices=["graph", "fused", "torch", "dp"],
                     help="graph: fused HIP step replayed from a hipGraph (default at 1 GPU); fused: same kernels "
                          "launched eagerly (default at N>1, gradient all-reduce in between); torch: torch dense tail")
     return ap.parse_args()
@@ -99,6 +101,58 @@ def cpu_baseline(w, trainer, cfg, batches, n_batches):
                       f"oracle/pcgnn_oracle.py train_step (dense-mask formulation as in the reference), {spent:.1f} s"}
 
 
+def run_partitioned(args, w, B, lr, wd, dev, dist, world, rank):
+    """N > 1: destination-node partition, RCCL all-gather of scores + all-to-all of remote neighbour rows +
+    gradient all-reduce (pc-gnn_amd/dist.py).  Weak scaling: every rank trains batches of B centres it owns."""
+    from pcgnn_amd.dist import DistributedPCGNN
+    cfg = dict(emb_size=args.emb, rho=args.rho, alpha=2.0, lr=lr, weight_decay=wd, batch_size=B, seed=args.seed)
+    d = DistributedPCGNN(w, cfg, dev)
+
+    def one_step(k):
+        ids = d.pick_epoch(B, k)
+        d.train_step(ids, d.labels_of(ids))
+
+    def barrier():
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for k in range(args.warmup):
+        one_step(k)
+    barrier()
+    t0 = time.perf_counter()
+    halo_rows = remote = entries = 0
+    for k in range(args.steps):
+        one_step(args.warmup + k)
+        st = d.halo.last_stats
+        halo_rows += st["halo_rows"]; remote += st["remote_entries"]; entries += st["entries"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    stats = torch.tensor([halo_rows, remote, entries], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(stats)
+    elapsed = float(t.item())
+    nodes_total = args.steps * B * world
+    if rank == 0:
+        hr, rm, en = (float(x) / (args.steps * world) for x in stats.tolist())
+        out = {
+            "metric": "sampled-nodes/sec", "value": nodes_total / elapsed, "unit": "nodes/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{w.name} N={w.n} F={w.X.shape[1]} R={len(w.csr)} "
+                                   f"edges={'/'.join(str(e) for e in w.meta['rel_edges'])}, PCGNN emb={args.emb} "
+                                   f"batch={B}/GPU rho={args.rho}",
+                       "global_batch": B * world, "parallelism": f"node-partition x{world}: score all-gather, "
+                       "id + feature-row all-to-all, grad all-reduce (RCCL)", "engine": "fused-eager",
+                       "nodes_processed": int(nodes_total),
+                       "per_rank_per_step": {"chosen_entries": en, "remote_entries": rm, "halo_rows_fetched": hr,
+                                             "halo_bytes": hr * w.X.shape[1] * 4}},
+        }
+        print(json.dumps(out))
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -109,8 +163,9 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_partitioned:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
@@ -119,7 +174,11 @@ def main():
 
     w, default_b, lr, wd = make_workload(args)
     B = args.batch_size or default_b
+    if (world > 1 or args.force_partitioned) and args.engine != "dp":
+        return run_partitioned(args, w, B, lr, wd, dev, dist, world, rank)
     engine = args.engine or ("graph" if world == 1 else "fused")
+    if engine == "dp":          # N>1 only: replicated graph, data-parallel batches (not the default)
+        engine = "fused"
     cfg = dict(emb_size=args.emb, rho=args.rho, alpha=2.0, lr=lr, weight_decay=wd, batch_size=B,
                seed=args.seed + 1000 * rank, engine=engine, world_size=world)
     tr = PCGNNTrainer(w, cfg, dev)

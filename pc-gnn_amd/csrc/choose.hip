@@ -734,8 +734,11 @@ __device__ __forceinline__ void select_row(const ChooseArgs &a, int row, uint32_
     for (int o = 1; o < PCG_WAVE; o <<= 1) vsum += __shfl_xor(vsum, o);
     int vpre, vtot;
     grp_scan<NW>(vsum, wave, lane, red, vpre, vtot);
+    const int used = ns + mt + n_self;
+    const int cap = (int)(a.w.row_begin[row + 1] - a.w.row_begin[row]);
+    for (int i = used + tid; i < cap; i += NT) out[i] = -1;   // unused tail of the region: the whole list prefix stays clean
     if (tid == 0) {
-        a.w.len[row] = ns + mt + n_self;
+        a.w.len[row] = used;
         a.cnt[row] = ns + vtot + n_self;
     }
     grp_sync<NW>();

@@ -40,7 +40,9 @@ def adj_to_csr(adj: AdjList, n_nodes: int) -> Tuple[np.ndarray, np.ndarray]:
 
 class DeviceGraph:
     def __init__(self, X, csr: Sequence[Tuple[np.ndarray, np.ndarray]], train_pos: Sequence[int],
-                 device: Optional[torch.device] = None):
+                 device: Optional[torch.device] = None, id_space: Optional[int] = None):
+        """id_space: size of the id space neighbour / train_pos ids live in when it is not this
+        table's own row count (a shard of a partitioned graph keeps GLOBAL ids, see dist.py)."""
         _lib.load()
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device())
@@ -49,6 +51,7 @@ class DeviceGraph:
             raise _lib.PcgnnLibraryError("DeviceGraph needs a GPU device: the PC-GNN hot path has no CPU fallback")
         X = torch.as_tensor(X, dtype=torch.float32)
         self.n_nodes, self.feat_dim = int(X.shape[0]), int(X.shape[1])
+        self.id_space = int(id_space or X.shape[0])
         self.feat_stride = (self.feat_dim + 3) // 4 * 4
         if self.feat_stride > 512:
             raise _lib.PcgnnLibraryError(f"feat_dim {self.feat_dim} > 512 is not supported by the gather kernels")
@@ -65,7 +68,7 @@ class DeviceGraph:
             indices = np.ascontiguousarray(indices, dtype=np.int32)
             if indptr.shape[0] != self.n_nodes + 1 or indptr[-1] != indices.shape[0]:
                 raise ValueError("CSR shape does not match the feature table")
-            if indices.size and (indices.min() < 0 or indices.max() >= self.n_nodes):
+            if indices.size and (indices.min() < 0 or indices.max() >= (id_space or self.n_nodes)):
                 raise ValueError("neighbour id out of range")
             deg = np.diff(indptr)
             self.deg_host.append(deg)
@@ -74,7 +77,7 @@ class DeviceGraph:
             self.indices.append(torch.from_numpy(indices).to(self.device) if indices.size
                                 else torch.zeros(1, dtype=torch.int32, device=self.device))
         tp = np.asarray(list(train_pos), dtype=np.int64)
-        if tp.size and (tp.min() < 0 or tp.max() >= self.n_nodes):
+        if tp.size and (tp.min() < 0 or tp.max() >= (id_space or self.n_nodes)):
             raise ValueError("train_pos id out of range")
         if np.unique(tp).size != tp.size:
             raise ValueError("train_pos contains duplicate ids (the reference builds it with pos_neg_split, "
