@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--edges", type=int, default=40_000_000, help="powerlaw only")
     ap.add_argument("--cpu-batches", type=int, default=2, help="oracle batches timed for cpu_baseline (0 = skip)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-epoch-graphs", action="store_true", help="graph engine: copy each batch into a static buffer "
+                    "instead of staging the whole epoch (A/B switch)")
     ap.add_argument("--force-partitioned", action="store_true",
                     help="run the node-partitioned RCCL path even at world size 1 (rehearsal of the N>1 code)")
     ap.add_argument("--event-every", type=int, default=4,
@@ -209,6 +211,8 @@ def main():
                     p.grad.copy_(flat[o:o + p.numel()].view_as(p))
                     o += p.numel()
             tr.opt.step()
+        elif epoch_graphs and not timed:
+            tr.fused.epoch_step(state["b"] - 1)
         elif dist is None:
             tr.step(ids, timed)
         else:
@@ -216,10 +220,13 @@ def main():
 
     state = {"epoch": 0, "ids": None, "b": 0}
     nb = tr.batches_per_epoch()
+    epoch_graphs = engine == "graph" and dist is None and not args.no_epoch_graphs   # ids/labels of an epoch in static buffers, 1 launch per step
 
     def next_batch():
         if state["ids"] is None or state["b"] == nb:
             state["ids"] = tr.start_epoch(state["epoch"])      # pick + shuffle on the device
+            if epoch_graphs:
+                tr.fused.begin_epoch(state["ids"], tr.labels_i32[state["ids"].long()], B)
             state["epoch"] += 1
             state["b"] = 0
         b = state["b"]

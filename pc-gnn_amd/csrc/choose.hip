@@ -165,7 +165,24 @@ constexpr int PLAN_PER = 4;     // rows per thread per tile
 __global__ void __launch_bounds__(PLAN_THREADS) plan_kernel(const ChooseArgs a) {
     __shared__ int lds[PLAN_THREADS / PCG_WAVE];
     __shared__ long long lds64[PLAN_THREADS / PCG_WAVE];
+    // per-relation constants in LDS: a per-lane relation index then costs one ds_read instead of a
+    // waterfall loop over the kernel-argument arrays (which also serialised every load behind it)
+    __shared__ const int64_t *t_indptr[PCG_MAX_REL];
+    __shared__ double t_thr[PCG_MAX_REL], t_rho[PCG_MAX_REL];
+    if (threadIdx.x < PCG_MAX_REL) {
+        t_indptr[threadIdx.x] = a.g.indptr[threadIdx.x < a.g.n_rel ? threadIdx.x : 0];
+        t_thr[threadIdx.x] = a.thr[threadIdx.x];
+        t_rho[threadIdx.x] = a.rho[threadIdx.x];
+    }
+    __syncthreads();
+    // branch-free optional inputs
+    const int32_t *lab_ptr = (a.train_flag && a.labels) ? a.labels : a.nodes;
+    const int lab_on = (a.train_flag && a.labels) ? 1 : 0;
+    const float *c_ptr = a.center_s0 ? a.center_s0 : a.s0;
+    const bool c_by_batch = a.center_s0 != nullptr;
     const int rows = a.g.n_rel * a.B;
+#define PLAN_STAMP(slot) do { if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)rows * 8 + (slot)] = wall_clock64(); } while (0)
+    PLAN_STAMP(0);
     long long run_cap = 0;
     int run_chunk = 0, run1 = 0, run4 = 0, run16 = 0;
     bool overflow = false;
@@ -175,29 +192,65 @@ __global__ void __launch_bounds__(PLAN_THREADS) plan_kernel(const ChooseArgs a) 
         int cap[PLAN_PER];
         long long cap_sum = 0;
         int chunk_sum = 0, n1 = 0, n4 = 0, n16 = 0;
+        // the dependent loads of the 4 rows are issued level by level, not row by row
+        int nodev[PLAN_PER], labv[PLAN_PER], rel[PLAN_PER], bidx[PLAN_PER];
+        long long s0v[PLAN_PER], s1v[PLAN_PER];
+        float cv[PLAN_PER];
+#pragma unroll
+        for (int i = 0; i < PLAN_PER; ++i) {
+            const int row = r0 + i < rows ? r0 + i : rows - 1;
+            rel[i] = row / a.B;
+            bidx[i] = row - rel[i] * a.B;
+            nodev[i] = a.nodes[bidx[i]];
+            labv[i] = lab_ptr[bidx[i]];
+        }
+#pragma unroll
+        for (int i = 0; i < PLAN_PER; ++i) {
+            const int64_t *ip = t_indptr[rel[i]];
+            s0v[i] = ip[nodev[i]];
+            s1v[i] = ip[nodev[i] + 1];
+            cv[i] = c_ptr[c_by_batch ? bidx[i] : nodev[i]];
+        }
 #pragma unroll
         for (int i = 0; i < PLAN_PER; ++i) {
             const int row = r0 + i;
             cap[i] = 0;
             if (row < rows) {
-                rec[i] = row_plan(a, row);
-                cap[i] = (rec[i].keep_all ? rec[i].d : rec[i].k) + rec[i].m + (a.add_self ? 1 : 0);
+                RowRec p;
+                p.node = nodev[i];
+                p.start = s0v[i];
+                p.d = (int)(s1v[i] - s0v[i]);
+                p.k = (int)ceil((double)p.d * t_thr[rel[i]]);             // layers.py:260
+                p.keep_all = !(p.d > p.k + 1);                            // layers.py:662
+                p.m = 0;
+                if (lab_on && labv[i] == 1) {                             // layers.py:675
+                    p.m = (int)((double)p.k * t_rho[rel[i]]);             // layers.py:681
+                    if (p.m > a.g.n_pos) p.m = a.g.n_pos;
+                    if (p.m < 0) p.m = 0;
+                }
+                p.c = cv[i];
+                rec[i] = p;
+                cap[i] = (p.keep_all ? p.d : p.k) + p.m + (a.add_self ? 1 : 0);
                 cap_sum += cap[i];
                 chunk_sum += (cap[i] + CHUNK - 1) / CHUNK;
-                n1 += rec[i].d <= T1_CAP;
-                n4 += rec[i].d > T1_CAP && rec[i].d <= T4_CAP;
-                n16 += rec[i].d > T4_CAP;
+                n1 += p.d <= T1_CAP;
+                n4 += p.d > T1_CAP && p.d <= T4_CAP;
+                n16 += p.d > T4_CAP;
             }
         }
-        long long t_cap;
-        int t_chunk, t1, t4, t16;
+        PLAN_STAMP(1);
+        // three scans instead of five: the tier counts (each <= 4 per thread, <= 4096 per tile) share one word
+        long long t_cap, t_tiers;
+        int t_chunk;
         long long o_cap = run_cap + block_excl_scan<long long>(cap_sum, lds64, t_cap);
         int o_chunk = run_chunk + block_excl_scan(chunk_sum, lds, t_chunk);
-        int o1 = run1 + block_excl_scan(n1, lds, t1);
-        int o4 = run4 + block_excl_scan(n4, lds, t4);
-        int o16 = run16 + block_excl_scan(n16, lds, t16);
+        const long long packed = (long long)n1 | ((long long)n4 << 20) | ((long long)n16 << 40);
+        const long long o_t = block_excl_scan<long long>(packed, lds64, t_tiers);
+        int o1 = run1 + (int)(o_t & 0xFFFFF), o4 = run4 + (int)((o_t >> 20) & 0xFFFFF), o16 = run16 + (int)(o_t >> 40);
+        const int t1 = (int)(t_tiers & 0xFFFFF), t4 = (int)((t_tiers >> 20) & 0xFFFFF), t16 = (int)(t_tiers >> 40);
         run_cap += t_cap; run_chunk += t_chunk; run1 += t1; run4 += t4; run16 += t16;
         overflow = overflow || run_cap > a.w.list_capacity || (long long)run_chunk > a.w.chunk_cap;
+        PLAN_STAMP(2);
 #pragma unroll
         for (int i = 0; i < PLAN_PER; ++i) {
             const int row = r0 + i;
@@ -216,6 +269,7 @@ __global__ void __launch_bounds__(PLAN_THREADS) plan_kernel(const ChooseArgs a) 
             o_chunk += nch;
         }
     }
+    PLAN_STAMP(3);
     if (threadIdx.x == 0) {
         a.w.row_begin[rows] = run_cap;
         a.w.chunk_begin[rows] = run_chunk;
@@ -754,7 +808,8 @@ __global__ void __launch_bounds__(T1_WAVES_PER_BLOCK *PCG_WAVE) select_t1(const 
     const int w = threadIdx.x >> 6;
     const uint32_t qi = blockIdx.x * T1_WAVES_PER_BLOCK + w;
     if (qi >= a.w.counters[C_N1]) return;
-    select_row<1>(a, a.w.q1[qi], keys[w], ids[w], ckeys[w], cand[w], nullptr);
+    const int row = __builtin_amdgcn_readfirstlane(a.w.q1[qi]);     // one row per wave: make it scalar
+    select_row<1>(a, row, keys[w], ids[w], ckeys[w], cand[w], nullptr);
 }
 
 // tiers 4 / 16: one workgroup per row, rows pulled from the tier's queue
@@ -776,7 +831,7 @@ __global__ void __launch_bounds__(NW *PCG_WAVE) select_wide(const ChooseArgs a) 
         const uint32_t qi = (uint32_t)*qslot;
         __syncthreads();
         if (qi >= nq) break;
-        const int row = queue[qi];
+        const int row = __builtin_amdgcn_readfirstlane(queue[qi]);  // one row per workgroup: scalar
         if (NW == 16 && a.w.recs[row].d > CAP) {   // over-long hub row: ids + keys in global scratch
             uint32_t *gk = a.w.scratch + (size_t)blockIdx.x * 3 * a.g.max_degree;
             select_row<NW>(a, row, gk, gk + a.g.max_degree, gk + 2 * (size_t)a.g.max_degree, cand, red);

@@ -70,6 +70,35 @@ __device__ __forceinline__ f32x4 tile_lds_glob(const float *A, int lda, const fl
     return acc;
 }
 
+// C[16x16] += A[16 x K] (LDS) * B[K x ..] (LDS copy of a weight matrix, leading dim ldb, column n0..n0+15)
+__device__ __forceinline__ f32x4 tile_lds_lds(const float *A, int lda, const float *Bl, int ldb, int n0, int Kp,
+                                              int lane) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int r = lane & 15, kq = lane >> 4;
+#pragma unroll 8
+    for (int k0 = 0; k0 < Kp; k0 += 4) {
+        const int k = k0 + kq;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[r * lda + k], Bl[k * ldb + n0 + r], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// cooperative copy of a row-major [rows x cols] weight matrix into LDS with leading dim ld; rows..rows_pad-1 zeroed
+__device__ __forceinline__ void stage_weights(float *dst, int ld, const float *__restrict__ src, int rows, int rows_pad,
+                                              int cols) {
+    const int c4 = cols >> 2;                       // cols % 4 == 0 (E % 16 == 0)
+    for (int i = threadIdx.x; i < rows * c4; i += blockDim.x) {
+        const int rr = i / c4, cc = (i - rr * c4) * 4;
+        const float4 v = *reinterpret_cast<const float4 *>(src + (size_t)rr * cols + cc);
+        float *d = dst + rr * ld + cc;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    for (int i = threadIdx.x; i < (rows_pad - rows) * cols; i += blockDim.x) {
+        const int rr = rows + i / cols, cc = i % cols;
+        dst[rr * ld + cc] = 0.f;
+    }
+}
+
 // C[16x16] = At^T * Bt with both operands row tiles in LDS: C[m][n] = sum_t At[t][m0+m] * Bt[t][n0+n], t < 16
 __device__ __forceinline__ f32x4 tile_ldsT_lds(const float *At, int lda, int m0, int M, const float *Bt, int ldb, int n0,
                                                int lane) {
@@ -96,6 +125,9 @@ __device__ __forceinline__ void xent2(float a, float b, int y, float &loss, floa
     db = eb / s - (y == 1 ? 1.f : 0.f);
 }
 
+// WLDS: the weight matrices are staged in LDS once per workgroup (when they fit), so every MFMA operand
+// is an LDS read; otherwise the B operands stream from global memory / L2.
+template <bool WLDS>
 __global__ void __launch_bounds__(DENSE_WAVES *PCG_WAVE) dense_step_kernel(const DenseArgs a) {
     extern __shared__ __align__(16) float sm[];
     const int F = a.feat_dim, E = a.emb, R = a.n_rel;
@@ -108,12 +140,22 @@ __global__ void __launch_bounds__(DENSE_WAVES *PCG_WAVE) dense_step_kernel(const
     float *s_dh = s_dcomb + TB * ldE;         // [TB][ldE]
     float *s_dlog = s_dh + TB * ldE;          // [TB][2] d loss / d gnn logits
     float *s_dcl = s_dlog + TB * 2;           // [TB][2] d loss / d centre scores (already times lambda_1)
+    float *s_wc = s_dcl + TB * 2;             // [2][E] W_cls, [2][F] W_clf, [2] b_clf
+    float *s_wi = s_wc + 2 * E + 2 * F + 4;   // WLDS: [K2p][ldE] copy of W_inter
+    float *s_wr = s_wi + (WLDS ? K2p * ldE : 0);   // WLDS: [R][K1p][ldE] copies of W_intra
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = blockIdx.x * TB;
     const bool train = a.slabs != nullptr;
     if (train && a.step_counter && blockIdx.x == 0 && tid == 0) a.step_counter[0] += 1;
 
+    for (int i = tid; i < 2 * E; i += blockDim.x) s_wc[i] = a.W_cls[i];
+    for (int i = tid; i < 2 * F; i += blockDim.x) s_wc[2 * E + i] = a.W_clf[i];
+    if (tid < 2) s_wc[2 * E + 2 * F + tid] = a.b_clf[tid];
+    if constexpr (WLDS) {
+        stage_weights(s_wi, ldE, a.W_inter, K2, K2p, E);
+        for (int r = 0; r < R; ++r) stage_weights(s_wr + r * K1p * ldE, ldE, a.W_intra[r], K1, K1p, E);
+    }
     // zero the padded tiles, then load self rows into cat[:, :F]
     for (int i = tid; i < TB * ld2; i += blockDim.x) s_cat[i] = 0.f;
     for (int i = tid; i < TB * ld1; i += blockDim.x) s_catr[i] = 0.f;
@@ -136,7 +178,8 @@ __global__ void __launch_bounds__(DENSE_WAVES *PCG_WAVE) dense_step_kernel(const
         }
         __syncthreads();
         for (int ct = wave; ct < ntile_e; ct += DENSE_WAVES) {
-            const f32x4 c = tile_lds_glob(s_catr, ld1, a.W_intra[r], E, ct * 16, K1, K1p, lane);
+            const f32x4 c = WLDS ? tile_lds_lds(s_catr, ld1, s_wr + r * K1p * ldE, ldE, ct * 16, K1p, lane)
+                                 : tile_lds_glob(s_catr, ld1, a.W_intra[r], E, ct * 16, K1, K1p, lane);
             const int col = ct * 16 + (lane & 15), rq = (lane >> 4) * 4;
 #pragma unroll
             for (int i = 0; i < 4; ++i) s_cat[(rq + i) * ld2 + F + r * E + col] = fmaxf(c[i], 0.f);
@@ -145,7 +188,8 @@ __global__ void __launch_bounds__(DENSE_WAVES *PCG_WAVE) dense_step_kernel(const
     }
     // ---- combined = relu(cat W)   (layers.py:284-289) -------------------------------------
     for (int ct = wave; ct < ntile_e; ct += DENSE_WAVES) {
-        const f32x4 c = tile_lds_glob(s_cat, ld2, a.W_inter, E, ct * 16, K2, K2p, lane);
+        const f32x4 c = WLDS ? tile_lds_lds(s_cat, ld2, s_wi, ldE, ct * 16, K2p, lane)
+                             : tile_lds_glob(s_cat, ld2, a.W_inter, E, ct * 16, K2, K2p, lane);
         const int col = ct * 16 + (lane & 15), rq = (lane >> 4) * 4;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -157,17 +201,19 @@ __global__ void __launch_bounds__(DENSE_WAVES *PCG_WAVE) dense_step_kernel(const
     }
     __syncthreads();
     // ---- logits, centre scores, loss gradients (model.py:38, layers.py:243, model.py:54-61) ---
-    if (tid < TB * 4) {                       // thread = (row t, which of the 4 dot products)
-        const int t = tid >> 2, which = tid & 3;
+    {   // 16 rows x 4 dot products, each split over 4 lanes (256 threads), combined by a 2-step butterfly
+        const int part = tid & 3, which = (tid >> 2) & 3, t = tid >> 4;
         float acc = 0.f;
         if (which < 2) {
-            for (int e = 0; e < E; ++e) acc = fmaf(s_comb[t * ldE + e], a.W_cls[which * E + e], acc);
+            const float *wv = s_wc + which * E;
+            for (int e = part; e < E; e += 4) acc = fmaf(s_comb[t * ldE + e], wv[e], acc);
         } else {
-            const int cls = which - 2;
-            for (int f = 0; f < F; ++f) acc = fmaf(s_cat[t * ld2 + f], a.W_clf[cls * F + f], acc);
-            acc += a.b_clf[cls];
+            const float *wv = s_wc + 2 * E + (which - 2) * F;
+            for (int f = part; f < F; f += 4) acc = fmaf(s_cat[t * ld2 + f], wv[f], acc);
         }
-        s_dh[t * 4 + which] = acc;            // scratch: [t][g0, g1, c0, c1]
+        acc += __shfl_xor(acc, 1);
+        acc += __shfl_xor(acc, 2);
+        if (part == 0) s_dh[t * 4 + which] = acc + (which >= 2 ? s_wc[2 * E + 2 * F + (which - 2)] : 0.f);   // scratch: [t][g0, g1, c0, c1]
     }
     __syncthreads();
     if (tid < TB) {
@@ -200,7 +246,7 @@ __global__ void __launch_bounds__(DENSE_WAVES *PCG_WAVE) dense_step_kernel(const
     // dcomb = (dlogits W_cls) * relu'(combined)
     for (int i = tid; i < TB * E; i += blockDim.x) {
         const int t = i / E, e = i - t * E;
-        const float g = s_dlog[2 * t] * a.W_cls[e] + s_dlog[2 * t + 1] * a.W_cls[E + e];
+        const float g = s_dlog[2 * t] * s_wc[e] + s_dlog[2 * t + 1] * s_wc[E + e];
         s_dcomb[t * ldE + e] = s_comb[t * ldE + e] > 0.f ? g : 0.f;
     }
     // dW_cls[c][e] = sum_t dlogits[t][c] comb[t][e];  dW_clf[c][f] = sum_t dcl[t][c] self[t][f];  db_clf
@@ -252,7 +298,8 @@ __global__ void __launch_bounds__(DENSE_WAVES *PCG_WAVE) dense_step_kernel(const
 #pragma unroll 4
             for (int e0 = 0; e0 < E; e0 += 4) {
                 const float av = s_dcomb[rr * ldE + e0 + kq];
-                const float bv = Wr[(size_t)(ct * 16 + rr) * E + e0 + kq];
+                const float bv = WLDS ? s_wi[(F + r * E + ct * 16 + rr) * ldE + e0 + kq]
+                                      : Wr[(size_t)(ct * 16 + rr) * E + e0 + kq];
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
             }
             const int col = ct * 16 + rr, rq = kq * 4;
@@ -274,7 +321,9 @@ __global__ void __launch_bounds__(DENSE_WAVES *PCG_WAVE) dense_step_kernel(const
     }
 }
 
-// g = sum over slabs (tile order); torch.optim.Adam step with coupled weight decay
+// g = sum over slabs in a fixed order (8 interleaved partial sums, then a fixed tree), so 8 slab
+// reads are in flight per thread; torch.optim.Adam step with coupled weight decay.
+constexpr int ADAM_ACC = 8;
 __global__ void __launch_bounds__(256) adam_reduce_kernel(float *__restrict__ theta, float *__restrict__ m,
                                                           float *__restrict__ v, const float *__restrict__ slabs,
                                                           int n_slabs, int64_t n_params,
@@ -283,8 +332,16 @@ __global__ void __launch_bounds__(256) adam_reduce_kernel(float *__restrict__ th
                                                           float *__restrict__ grad_out, int apply) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_params) return;
-    float g = 0.f;
-    for (int s = 0; s < n_slabs; ++s) g += slabs[(size_t)s * n_params + i];
+    float acc[ADAM_ACC];
+#pragma unroll
+    for (int u = 0; u < ADAM_ACC; ++u) acc[u] = 0.f;
+    int s = 0;
+    for (; s + ADAM_ACC <= n_slabs; s += ADAM_ACC) {
+#pragma unroll
+        for (int u = 0; u < ADAM_ACC; ++u) acc[u] += slabs[(size_t)(s + u) * n_params + i];
+    }
+    for (int u = 0; s < n_slabs; ++s, ++u) acc[u] += slabs[(size_t)s * n_params + i];
+    float g = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     if (grad_out) grad_out[i] = g;
     if (!apply) return;
     const float p = theta[i];
@@ -299,9 +356,11 @@ __global__ void __launch_bounds__(256) adam_reduce_kernel(float *__restrict__ th
     theta[i] = p - (lr / bc1) * (mi / denom);
 }
 
-static size_t dense_smem_bytes(int F, int E, int R) {
+static size_t dense_smem_bytes(int F, int E, int R, bool wlds) {
     const int K1p = (2 * F + 3) & ~3, K2p = (F + R * E + 3) & ~3;
-    return sizeof(float) * (size_t)(TB * (K1p + 1) + TB * (K2p + 1) + 3 * TB * (E + 1) + 4 * TB);
+    size_t fl = (size_t)(TB * (K1p + 1) + TB * (K2p + 1) + 3 * TB * (E + 1) + 4 * TB + 2 * E + 2 * F + 4);
+    if (wlds) fl += (size_t)(K2p + R * K1p) * (E + 1);
+    return sizeof(float) * fl;
 }
 
 }  // namespace pcg
@@ -335,7 +394,8 @@ int pcg_dense_step(const pcg_graph_desc *g, const float *theta, int32_t emb, con
     if (emb < 16 || emb % 16 != 0 || g->n_rel < 1 || g->n_rel > PCG_MAX_REL) return PCG_E_UNSUPPORTED;
     if (slabs && !labels) return PCG_E_ARG;
     const int F = g->feat_dim, E = emb, R = g->n_rel;
-    const size_t smem = pcg::dense_smem_bytes(F, E, R);
+    const bool wlds = pcg::dense_smem_bytes(F, E, R, true) <= 160 * 1024;
+    const size_t smem = pcg::dense_smem_bytes(F, E, R, wlds);
     if (smem > 160 * 1024) return PCG_E_UNSUPPORTED;
     pcg::DenseArgs a;
     a.X = g->X;
@@ -364,13 +424,16 @@ int pcg_dense_step(const pcg_graph_desc *g, const float *theta, int32_t emb, con
     a.step_counter = step_counter;
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(pcg::dense_step_kernel),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(pcg::dense_step_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(pcg::dense_step_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return PCG_E_LAUNCH;
         attr = true;
     }
-    hipLaunchKernelGGL(pcg::dense_step_kernel, dim3((B + pcg::TB - 1) / pcg::TB), dim3(pcg::DENSE_WAVES * PCG_WAVE),
-                       smem, static_cast<hipStream_t>(stream), a);
+    const dim3 grid((B + pcg::TB - 1) / pcg::TB), block(pcg::DENSE_WAVES * PCG_WAVE);
+    if (wlds) hipLaunchKernelGGL(pcg::dense_step_kernel<true>, grid, block, smem, static_cast<hipStream_t>(stream), a);
+    else hipLaunchKernelGGL(pcg::dense_step_kernel<false>, grid, block, smem, static_cast<hipStream_t>(stream), a);
     PCG_LAUNCH_CHECK();
     return PCG_OK;
 }

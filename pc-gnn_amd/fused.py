@@ -176,7 +176,12 @@ class FusedPCGNN:
         self.lab_buf[:B].copy_(labels)
         if timed and self._prof is not None:
             gr["pre"].replay()
-            self._enqueue_choose(self.ids_buf[:B], self.lab_buf[:B], B, self.keys if self.g.n_pos else None, True)
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+            gr["choose"].replay()          # the same launches as inside "full", as a graph of their own
+            ev[1].record()
+            self._prof.append(ev)
+            self.last_counts = self.cnt.view(-1)[:self.g.R * B].view(self.g.R, B)
             gr["post"].replay()
         else:
             gr["full"].replay()
@@ -194,9 +199,12 @@ class FusedPCGNN:
             self._enqueue_dense(ids, lab, B, agg, True)
             self._enqueue_adam(B, apply=True)
 
+        def choose():
+            self._enqueue_choose(ids, lab, B, keys, True)
+
         def full():
             pre()
-            self._enqueue_choose(ids, lab, B, keys, True)
+            choose()
             post()
 
         # warm up on a side stream (sets kernel attributes) and put the optimizer state back afterwards
@@ -208,7 +216,7 @@ class FusedPCGNN:
             full()
         torch.cuda.current_stream(self.dev).wait_stream(s)
         graphs = {}
-        for name, fn in (("full", full), ("pre", pre), ("post", post)):
+        for name, fn in (("full", full), ("pre", pre), ("choose", choose), ("post", post)):
             gr = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gr):
                 fn()
@@ -218,6 +226,45 @@ class FusedPCGNN:
         self._prof = prof
         self._graphs[B] = graphs
         return graphs
+
+    # -- whole-epoch path: ids / labels of an epoch live in static buffers, one graph per batch slot ------
+    def begin_epoch(self, ids: torch.Tensor, labels: torch.Tensor, batch_size: int):
+        """Stage an epoch's (already shuffled) ids and labels; afterwards ``epoch_step(b)`` is exactly one
+        graph launch - no copies, no indexing kernels (model_handler.py:142-148 slices a Python list here)."""
+        n = ids.numel()
+        if getattr(self, "_ep_ids", None) is None or self._ep_ids.numel() < n:
+            self._ep_ids = torch.zeros(n, dtype=torch.int32, device=self.dev)
+            self._ep_lab = torch.zeros(n, dtype=torch.int32, device=self.dev)
+            self._ep_graphs = {}
+        self._ep_ids[:n].copy_(ids)
+        self._ep_lab[:n].copy_(labels)
+        self._ep_n, self._ep_bs = n, batch_size
+
+    def epoch_step(self, b: int):
+        lo = b * self._ep_bs
+        B = min(self._ep_bs, self._ep_n - lo)
+        if B <= 0:
+            return
+        self._lastB = B
+        key = (lo, B)
+        gr = self._ep_graphs.get(key)
+        if gr is None:
+            ids, lab = self._ep_ids[lo:lo + B], self._ep_lab[lo:lo + B]
+            state = (self.theta.clone(), self.m.clone(), self.v.clone(), self.step_counter.clone())
+            prof, self._prof = self._prof, None
+            s = torch.cuda.Stream(self.dev)
+            s.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(s):
+                self.train_step(ids, lab)
+            torch.cuda.current_stream(self.dev).wait_stream(s)
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                self.train_step(ids, lab)
+            for dst, src in zip((self.theta, self.m, self.v, self.step_counter), state):
+                dst.copy_(src)
+            self._prof = prof
+            self._ep_graphs[key] = gr
+        gr.replay()
 
     def last_loss(self) -> torch.Tensor:
         B = self._lastB

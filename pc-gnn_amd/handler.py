@@ -85,6 +85,15 @@ class PCGNNTrainer:
         self.opt.step()
         return loss
 
+    def run_epoch_graph(self, epoch: int) -> int:
+        """One epoch through the per-slot graphs: pick + shuffle + label gather once, then one graph
+        launch per batch.  Returns the number of sampled nodes."""
+        ids = self.start_epoch(epoch)
+        self.fused.begin_epoch(ids, self.labels_i32[ids.long()], self.batch_size)
+        for b in range(self.batches_per_epoch()):
+            self.fused.epoch_step(b)
+        return self.pick_size
+
     def train_epoch(self, epoch: int):
         """Returns (#sampled nodes, seconds inside the reference's per-batch window,
         seconds including pick + shuffle)."""

@@ -10,14 +10,16 @@ fz = tr.fused; g = fz.g; lib = _lib.load()
 ids_all = tr.start_epoch(0)
 B = 1024; ids = ids_all[:B].contiguous(); lab = tr.labels_i32[ids.long()]
 rows = g.R * B
-stamps = torch.zeros(rows, 8, dtype=torch.int64, device="cuda")
+stamps = torch.zeros(rows + 1, 8, dtype=torch.int64, device="cuda")
 for it in range(3):
     keys = fz._enqueue_scores(True)
     if it == 2: lib.pcg_debug_set_stamps(C.c_void_p(stamps.data_ptr()))
     fz._enqueue_choose(ids, lab, B, keys, True)
     torch.cuda.synchronize()
 lib.pcg_debug_set_stamps(None)
-st = stamps.cpu().numpy().astype(np.float64) * 0.01   # us
+plan = stamps[rows].cpu().numpy().astype(np.float64) * 0.01
+print('plan phases (us): load+rowplan %.2f, scans %.2f, writes %.2f; plan start -> first select start %.2f' % (plan[1]-plan[0], plan[2]-plan[1], plan[3]-plan[2], stamps[:rows,0].cpu().numpy().min()*0.01 - plan[0]))
+st = stamps[:rows].cpu().numpy().astype(np.float64) * 0.01   # us
 deg = np.stack([g.deg_host[r][ids.cpu().numpy()] for r in range(g.R)]).reshape(-1)
 t0 = st[:, 0].min()
 names = ["rec+keys(1)", "kth(2)", "compact+list(3)", "min-search(4)", "min-resolve(5)", "tail(6)"]
@@ -35,8 +37,8 @@ for lo, hi, tier in ((0, 512, "T1"), (512, 4096, "T4"), (4096, 1 << 30, "T16")):
     tot = s[:, 6] - s[:, 0]
     print(f"   total per row      mean {tot.mean():7.2f} us  max {tot.max():7.2f}")
 
-rounds = (stamps.cpu().numpy()[:, 7] & 0xFFFFFFFF).astype(np.int64)
-ncand = (stamps.cpu().numpy()[:, 7] >> 32).astype(np.int64)
+rounds = (stamps[:rows].cpu().numpy()[:, 7] & 0xFFFFFFFF).astype(np.int64)
+ncand = (stamps[:rows].cpu().numpy()[:, 7] >> 32).astype(np.int64)
 kth = st[:, 2] - st[:, 1]
 print("kth phase by degree bucket: rows, mean us, max us, mean rounds, max rounds, mean ncand at exit")
 for lo, hi in ((0, 3), (3, 64), (64, 128), (128, 256), (256, 512), (512, 1024), (1024, 4096), (4096, 1 << 30)):
