@@ -1,0 +1,129 @@
+"""Host-side helpers around the hot path, mirroring the reference's src/utils.py where the
+training / evaluation loop touches them: ``test`` (:280-333), ``pos_neg_split`` (:256-271),
+``normalize`` (:212-222), ``sparse_to_adjlist_for_train`` / graph ingestion (:226-254), ``set_seeds``.
+
+``test`` keeps the reference's signature and return value; predictions stay on the device for the
+whole pass and come back in ONE copy (the reference copies every batch, :305), and the
+degenerate empty trailing batch its ``int(len/B)+1`` produces is not run.  Metrics are computed
+with numpy restatements of the sklearn functions the reference calls (checked against sklearn in
+the tests), so evaluation does not depend on sklearn being installed.
+"""
+import random
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+
+# ---- metrics (sklearn.metrics.{accuracy,f1,precision,recall,roc_auc}_score restated) --------------
+def _prf(y, p, cls):
+    tp = float(np.sum((p == cls) & (y == cls)))
+    fp = float(np.sum((p == cls) & (y != cls)))
+    fn = float(np.sum((p != cls) & (y == cls)))
+    prec = tp / (tp + fp) if tp + fp > 0 else 0.0         # zero_division=0 (utils.py:319)
+    rec = tp / (tp + fn) if tp + fn > 0 else 0.0
+    f1 = 2 * prec * rec / (prec + rec) if prec + rec > 0 else 0.0
+    return prec, rec, f1
+
+
+def binary_metrics(y_true, y_pred, y_score) -> dict:
+    y = np.asarray(y_true).astype(np.int64)
+    p = np.asarray(y_pred).astype(np.int64)
+    p1, r1, f1 = _prf(y, p, 1)
+    p0, r0, f0 = _prf(y, p, 0)
+    return {"accuracy": float(np.mean(y == p)), "f1": f1, "f1_macro": (f1 + f0) / 2, "precision": p1,
+            "precision_macro": (p1 + p0) / 2, "recall": r1, "recall_macro": (r1 + r0) / 2, "auc": roc_auc(y, y_score)}
+
+
+def roc_auc(y_true, score) -> float:
+    """Area under the ROC curve = Mann-Whitney U with average ranks for ties."""
+    y = np.asarray(y_true).astype(bool)
+    s = np.asarray(score, dtype=np.float64)
+    n1, n0 = int(y.sum()), int((~y).sum())
+    if n1 == 0 or n0 == 0:
+        raise ValueError("Only one class present in y_true. ROC AUC score is not defined in that case.")
+    order = np.argsort(s, kind="mergesort")
+    ranks = np.empty(len(s), dtype=np.float64)
+    sorted_s = s[order]
+    i = 0
+    while i < len(s):
+        j = i
+        while j + 1 < len(s) and sorted_s[j + 1] == sorted_s[i]:
+            j += 1
+        ranks[order[i:j + 1]] = 0.5 * (i + j) + 1.0
+        i = j + 1
+    return float((ranks[y].sum() - n1 * (n1 + 1) / 2.0) / (n1 * n0))
+
+
+def test(test_nodes, labels, model, batch_size: int, result=None, epoch: Optional[int] = None,
+         epoch_best: Optional[int] = None, flag: Optional[str] = None,
+         print_line: Optional[bool] = True) -> Tuple[float, float, float, float]:
+    """Evaluate ``model`` (PCALayer / GCN / GraphSage mirror, or a FusedPCGNN) on ``test_nodes``:
+    batched ``to_prob(..., train_flag=False)`` -> argmax / positive-class confidence -> metrics.
+    Returns (auc, recall, f1_macro, precision) like the reference (utils.py:333)."""
+    nodes = np.asarray(test_nodes)
+    labels = np.asarray(labels)
+    outs = []
+    with torch.no_grad():
+        for start in range(0, len(nodes), batch_size):                      # :298-303 (no empty trailing batch)
+            batch = nodes[start:start + batch_size]
+            blab = labels[start:start + batch_size]
+            if hasattr(model, "predict"):                                   # FusedPCGNN
+                ids = torch.as_tensor(batch, dtype=torch.int32, device=model.dev)
+                outs.append(torch.sigmoid(model.predict(ids, None, False)[0]))
+            else:
+                outs.append(model.to_prob(batch.tolist(), blab, train_flag=False)[0])   # :305
+    prob = torch.cat(outs).float().cpu().numpy() if outs else np.zeros((0, 2), np.float32)
+    pred = prob.argmax(axis=1)                                               # :306
+    m = binary_metrics(labels, pred, prob[:, 1])                             # :308, :316-323
+    line = (f"- F1: {m['f1']:.4f}\t- Recall: {m['recall']:.4f}\t- Precision: {m['precision']:.4f}\t"
+            f"- Accuracy: {m['accuracy']:.4f}\t- AUC-ROC: {m['auc']:.4f}\t- F1-macro: {m['f1_macro']:.4f}\t"
+            f"- Recall-macro: {m['recall_macro']:.4f}\t- AP: {m['precision_macro']:.4f}\t\n")   # :325
+    if result is not None:
+        args = (m["accuracy"], m["f1"], m["f1_macro"], m["precision"], m["precision_macro"], m["recall"],
+                m["recall_macro"], m["auc"], line, print_line)
+        if flag == "val":
+            result.write_val_log(epoch, epoch_best, *args)
+        elif flag == "test":
+            result.write_test_log(epoch_best, *args)
+    elif print_line:
+        print(line, end="")
+    return m["auc"], m["recall"], m["f1_macro"], m["precision"]
+
+
+# ---- data helpers ------------------------------------------------------------------------------------
+def pos_neg_split(nodes, labels):
+    """positive / negative node ids in input order (utils.py:256-271, which is O(n^2) there)."""
+    nodes = list(nodes)
+    lab = np.asarray(labels)
+    pos = [n for n, l in zip(nodes, lab) if l == 1]
+    neg = [n for n, l in zip(nodes, lab) if l != 1]
+    return pos, neg
+
+
+def normalize(mx):
+    """Row-normalise a dense or scipy-sparse feature matrix: x / (rowsum + 0.01) (utils.py:212-222)."""
+    import scipy.sparse as sp
+    rowsum = np.array(mx.sum(1)) + 0.01
+    r_inv = np.power(rowsum, -1).flatten()
+    r_inv[np.isinf(r_inv)] = 0.
+    return sp.diags(r_inv).dot(mx)
+
+
+def sparse_to_csr(sp_matrix):
+    """What sparse_to_adjlist_for_train (utils.py:243-254) builds - self-loops added, symmetrised - but
+    straight to the device layout: (indptr int64, indices int32 ascending), no dict-of-sets in between."""
+    import scipy.sparse as sp
+    a = sp.csr_matrix(sp_matrix)
+    a = a + a.T + sp.eye(a.shape[0], format="csr")
+    a.sum_duplicates()
+    a.sort_indices()
+    return a.indptr.astype(np.int64), a.indices.astype(np.int32)
+
+
+def set_seeds(seed):
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)

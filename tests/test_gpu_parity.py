@@ -441,3 +441,61 @@ def test_fused_graph_equals_eager_and_torch(P, case):
     for k in PARAM_KEYS(c.R):
         np.testing.assert_allclose(sd1[k].cpu().numpy(), sd3[k].cpu().numpy(), rtol=0, atol=c.lr * 0.25, err_msg=k)
     assert abs(float(f1.last_loss()) - float(f2.last_loss())) == 0.0
+
+
+# ---------------------------------------------------------------------------
+# GraphSAGE / GCN baselines and the evaluation loop on the same kernels
+# ---------------------------------------------------------------------------
+def test_graphsage_gcn_models_golden(P, case):
+    from pcgnn_amd import graphsage as GS
+    c = case
+    feats = torch.nn.Embedding(c.n, c.f)
+    feats.weight = torch.nn.Parameter(torch.from_numpy(c.X.copy()), requires_grad=False)
+    homo = c.adj(None)
+    sub = c.z["s1_nodes"].tolist()
+    # Encoder(gcn=True) over a MeanAggregator with its own gcn=False - exactly what the fixture generator built
+    enc = GS.Encoder(feats, c.f, c.emb, homo, GS.MeanAggregator(feats, cuda=True), gcn=True, cuda=True).to("cuda")
+    with torch.no_grad():
+        enc.weight.copy_(torch.from_numpy(c.z["s1_sage_enc_w"]))
+    np.testing.assert_allclose(enc(sub).detach().cpu().numpy(), c.z["s1_sage_enc"], rtol=0, atol=FEAT_TOL)
+    genc = GS.GCNEncoder(feats, c.f, c.emb, homo, GS.GCNAggregator(feats, cuda=True), cuda=True).to("cuda")
+    with torch.no_grad():
+        genc.weight.copy_(torch.from_numpy(c.z["s1_gcn_enc_w"]))
+    np.testing.assert_allclose(genc(sub).detach().cpu().numpy(), c.z["s1_gcn_enc"], rtol=0, atol=5e-5)
+    # aggregators with explicit neighbour sets (reference call shape) incl. the gcn self-union
+    neighs = [homo[int(v)] for v in sub]
+    magg = GS.MeanAggregator(feats, cuda=True, gcn=True)
+    magg._dev = dev()
+    magg.adj_lists = None
+    got = magg.forward(sub, neighs)
+    np.testing.assert_allclose(got.cpu().numpy(), c.z["s1_mean_gcn"], rtol=0, atol=FEAT_TOL)
+    # full models train: loss decreases over a few Adam steps
+    labels = c.labels[np.array(sub)]
+    for model in (GS.GCN(2, genc).to("cuda"), GS.GraphSage(2, enc).to("cuda")):
+        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=0.01)
+        losses = []
+        for _ in range(8):
+            opt.zero_grad()
+            loss = model.loss(sub, torch.from_numpy(labels).cuda())
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        assert losses[-1] < losses[0]
+        prob, _ = model.to_prob(sub, labels, train_flag=False)
+        assert tuple(prob.shape) == (len(sub), 2)
+
+
+def test_eval_loop_matches_reference_probabilities(P, case):
+    """utils.test mirror (utils.py:280-333): batched inference -> metrics, torch path and fused path."""
+    from pcgnn_amd import utils as U
+    from pcgnn_amd.fused import FusedPCGNN
+    c = case
+    prob = c.z["test_gnn_prob"]
+    want = U.binary_metrics(c.batch_labels, prob.argmax(1), prob[:, 1])
+    m = build_model(P, c, c.rhos[0], graph=graph_of(P, c))
+    auc, recall, f1m, prec = U.test(np.array(c.nodes), c.batch_labels, m, batch_size=50, print_line=False)
+    assert abs(auc - want["auc"]) < 1e-6 and abs(f1m - want["f1_macro"]) < 1e-6
+    assert abs(recall - want["recall"]) < 1e-6 and abs(prec - want["precision"]) < 1e-6
+    fz = FusedPCGNN(m, c.lr, c.wd, max_batch=64)
+    auc2, recall2, f1m2, prec2 = U.test(np.array(c.nodes), c.batch_labels, fz, batch_size=64, print_line=False)
+    assert abs(auc2 - want["auc"]) < 1e-6 and abs(f1m2 - want["f1_macro"]) < 1e-6
