@@ -499,3 +499,67 @@ def test_eval_loop_matches_reference_probabilities(P, case):
     fz = FusedPCGNN(m, c.lr, c.wd, max_batch=64)
     auc2, recall2, f1m2, prec2 = U.test(np.array(c.nodes), c.batch_labels, fz, batch_size=64, print_line=False)
     assert abs(auc2 - want["auc"]) < 1e-6 and abs(f1m2 - want["f1_macro"]) < 1e-6
+
+
+# ---------------------------------------------------------------------------
+# BASELINE-size workload (configs[1]: YelpChi-shaped graph, batch 1024): size-independent properties
+# ---------------------------------------------------------------------------
+def test_full_size_properties_yelp_like(P):
+    from pcgnn_amd import synth
+    from pcgnn_amd.handler import PCGNNTrainer
+    ops = P.ops
+    w = synth.yelp_like(0)
+    tr = PCGNNTrainer(w, dict(engine="fused", batch_size=1024), dev())
+    g, fz = tr.graph, tr.fused
+    ids = tr.start_epoch(0)[:1024].contiguous()
+    lab = tr.labels_i32[ids.long()]
+    s0 = ops.score_table(g, fz.w_clf, fz.b_clf)
+    keys = ops.pos_sort(g, s0)
+    B, R = 1024, g.R
+    ids_h, lab_h = ids.cpu().numpy(), lab.cpu().numpy()
+    tp = set(w.train_pos)
+    for train in (False, True):
+        ws = ops.ChooseWorkspace(g, B)
+        agg, cnt = ops.choose_aggregate(g, ids, lab if train else None, s0, keys if train else None, [0.5] * R, 0.5, train, ws=ws)
+        agg2, cnt2 = ops.choose_aggregate(g, ids, lab if train else None, s0, keys if train else None, [0.5] * R, 0.5, train, ws=ws)
+        torch.cuda.synchronize()
+        assert torch.equal(agg, agg2) and torch.equal(cnt, cnt2), "idempotent and run-to-run bitwise reproducible"
+        begin = ws.view(0, torch.int64, R * B + 1).cpu().numpy()
+        length = ws.view(1, torch.int32, R * B).cpu().numpy()
+        lst = ws.view(2, torch.int32, int(begin[-1])).cpu().numpy()
+        cnt_h = cnt.cpu().numpy()
+        # recompute every mean from the materialised lists in float64 on the host (size-independent check of gather + combine)
+        for r in range(R):
+            indptr, idx = w.csr[r]
+            deg = np.diff(indptr)[ids_h]
+            k = np.ceil(deg * 0.5).astype(np.int64)
+            kept = np.where(deg > k + 1, k, deg)
+            for b in range(0, B, 7):                      # every 7th centre: ~150 rows per relation, hubs included
+                row = r * B + b
+                seg = lst[begin[row]:begin[row] + length[row]]
+                chosen = seg[seg >= 0]
+                assert len(chosen) == cnt_h[r, b] and len(set(chosen.tolist())) == len(chosen), "a set: no duplicates"
+                nb = idx[indptr[ids_h[b]]:indptr[ids_h[b] + 1]]
+                first = chosen[:kept[b]]
+                assert np.all(np.diff(first) > 0) and np.isin(first, nb).all(), "kept neighbours: ascending subset of the row"
+                extra = chosen[kept[b]:]
+                if not train or lab_h[b] != 1:
+                    assert len(extra) == 0 and cnt_h[r, b] == kept[b]
+                else:
+                    m = min(int(k[b] * 0.5), len(w.train_pos))
+                    assert len(extra) <= m and all(int(e) in tp for e in extra) and not np.isin(extra, first).any()
+                ref = w.X[chosen].astype(np.float64).mean(0)
+                np.testing.assert_allclose(agg[r, b].cpu().numpy(), ref, rtol=0, atol=2e-5)
+        # test mode count law over ALL rows at once
+        if not train:
+            for r in range(R):
+                deg = np.diff(w.csr[r][0])[ids_h]
+                k = np.ceil(deg * 0.5).astype(np.int64)
+                assert np.array_equal(cnt_h[r], np.where(deg > k + 1, k, deg))
+    # a few training epochs through the hipGraph engine: finite loss that goes down
+    tr2 = PCGNNTrainer(w, dict(engine="graph", batch_size=1024), dev())
+    losses = []
+    for e in range(4):
+        tr2.train_epoch(e)
+        losses.append(float(tr2.fused.last_loss()))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
