@@ -126,7 +126,7 @@ def run_partitioned(args, w, B, lr, wd, dev, dist, world, rank):
     for k in range(args.steps):
         one_step(args.warmup + k)
         st = d.halo.last_stats
-        halo_rows += st["halo_rows"]; remote += st["remote_entries"]; entries += st["entries"]
+        halo_rows += st["halo_rows"]; remote += st.get("rows_served", 0); entries += st["bytes_in"]
     barrier()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -148,8 +148,7 @@ def run_partitioned(args, w, B, lr, wd, dev, dist, world, rank):
                        "global_batch": B * world, "parallelism": f"node-partition x{world}: score all-gather, "
                        "id + feature-row all-to-all, grad all-reduce (RCCL)", "engine": "fused-eager",
                        "nodes_processed": int(nodes_total),
-                       "per_rank_per_step": {"chosen_entries": en, "remote_entries": rm, "halo_rows_fetched": hr,
-                                             "halo_bytes": hr * w.X.shape[1] * 4}},
+                       "per_rank_per_step": {"halo_rows_fetched": hr, "rows_served_to_others": rm, "halo_bytes_in": en}},
         }
         print(json.dumps(out))
     dist.destroy_process_group()

@@ -145,6 +145,7 @@ int pcg_choose_aggregate(const pcg_graph_desc *g, const int32_t *nodes, const in
 
 /* diagnostic only: per-row phase timestamps of the select kernels ([rows][8] uint64, 10-ns ticks); NULL = off */
 void pcg_debug_set_stamps(void *ptr);
+void pcg_debug_set_dense_stamps(void *ptr);   /* [tiles][16] uint64 per dense_step tile */
 
 /* Upper bound on |chosen set| of one row (host helper, pure arithmetic):
  * (deg > k+1 ? k : deg) + m [+1 if add_self]. */
@@ -201,6 +202,19 @@ int pcg_dense_step(const pcg_graph_desc *g, const float *theta, int32_t emb,
 int pcg_adam_step(float *theta, float *m, float *v, const float *slabs, int32_t n_slabs, int64_t n_params,
                   const int32_t *step_counter, double lr, double beta1, double beta2, double eps,
                   double weight_decay, float *grad_out, int32_t apply, void *stream);
+
+/* ---- multi-GPU halo exchange helpers (no counterpart in the reference) ----------
+ * The selection list of a partitioned run holds GLOBAL ids.  `total` is a device int64: the
+ * number of list entries in use (row_begin[n_rel*B] of the choose workspace).
+ * classify: owned id (lo <= id < hi) -> id - lo; train-pos id (posmap[id] >= 0) -> n_local + posmap[id];
+ *           remote id -> -(id + 2) in the list and flag[id] = 1 (flag: int32 [n_nodes], all zero on entry).
+ * compact : uniq[slot[v] - 1] = v for every flagged v, slot = inclusive prefix sum of flag (caller-computed).
+ * remap   : marked entries -> halo_base + slot[id] - 1; clears the flags it meets. */
+int pcg_halo_classify(int32_t *list, const int64_t *total, int64_t list_capacity, int32_t lo, int32_t hi,
+                      int32_t n_local, const int32_t *posmap, int32_t *flag, void *stream);
+int pcg_halo_compact(const int32_t *flag, const int32_t *slot, int32_t n_nodes, int32_t *uniq, void *stream);
+int pcg_halo_remap(int32_t *list, const int64_t *total, int64_t list_capacity, const int32_t *slot,
+                   int32_t halo_base, int32_t *flag, void *stream);
 
 /* gather rows: out[i, :feat_dim] = X[ids[i], :feat_dim]  (self_feats, layers.py:273-277) */
 int pcg_gather_rows(const pcg_graph_desc *g, const int32_t *ids, int32_t n_ids,

@@ -51,10 +51,14 @@ PROTOTYPES = {
     "pcg_choose_aggregate": (C.c_int, [_G, _P, _P, _I32, _P, _P, _P, C.POINTER(_F64), C.POINTER(_F64), _I32, _I32,
                                        _I32, _P, _I32, _P, _P, _I64, _P, _P]),
     "pcg_debug_set_stamps": (None, [_P]),
+    "pcg_debug_set_dense_stamps": (None, [_P]),
     "pcg_sel_capacity_row": (_I64, [_I64, _F64, _F64, _I32, _I32, _I32]),
     "pcg_segment_mean": (C.c_int, [_G, _P, _P, _P, _I32, _I32, _P, _I32, _P]),
     "pcg_pick": (C.c_int, [_P, _P, _I32, _P, _U64, _U64, _I32, _P, _P]),
     "pcg_gather_rows": (C.c_int, [_G, _P, _I32, _P, _I32, _P]),
+    "pcg_halo_classify": (C.c_int, [_P, _P, _I64, _I32, _I32, _I32, _P, _P, _P]),
+    "pcg_halo_compact": (C.c_int, [_P, _P, _I32, _P, _P]),
+    "pcg_halo_remap": (C.c_int, [_P, _P, _I64, _P, _I32, _P, _P]),
     "pcg_dense_n_params": (_I64, [_I32, _I32, _I32]),
     "pcg_dense_param_offset": (_I64, [_I32, _I32, _I32, _I32, _I32]),
     "pcg_dense_n_tiles": (_I32, [_I32]),

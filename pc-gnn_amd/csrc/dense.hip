@@ -43,7 +43,9 @@ struct DenseArgs {
     float *slabs;               // [n_tiles, n_params] or null
     int64_t n_params;
     int32_t *step_counter;      // incremented once per training launch (Adam's t), or null
+    unsigned long long *stamps; // diagnostic only (pcg_debug_set_dense_stamps): [tiles][16] wall-clock ticks, else null
 };
+#define DENSE_STAMP(slot) do { if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 16 + (slot)] = wall_clock64(); } while (0)
 
 // flat parameter / gradient order: W_cls | W_inter | W_intra[0..R) | W_clf | b_clf
 __host__ __device__ inline int64_t off_cls(int F, int E, int R) { return 0; }
@@ -148,6 +150,7 @@ __global__ void __launch_bounds__(DENSE_WAVES *PCG_WAVE) dense_step_kernel(const
     const int row0 = blockIdx.x * TB;
     const bool train = a.slabs != nullptr;
     if (train && a.step_counter && blockIdx.x == 0 && tid == 0) a.step_counter[0] += 1;
+    DENSE_STAMP(0);
 
     for (int i = tid; i < 2 * E; i += blockDim.x) s_wc[i] = a.W_cls[i];
     for (int i = tid; i < 2 * F; i += blockDim.x) s_wc[2 * E + i] = a.W_clf[i];
@@ -167,6 +170,7 @@ __global__ void __launch_bounds__(DENSE_WAVES *PCG_WAVE) dense_step_kernel(const
     }
     __syncthreads();
 
+    DENSE_STAMP(1);
     // ---- forward: h_r = relu([self | agg_r] W_r)   (layers.py:625-629) -----------------
     const int ntile_e = E / 16;
     for (int r = 0; r < R; ++r) {
@@ -186,6 +190,7 @@ __global__ void __launch_bounds__(DENSE_WAVES *PCG_WAVE) dense_step_kernel(const
         }
         __syncthreads();
     }
+    DENSE_STAMP(2);
     // ---- combined = relu(cat W)   (layers.py:284-289) -------------------------------------
     for (int ct = wave; ct < ntile_e; ct += DENSE_WAVES) {
         const f32x4 c = WLDS ? tile_lds_lds(s_cat, ld2, s_wi, ldE, ct * 16, K2p, lane)
@@ -200,6 +205,7 @@ __global__ void __launch_bounds__(DENSE_WAVES *PCG_WAVE) dense_step_kernel(const
         }
     }
     __syncthreads();
+    DENSE_STAMP(3);
     // ---- logits, centre scores, loss gradients (model.py:38, layers.py:243, model.py:54-61) ---
     {   // 16 rows x 4 dot products, each split over 4 lanes (256 threads), combined by a 2-step butterfly
         const int part = tid & 3, which = (tid >> 2) & 3, t = tid >> 4;
@@ -239,6 +245,7 @@ __global__ void __launch_bounds__(DENSE_WAVES *PCG_WAVE) dense_step_kernel(const
         s_dcl[2 * t] = dc0; s_dcl[2 * t + 1] = dc1;
     }
     __syncthreads();
+    DENSE_STAMP(4);
     if (!train) return;
 
     float *slab = a.slabs + (size_t)blockIdx.x * a.n_params;
@@ -268,6 +275,7 @@ __global__ void __launch_bounds__(DENSE_WAVES *PCG_WAVE) dense_step_kernel(const
         slab[off_bias(F, E, R) + tid] = s;
     }
     __syncthreads();
+    DENSE_STAMP(5);
     // dW_inter[m][n] = sum_t cat[t][m] dcomb[t][n]
     {
         const int mt = (K2 + 15) / 16;
@@ -281,6 +289,7 @@ __global__ void __launch_bounds__(DENSE_WAVES *PCG_WAVE) dense_step_kernel(const
                 if (m0 + rq + i < K2) dst[(size_t)(m0 + rq + i) * E + col] = c[i];
         }
     }
+    DENSE_STAMP(6);
     // per relation: dh_r = (dcomb W[F+rE.., :]^T) * relu'(h_r);  dW_r = [self|agg_r]^T dh_r
     for (int r = 0; r < R; ++r) {
         __syncthreads();
@@ -319,6 +328,8 @@ __global__ void __launch_bounds__(DENSE_WAVES *PCG_WAVE) dense_step_kernel(const
                 if (m0 + rq + i < K1) dst[(size_t)(m0 + rq + i) * E + col] = c[i];
         }
     }
+    __syncthreads();
+    DENSE_STAMP(7);
 }
 
 // g = sum over slabs in a fixed order (8 interleaved partial sums, then a fixed tree), so 8 slab
@@ -363,9 +374,13 @@ static size_t dense_smem_bytes(int F, int E, int R, bool wlds) {
     return sizeof(float) * fl;
 }
 
+static unsigned long long *g_dense_stamps = nullptr;
+
 }  // namespace pcg
 
 extern "C" {
+
+void pcg_debug_set_dense_stamps(void *ptr) { pcg::g_dense_stamps = static_cast<unsigned long long *>(ptr); }
 
 int64_t pcg_dense_n_params(int32_t feat_dim, int32_t emb, int32_t n_rel) {
     if (feat_dim < 1 || emb < 1 || n_rel < 1 || n_rel > PCG_MAX_REL) return PCG_E_ARG;
@@ -422,6 +437,7 @@ int pcg_dense_step(const pcg_graph_desc *g, const float *theta, int32_t emb, con
     a.slabs = slabs;
     a.n_params = pcg::n_params_of(F, E, R);
     a.step_counter = step_counter;
+    a.stamps = pcg::g_dense_stamps;
     static bool attr = false;
     if (!attr) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(pcg::dense_step_kernel<true>),

@@ -122,6 +122,64 @@ class HaloExchange:
         return n_halo
 
 
+class HaloExchangeHip(HaloExchange):
+    """Same exchange with the list work done by three HIP kernels (pcg_halo_classify / _compact / _remap)
+    and ONE host synchronisation per step: the per-owner request counts of every rank are all-gathered as
+    a world x world matrix, which gives a rank both its send and its receive split sizes."""
+
+    def __init__(self, part, X_ext, n_pos, posmap, n_nodes, group=None, stage_host=False):
+        super().__init__(part, X_ext, n_pos, posmap, group, stage_host)
+        from . import _lib, ops
+        self._lib, self._ops = _lib, ops
+        dev = X_ext.device
+        self.flag = torch.zeros(n_nodes, dtype=torch.int32, device=dev)
+        self.uniq = torch.empty(self.halo_cap, dtype=torch.int32, device=dev)
+        self.n_nodes = n_nodes
+        w = part.world
+        self._last = torch.tensor([min((r + 1) * part.n_per, n_nodes) - 1 for r in range(w)], dtype=torch.long, device=dev)
+        self._counts_all = torch.zeros(w * w, dtype=torch.int32, device=dev)
+        self._req = torch.empty(self.halo_cap, dtype=torch.int32, device=dev)
+        self._rows = torch.zeros(self.halo_cap, X_ext.shape[1], dtype=torch.float32, device=dev)
+
+    def _gather_counts(self, out, inp):
+        if self.stage_host:
+            o = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(o, inp.cpu(), group=self.group)
+            out.copy_(o)
+        else:
+            dist.all_gather_into_tensor(out, inp, group=self.group)
+
+    def fetch_and_remap_device(self, lst_full: torch.Tensor, total_dev: torch.Tensor, graph) -> int:
+        """lst_full: the workspace's whole list buffer; total_dev: device int64 scalar (entries in use)."""
+        lib, ops, part = self._lib.load(), self._ops, self.part
+        _p, st = ops._p, ops._stream(lst_full.device)
+        w, rank = part.world, part.rank
+        self._lib.check(lib.pcg_halo_classify(_p(lst_full), _p(total_dev), lst_full.numel(), part.lo, part.hi, part.n_local,
+                                              _p(self.posmap), _p(self.flag), st), "pcg_halo_classify")
+        slot = torch.cumsum(self.flag, 0, dtype=torch.int32)
+        ends = slot[self._last]                                            # inclusive count up to each owner's last id
+        counts = torch.diff(ends, prepend=ends.new_zeros(1))              # ids requested from every owner
+        self._gather_counts(self._counts_all, counts.contiguous())
+        mat = self._counts_all.view(w, w).cpu()                            # the step's single host sync
+        sc, rc = mat[rank].tolist(), mat[:, rank].tolist()
+        n_halo, n_req = sum(sc), sum(rc)
+        if n_halo > self.halo_cap or n_req > self.halo_cap:
+            raise RuntimeError(f"halo needs {max(n_halo, n_req)} rows but only {self.halo_cap} were reserved")
+        self._lib.check(lib.pcg_halo_compact(_p(self.flag), _p(slot), self.n_nodes, _p(self.uniq), st), "pcg_halo_compact")
+        req = self._req[:n_req]
+        self._a2a(req, self.uniq[:n_halo], rc, sc)                         # all-to-all #1: requested ids
+        rows = self._rows[:n_req]
+        if n_req:
+            ops.gather_rows(graph, req - part.lo, out=rows)                # the owner gathers its rows (pad columns stay 0)
+        halo = self.X_ext[self.halo_base:self.halo_base + n_halo]
+        self._a2a(halo, rows, sc, rc)                                      # all-to-all #2: feature rows
+        self._lib.check(lib.pcg_halo_remap(_p(lst_full), _p(total_dev), lst_full.numel(), _p(slot), self.halo_base,
+                                           _p(self.flag), st), "pcg_halo_remap")
+        self.last_stats = {"halo_rows": n_halo, "rows_served": n_req, "bytes_in": n_halo * self.X_ext.shape[1] * 4,
+                           "bytes_out": n_req * self.X_ext.shape[1] * 4}
+        return n_halo
+
+
 class DistributedPCGNN:
     """The step driver of one rank of a node-partitioned run (HIP kernels + RCCL)."""
 
@@ -159,7 +217,7 @@ class DistributedPCGNN:
         posmap = torch.full((w.n,), -1, dtype=torch.int32)
         if P:
             posmap[torch.as_tensor(sh["train_pos"], dtype=torch.long)] = torch.arange(P, dtype=torch.int32)
-        self.halo = HaloExchange(part, g.X, P, posmap.to(self.dev), group, stage_host)
+        self.halo = HaloExchangeHip(part, g.X, P, posmap.to(self.dev), w.n, group, stage_host)
         self.labels_local = torch.from_numpy(sh["labels_local"].astype(np.int32)).to(self.dev)
 
         # parameters: identical on every rank (same seed), flat buffer as in fused.py
@@ -231,10 +289,8 @@ class DistributedPCGNN:
         cnt = self.cnt[:g.R * B]
         ops.choose_select(g, ids_local, labels if train_flag else None, self.s0_full, keys, self.thresholds, self.rho,
                           train_flag, ws, cnt, center_s0=center)
-        total = int(ws.view(0, torch.int64, g.R * B + 1)[-1].item())        # list entries in use (host sync)
-        ws.check()
-        lst = ws.view(2, torch.int32, max(total, 1))[:total]
-        self.halo.fetch_and_remap(lst)
+        total_dev = ws.view(0, torch.int64, g.R * B + 1)[-1:]               # list entries in use: stays on the device
+        self.halo.fetch_and_remap_device(ws.view(2, torch.int32, ws.list_capacity), total_dev, g)
         agg = self.agg.view(-1)[:g.R * B * self.F].view(g.R, B, self.F)
         ops.aggregate_lists(g, g.X, B, ws, cnt, agg)
         return agg, cnt

@@ -45,3 +45,19 @@ for lo, hi in ((0, 3), (3, 64), (64, 128), (128, 256), (256, 512), (512, 1024), 
     sel = (deg > lo) & (deg <= hi)
     if sel.any():
         print(f"  deg ({lo},{hi}]: {sel.sum():5d} rows  kth {kth[sel].mean():6.2f} / {kth[sel].max():6.2f} us   rounds {rounds[sel].mean():5.1f} / {rounds[sel].max():3d}   ncand {ncand[sel].mean():6.1f}")
+
+# ---- dense_step phases
+tiles = (B + 15) // 16
+dst = torch.zeros(tiles, 16, dtype=torch.int64, device="cuda")
+agg, _ = fz._enqueue_sample(ids, lab, B, True)
+for it in range(3):
+    if it == 2: lib.pcg_debug_set_dense_stamps(C.c_void_p(dst.data_ptr()))
+    fz._enqueue_dense(ids, lab, B, agg, True)
+    torch.cuda.synchronize()
+lib.pcg_debug_set_dense_stamps(None)
+d = dst.cpu().numpy().astype(np.float64) * 0.01
+names = ["stage weights+self(1)", "h_r fwd(2)", "combined(3)", "logits(4)", "loss grads(5)", "dcomb+small dW(6)", "dW_inter(7)", "per-rel bwd(8)"]
+print("dense_step per tile (us):", "start skew %.1f" % (d[:,0].max()-d[:,0].min()), " total mean %.1f max %.1f" % ((d[:,7]-d[:,0]).mean(), (d[:,7]-d[:,0]).max()))
+for i in range(1, 8):
+    dt = d[:, i] - d[:, i-1]
+    print(f"   {names[i-1]:24s} mean {dt.mean():6.2f}  max {dt.max():6.2f}")
