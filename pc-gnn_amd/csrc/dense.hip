@@ -20,7 +20,7 @@ namespace pcg {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TB = 16;          // batch rows per workgroup (one MFMA M-tile)
-constexpr int DENSE_WAVES = 4;
+constexpr int DENSE_WAVES = 8;
 
 struct DenseArgs {
     const float *X;
@@ -129,22 +129,25 @@ __device__ __forceinline__ void xent2(float a, float b, int y, float &loss, floa
 
 // WLDS: the weight matrices are staged in LDS once per workgroup (when they fit), so every MFMA operand
 // is an LDS read; otherwise the B operands stream from global memory / L2.
+// Phases (one barrier between them): stage -> h_r for all relations -> combined -> logits ->
+// loss grads -> dcomb + small dW -> {dh_r for all r, dW_inter} -> dW_r for all r.
 template <bool WLDS>
 __global__ void __launch_bounds__(DENSE_WAVES *PCG_WAVE) dense_step_kernel(const DenseArgs a) {
     extern __shared__ __align__(16) float sm[];
     const int F = a.feat_dim, E = a.emb, R = a.n_rel;
     const int K1 = 2 * F, K1p = (K1 + 3) & ~3, K2 = F + R * E, K2p = (K2 + 3) & ~3;
-    const int ld1 = K1p + 1, ld2 = K2p + 1, ldE = E + 1;
-    float *s_catr = sm;                       // [TB][ld1]  [self | agg_r] of the relation being processed
-    float *s_cat = s_catr + TB * ld1;         // [TB][ld2]  [self | h_1 .. h_R]
-    float *s_comb = s_cat + TB * ld2;         // [TB][ldE]
-    float *s_dcomb = s_comb + TB * ldE;       // [TB][ldE]
-    float *s_dh = s_dcomb + TB * ldE;         // [TB][ldE]
-    float *s_dlog = s_dh + TB * ldE;          // [TB][2] d loss / d gnn logits
-    float *s_dcl = s_dlog + TB * 2;           // [TB][2] d loss / d centre scores (already times lambda_1)
-    float *s_wc = s_dcl + TB * 2;             // [2][E] W_cls, [2][F] W_clf, [2] b_clf
-    float *s_wi = s_wc + 2 * E + 2 * F + 4;   // WLDS: [K2p][ldE] copy of W_inter
-    float *s_wr = s_wi + (WLDS ? K2p * ldE : 0);   // WLDS: [R][K1p][ldE] copies of W_intra
+    const int ld1 = K1p + 1, ld2 = K2p + 1, ldE = E + 1, ldW = E + 4;   // ldW: rows stay 16-B aligned (ds_write_b128)
+    float *s_wi = sm;                               // WLDS: [K2p][ldW] copy of W_inter   (first: 16-B aligned)
+    float *s_wr = s_wi + (WLDS ? K2p * ldW : 0);    // WLDS: [R][K1p][ldW] copies of W_intra
+    float *s_catr = s_wr + (WLDS ? R * K1p * ldW : 0);   // [R][TB][ld1]  [self | agg_r]
+    float *s_cat = s_catr + R * TB * ld1;           // [TB][ld2]  [self | h_1 .. h_R]
+    float *s_comb = s_cat + TB * ld2;               // [TB][ldE]
+    float *s_dcomb = s_comb + TB * ldE;             // [TB][ldE]
+    float *s_dh = s_dcomb + TB * ldE;               // [R][TB][ldE]
+    float *s_dlog = s_dh + R * TB * ldE;            // [TB][2] d loss / d gnn logits
+    float *s_dcl = s_dlog + TB * 2;                 // [TB][2] d loss / d centre scores (already times lambda_1)
+    float *s_wc = s_dcl + TB * 2;                   // [2][E] W_cls, [2][F] W_clf, [2] b_clf
+    float *s_tmp = s_wc + 2 * E + 2 * F + 4;        // [TB][4] logits scratch
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = blockIdx.x * TB;
@@ -152,48 +155,63 @@ __global__ void __launch_bounds__(DENSE_WAVES *PCG_WAVE) dense_step_kernel(const
     if (train && a.step_counter && blockIdx.x == 0 && tid == 0) a.step_counter[0] += 1;
     DENSE_STAMP(0);
 
+    // ---- stage: weights (16-B global loads -> 16-B LDS stores), classifier weights, zeroed tiles, self rows
+    if constexpr (WLDS) {
+        const int c4 = E >> 2;
+        for (int i = tid; i < K2 * c4; i += blockDim.x) {
+            const int rr = i / c4, cc = (i - rr * c4) * 4;
+            *reinterpret_cast<float4 *>(s_wi + rr * ldW + cc) = *reinterpret_cast<const float4 *>(a.W_inter + (size_t)rr * E + cc);
+        }
+        for (int i = tid; i < (K2p - K2) * E; i += blockDim.x) s_wi[(K2 + i / E) * ldW + i % E] = 0.f;
+        for (int r = 0; r < R; ++r) {
+            float *dst = s_wr + r * K1p * ldW;
+            const float *src = a.W_intra[r];
+            for (int i = tid; i < K1 * c4; i += blockDim.x) {
+                const int rr = i / c4, cc = (i - rr * c4) * 4;
+                *reinterpret_cast<float4 *>(dst + rr * ldW + cc) = *reinterpret_cast<const float4 *>(src + (size_t)rr * E + cc);
+            }
+            for (int i = tid; i < (K1p - K1) * E; i += blockDim.x) dst[(K1 + i / E) * ldW + i % E] = 0.f;
+        }
+    }
     for (int i = tid; i < 2 * E; i += blockDim.x) s_wc[i] = a.W_cls[i];
     for (int i = tid; i < 2 * F; i += blockDim.x) s_wc[2 * E + i] = a.W_clf[i];
     if (tid < 2) s_wc[2 * E + 2 * F + tid] = a.b_clf[tid];
-    if constexpr (WLDS) {
-        stage_weights(s_wi, ldE, a.W_inter, K2, K2p, E);
-        for (int r = 0; r < R; ++r) stage_weights(s_wr + r * K1p * ldE, ldE, a.W_intra[r], K1, K1p, E);
-    }
-    // zero the padded tiles, then load self rows into cat[:, :F]
     for (int i = tid; i < TB * ld2; i += blockDim.x) s_cat[i] = 0.f;
-    for (int i = tid; i < TB * ld1; i += blockDim.x) s_catr[i] = 0.f;
+    for (int i = tid; i < R * TB * ld1; i += blockDim.x) s_catr[i] = 0.f;
     __syncthreads();
     for (int i = tid; i < TB * F; i += blockDim.x) {
         const int t = i / F, f = i - t * F;
         const int b = row0 + t;
-        if (b < a.B) s_cat[t * ld2 + f] = a.X[(size_t)a.ids[b] * a.feat_stride + f];
+        if (b < a.B) {
+            const float v = a.X[(size_t)a.ids[b] * a.feat_stride + f];
+            s_cat[t * ld2 + f] = v;
+            for (int r = 0; r < R; ++r) s_catr[(r * TB + t) * ld1 + f] = v;
+        }
+    }
+    for (int i = tid; i < R * TB * F; i += blockDim.x) {
+        const int r = i / (TB * F), j = i - r * TB * F, t = j / F, f = j - t * F;
+        const int b = row0 + t;
+        if (b < a.B) s_catr[(r * TB + t) * ld1 + F + f] = a.agg[((size_t)r * a.B + b) * a.agg_stride + f];
     }
     __syncthreads();
-
     DENSE_STAMP(1);
-    // ---- forward: h_r = relu([self | agg_r] W_r)   (layers.py:625-629) -----------------
+
+    // ---- forward: h_r = relu([self | agg_r] W_r) for every relation   (layers.py:625-629) ---------
     const int ntile_e = E / 16;
-    for (int r = 0; r < R; ++r) {
-        for (int i = tid; i < TB * F; i += blockDim.x) {
-            const int t = i / F, f = i - t * F;
-            const int b = row0 + t;
-            s_catr[t * ld1 + f] = s_cat[t * ld2 + f];
-            s_catr[t * ld1 + F + f] = b < a.B ? a.agg[((size_t)r * a.B + b) * a.agg_stride + f] : 0.f;
-        }
-        __syncthreads();
-        for (int ct = wave; ct < ntile_e; ct += DENSE_WAVES) {
-            const f32x4 c = WLDS ? tile_lds_lds(s_catr, ld1, s_wr + r * K1p * ldE, ldE, ct * 16, K1p, lane)
-                                 : tile_lds_glob(s_catr, ld1, a.W_intra[r], E, ct * 16, K1, K1p, lane);
-            const int col = ct * 16 + (lane & 15), rq = (lane >> 4) * 4;
+    for (int tile = wave; tile < R * ntile_e; tile += DENSE_WAVES) {
+        const int r = tile / ntile_e, ct = tile - r * ntile_e;
+        const float *A = s_catr + r * TB * ld1;
+        const f32x4 c = WLDS ? tile_lds_lds(A, ld1, s_wr + r * K1p * ldW, ldW, ct * 16, K1p, lane)
+                             : tile_lds_glob(A, ld1, a.W_intra[r], E, ct * 16, K1, K1p, lane);
+        const int col = ct * 16 + (lane & 15), rq = (lane >> 4) * 4;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) s_cat[(rq + i) * ld2 + F + r * E + col] = fmaxf(c[i], 0.f);
-        }
-        __syncthreads();
+        for (int i = 0; i < 4; ++i) s_cat[(rq + i) * ld2 + F + r * E + col] = fmaxf(c[i], 0.f);
     }
+    __syncthreads();
     DENSE_STAMP(2);
     // ---- combined = relu(cat W)   (layers.py:284-289) -------------------------------------
     for (int ct = wave; ct < ntile_e; ct += DENSE_WAVES) {
-        const f32x4 c = WLDS ? tile_lds_lds(s_cat, ld2, s_wi, ldE, ct * 16, K2p, lane)
+        const f32x4 c = WLDS ? tile_lds_lds(s_cat, ld2, s_wi, ldW, ct * 16, K2p, lane)
                              : tile_lds_glob(s_cat, ld2, a.W_inter, E, ct * 16, K2, K2p, lane);
         const int col = ct * 16 + (lane & 15), rq = (lane >> 4) * 4;
 #pragma unroll
@@ -207,7 +225,7 @@ __global__ void __launch_bounds__(DENSE_WAVES *PCG_WAVE) dense_step_kernel(const
     __syncthreads();
     DENSE_STAMP(3);
     // ---- logits, centre scores, loss gradients (model.py:38, layers.py:243, model.py:54-61) ---
-    {   // 16 rows x 4 dot products, each split over 4 lanes (256 threads), combined by a 2-step butterfly
+    if (tid < TB * 16) {   // 16 rows x 4 dot products, each split over 4 lanes, combined by a 2-step butterfly
         const int part = tid & 3, which = (tid >> 2) & 3, t = tid >> 4;
         float acc = 0.f;
         if (which < 2) {
@@ -219,12 +237,12 @@ __global__ void __launch_bounds__(DENSE_WAVES *PCG_WAVE) dense_step_kernel(const
         }
         acc += __shfl_xor(acc, 1);
         acc += __shfl_xor(acc, 2);
-        if (part == 0) s_dh[t * 4 + which] = acc + (which >= 2 ? s_wc[2 * E + 2 * F + (which - 2)] : 0.f);   // scratch: [t][g0, g1, c0, c1]
+        if (part == 0) s_tmp[t * 4 + which] = acc + (which >= 2 ? s_wc[2 * E + 2 * F + (which - 2)] : 0.f);
     }
     __syncthreads();
     if (tid < TB) {
         const int t = tid, b = row0 + t;
-        const float g0 = s_dh[t * 4 + 0], g1 = s_dh[t * 4 + 1], c0 = s_dh[t * 4 + 2], c1 = s_dh[t * 4 + 3];
+        const float g0 = s_tmp[t * 4 + 0], g1 = s_tmp[t * 4 + 1], c0 = s_tmp[t * 4 + 2], c1 = s_tmp[t * 4 + 3];
         float dg0 = 0.f, dg1 = 0.f, dc0 = 0.f, dc1 = 0.f;
         if (b < a.B) {
             a.logits[2 * b] = g0;
@@ -250,78 +268,74 @@ __global__ void __launch_bounds__(DENSE_WAVES *PCG_WAVE) dense_step_kernel(const
 
     float *slab = a.slabs + (size_t)blockIdx.x * a.n_params;
     // ---- backward ----------------------------------------------------------------------------
-    // dcomb = (dlogits W_cls) * relu'(combined)
+    // dcomb = (dlogits W_cls) * relu'(combined);  dW_cls, dW_clf, db_clf
     for (int i = tid; i < TB * E; i += blockDim.x) {
         const int t = i / E, e = i - t * E;
         const float g = s_dlog[2 * t] * s_wc[e] + s_dlog[2 * t + 1] * s_wc[E + e];
         s_dcomb[t * ldE + e] = s_comb[t * ldE + e] > 0.f ? g : 0.f;
     }
-    // dW_cls[c][e] = sum_t dlogits[t][c] comb[t][e];  dW_clf[c][f] = sum_t dcl[t][c] self[t][f];  db_clf
     for (int i = tid; i < 2 * E; i += blockDim.x) {
         const int cidx = i / E, e = i - cidx * E;
-        float s = 0.f;
-        for (int t = 0; t < TB; ++t) s = fmaf(s_dlog[2 * t + cidx], s_comb[t * ldE + e], s);
-        slab[off_cls(F, E, R) + i] = s;
+        float sacc = 0.f;
+        for (int t = 0; t < TB; ++t) sacc = fmaf(s_dlog[2 * t + cidx], s_comb[t * ldE + e], sacc);
+        slab[off_cls(F, E, R) + i] = sacc;
     }
     for (int i = tid; i < 2 * F; i += blockDim.x) {
         const int cidx = i / F, f = i - cidx * F;
-        float s = 0.f;
-        for (int t = 0; t < TB; ++t) s = fmaf(s_dcl[2 * t + cidx], s_cat[t * ld2 + f], s);
-        slab[off_clf(F, E, R) + i] = s;
+        float sacc = 0.f;
+        for (int t = 0; t < TB; ++t) sacc = fmaf(s_dcl[2 * t + cidx], s_cat[t * ld2 + f], sacc);
+        slab[off_clf(F, E, R) + i] = sacc;
     }
     if (tid < 2) {
-        float s = 0.f;
-        for (int t = 0; t < TB; ++t) s += s_dcl[2 * t + tid];
-        slab[off_bias(F, E, R) + tid] = s;
+        float sacc = 0.f;
+        for (int t = 0; t < TB; ++t) sacc += s_dcl[2 * t + tid];
+        slab[off_bias(F, E, R) + tid] = sacc;
     }
     __syncthreads();
     DENSE_STAMP(5);
-    // dW_inter[m][n] = sum_t cat[t][m] dcomb[t][n]
+    // one phase: dh_r = (dcomb W[F+rE.., :]^T) * relu'(h_r) for every r   and   dW_inter = cat^T dcomb
     {
-        const int mt = (K2 + 15) / 16;
+        const int mt2 = (K2 + 15) / 16;
+        const int n_dh = R * ntile_e, n_all = n_dh + mt2 * ntile_e;
         float *dst = slab + off_inter(F, E, R);
-        for (int tile = wave; tile < mt * ntile_e; tile += DENSE_WAVES) {
-            const int m0 = (tile / ntile_e) * 16, n0 = (tile % ntile_e) * 16;
-            const f32x4 c = tile_ldsT_lds(s_cat, ld2, m0, K2, s_dcomb, ldE, n0, lane);
-            const int col = n0 + (lane & 15), rq = (lane >> 4) * 4;
+        for (int tile = wave; tile < n_all; tile += DENSE_WAVES) {
+            if (tile < n_dh) {
+                const int r = tile / ntile_e, ct = tile - r * ntile_e;
+                const float *Wr = a.W_inter + (size_t)(F + r * E) * E;   // rows of W_inter that multiply h_r
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                const int rr = lane & 15, kq = lane >> 4;
+#pragma unroll 4
+                for (int e0 = 0; e0 < E; e0 += 4) {                       // out[t][j] = sum_e dcomb[t][e] * Wr[j][e]
+                    const float av = s_dcomb[rr * ldE + e0 + kq];
+                    const float bv = WLDS ? s_wi[(F + r * E + ct * 16 + rr) * ldW + e0 + kq]
+                                          : Wr[(size_t)(ct * 16 + rr) * E + e0 + kq];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+                }
+                const int col = ct * 16 + rr, rq = kq * 4;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (m0 + rq + i < K2) dst[(size_t)(m0 + rq + i) * E + col] = c[i];
+                for (int i = 0; i < 4; ++i)
+                    s_dh[(r * TB + rq + i) * ldE + col] = s_cat[(rq + i) * ld2 + F + r * E + col] > 0.f ? acc[i] : 0.f;
+            } else {
+                const int tl = tile - n_dh;
+                const int m0 = (tl / ntile_e) * 16, n0 = (tl % ntile_e) * 16;
+                const f32x4 c = tile_ldsT_lds(s_cat, ld2, m0, K2, s_dcomb, ldE, n0, lane);
+                const int col = n0 + (lane & 15), rq = (lane >> 4) * 4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (m0 + rq + i < K2) dst[(size_t)(m0 + rq + i) * E + col] = c[i];
+            }
         }
     }
+    __syncthreads();
     DENSE_STAMP(6);
-    // per relation: dh_r = (dcomb W[F+rE.., :]^T) * relu'(h_r);  dW_r = [self|agg_r]^T dh_r
-    for (int r = 0; r < R; ++r) {
-        __syncthreads();
-        for (int i = tid; i < TB * F; i += blockDim.x) {     // reload [self | agg_r]
-            const int t = i / F, f = i - t * F;
-            const int b = row0 + t;
-            s_catr[t * ld1 + f] = s_cat[t * ld2 + f];
-            s_catr[t * ld1 + F + f] = b < a.B ? a.agg[((size_t)r * a.B + b) * a.agg_stride + f] : 0.f;
-        }
-        const float *Wr = a.W_inter + (size_t)(F + r * E) * E;   // rows of W_inter that multiply h_r
-        for (int ct = wave; ct < ntile_e; ct += DENSE_WAVES) {
-            // out[t][j] = sum_e dcomb[t][e] * Wr[j][e]
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            const int rr = lane & 15, kq = lane >> 4;
-#pragma unroll 4
-            for (int e0 = 0; e0 < E; e0 += 4) {
-                const float av = s_dcomb[rr * ldE + e0 + kq];
-                const float bv = WLDS ? s_wi[(F + r * E + ct * 16 + rr) * ldE + e0 + kq]
-                                      : Wr[(size_t)(ct * 16 + rr) * E + e0 + kq];
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
-            }
-            const int col = ct * 16 + rr, rq = kq * 4;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                s_dh[(rq + i) * ldE + col] = s_cat[(rq + i) * ld2 + F + r * E + col] > 0.f ? acc[i] : 0.f;
-        }
-        __syncthreads();
-        const int mt = (K1 + 15) / 16;
-        float *dst = slab + off_intra(F, E, R, r);
-        for (int tile = wave; tile < mt * ntile_e; tile += DENSE_WAVES) {
-            const int m0 = (tile / ntile_e) * 16, n0 = (tile % ntile_e) * 16;
-            const f32x4 c = tile_ldsT_lds(s_catr, ld1, m0, K1, s_dh, ldE, n0, lane);
+    // dW_r = [self|agg_r]^T dh_r for every r
+    {
+        const int mt1 = (K1 + 15) / 16, per_r = mt1 * ntile_e;
+        for (int tile = wave; tile < R * per_r; tile += DENSE_WAVES) {
+            const int r = tile / per_r, tl = tile - r * per_r;
+            const int m0 = (tl / ntile_e) * 16, n0 = (tl % ntile_e) * 16;
+            const f32x4 c = tile_ldsT_lds(s_catr + r * TB * ld1, ld1, m0, K1, s_dh + r * TB * ldE, ldE, n0, lane);
+            float *dst = slab + off_intra(F, E, R, r);
             const int col = n0 + (lane & 15), rq = (lane >> 4) * 4;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -369,8 +383,8 @@ __global__ void __launch_bounds__(256) adam_reduce_kernel(float *__restrict__ th
 
 static size_t dense_smem_bytes(int F, int E, int R, bool wlds) {
     const int K1p = (2 * F + 3) & ~3, K2p = (F + R * E + 3) & ~3;
-    size_t fl = (size_t)(TB * (K1p + 1) + TB * (K2p + 1) + 3 * TB * (E + 1) + 4 * TB + 2 * E + 2 * F + 4);
-    if (wlds) fl += (size_t)(K2p + R * K1p) * (E + 1);
+    size_t fl = (size_t)(R * TB * (K1p + 1) + TB * (K2p + 1) + (2 + R) * TB * (E + 1) + 4 * TB + 2 * E + 2 * F + 4 + 4 * TB);
+    if (wlds) fl += (size_t)(K2p + R * K1p) * (E + 4);
     return sizeof(float) * fl;
 }
 
