@@ -37,6 +37,7 @@ constexpr int CHUNK = 256;       // list entries per gather work item
 constexpr int UNROLL = 8;        // row-gather instructions in flight per wave
 constexpr int KEY_UNROLL = 4;    // neighbour-score gathers in flight per lane
 constexpr int PLAN_THREADS = 1024;
+constexpr int PLAN_PER = 4;      // rows per plan thread per tile
 constexpr int GATHER_BLOCKS = 2048;
 
 // counters (uint32) at the head of the workspace
@@ -56,6 +57,7 @@ struct Workspace {
     int32_t *len;          // [rows]     entries (holes included) actually written
     int32_t *q1, *q4, *q16;  // [rows] each
     struct RowRec *recs;   // [rows] what plan worked out per row
+    unsigned char *plan_totals;   // [blocks of the two-pass plan] PlanTotals
     int32_t *chunk_row;    // [chunk_cap]
     float *partial;        // [chunk_cap, feat_stride]
     int32_t *list;         // [list_capacity]  chosen ids; -1 = hole
@@ -83,6 +85,7 @@ static int64_t carve(const pcg_graph_desc *g, int32_t B, int64_t list_capacity, 
     p = take(4 * rows);                            if (w) w->q4 = reinterpret_cast<int32_t *>(p);
     p = take(4 * rows);                            if (w) w->q16 = reinterpret_cast<int32_t *>(p);
     p = take(32 * rows);                           if (w) w->recs = reinterpret_cast<RowRec *>(p);
+    p = take(32 * (rows / (PLAN_THREADS * PLAN_PER) + 1));   if (w) w->plan_totals = p;
     p = take(4 * chunk_cap);                       if (w) w->chunk_row = reinterpret_cast<int32_t *>(p);
     p = take(4 * chunk_cap * g->feat_stride);      if (w) w->partial = reinterpret_cast<float *>(p);
     p = take(4 * list_capacity);                   if (w) w->list = reinterpret_cast<int32_t *>(p);
@@ -160,7 +163,6 @@ __device__ __forceinline__ T block_excl_scan(T v, T *lds /* >= waves */, T &tota
     return pre + inc - v;
 }
 
-constexpr int PLAN_PER = 4;     // rows per thread per tile
 
 __global__ void __launch_bounds__(PLAN_THREADS) plan_kernel(const ChooseArgs a) {
     __shared__ int lds[PLAN_THREADS / PCG_WAVE];
@@ -279,6 +281,125 @@ __global__ void __launch_bounds__(PLAN_THREADS) plan_kernel(const ChooseArgs a) 
         a.w.counters[C_HEAD4] = 0;
         a.w.counters[C_HEAD16] = 0;
         a.w.counters[C_NCHUNK] = overflow ? 0 : run_chunk;
+        if (overflow && a.status) atomicOr(a.status, (uint32_t)PCG_ST_SEL_OVERFLOW);
+    }
+}
+
+// Large batches (rows > PLAN_THREADS * PLAN_PER): the same plan in two launches of many workgroups.
+//   plan_count : every block works out the records of its PLAN_THREADS * PLAN_PER rows and their totals
+//   plan_write : every block adds up the totals of the blocks before it (a few dozen values), then scans its
+//                own rows and writes offsets / queues / chunk table exactly as the single-block kernel does
+struct PlanTotals {
+    long long cap;
+    int chunk, n1, n4, n16;
+    int pad[3];
+};
+
+__device__ __forceinline__ int row_cap(const RowRec &p, int add_self) {
+    return (p.keep_all ? p.d : p.k) + p.m + (add_self ? 1 : 0);
+}
+
+__global__ void __launch_bounds__(PLAN_THREADS) plan_count(const ChooseArgs a, PlanTotals *totals) {
+    __shared__ int lds[PLAN_THREADS / PCG_WAVE];
+    __shared__ long long lds64[PLAN_THREADS / PCG_WAVE];
+    const int rows = a.g.n_rel * a.B;
+    const int r0 = (blockIdx.x * PLAN_THREADS + threadIdx.x) * PLAN_PER;
+    long long cap_sum = 0;
+    int chunk_sum = 0, n1 = 0, n4 = 0, n16 = 0;
+#pragma unroll
+    for (int i = 0; i < PLAN_PER; ++i) {
+        const int row = r0 + i;
+        if (row < rows) {
+            const RowRec p = row_plan(a, row);
+            a.w.recs[row] = p;
+            const int cap = row_cap(p, a.add_self);
+            cap_sum += cap;
+            chunk_sum += (cap + CHUNK - 1) / CHUNK;
+            n1 += p.d <= T1_CAP;
+            n4 += p.d > T1_CAP && p.d <= T4_CAP;
+            n16 += p.d > T4_CAP;
+        }
+    }
+    long long t_cap, t_tiers;
+    int t_chunk;
+    block_excl_scan<long long>(cap_sum, lds64, t_cap);
+    block_excl_scan(chunk_sum, lds, t_chunk);
+    block_excl_scan<long long>((long long)n1 | ((long long)n4 << 20) | ((long long)n16 << 40), lds64, t_tiers);
+    if (threadIdx.x == 0) {
+        PlanTotals t;
+        t.cap = t_cap;
+        t.chunk = t_chunk;
+        t.n1 = (int)(t_tiers & 0xFFFFF);
+        t.n4 = (int)((t_tiers >> 20) & 0xFFFFF);
+        t.n16 = (int)(t_tiers >> 40);
+        totals[blockIdx.x] = t;
+    }
+}
+
+__global__ void __launch_bounds__(PLAN_THREADS) plan_write(const ChooseArgs a, const PlanTotals *totals) {
+    __shared__ int lds[PLAN_THREADS / PCG_WAVE];
+    __shared__ long long lds64[PLAN_THREADS / PCG_WAVE];
+    const int rows = a.g.n_rel * a.B;
+    long long run_cap = 0, all_cap = 0;
+    int run_chunk = 0, run1 = 0, run4 = 0, run16 = 0, all_chunk = 0, all1 = 0, all4 = 0, all16 = 0;
+    for (int bk = 0; bk < (int)gridDim.x; ++bk) {       // gridDim.x is small (rows / 4096)
+        const PlanTotals t = totals[bk];
+        if (bk < (int)blockIdx.x) {
+            run_cap += t.cap; run_chunk += t.chunk; run1 += t.n1; run4 += t.n4; run16 += t.n16;
+        }
+        all_cap += t.cap; all_chunk += t.chunk; all1 += t.n1; all4 += t.n4; all16 += t.n16;
+    }
+    const bool overflow = all_cap > a.w.list_capacity || (long long)all_chunk > a.w.chunk_cap;
+    const int r0 = (blockIdx.x * PLAN_THREADS + threadIdx.x) * PLAN_PER;
+    RowRec rec[PLAN_PER];
+    int cap[PLAN_PER];
+    long long cap_sum = 0;
+    int chunk_sum = 0, n1 = 0, n4 = 0, n16 = 0;
+#pragma unroll
+    for (int i = 0; i < PLAN_PER; ++i) {
+        const int row = r0 + i;
+        cap[i] = 0;
+        if (row < rows) {
+            rec[i] = a.w.recs[row];
+            cap[i] = row_cap(rec[i], a.add_self);
+            cap_sum += cap[i];
+            chunk_sum += (cap[i] + CHUNK - 1) / CHUNK;
+            n1 += rec[i].d <= T1_CAP;
+            n4 += rec[i].d > T1_CAP && rec[i].d <= T4_CAP;
+            n16 += rec[i].d > T4_CAP;
+        }
+    }
+    long long t_cap, t_tiers;
+    int t_chunk;
+    long long o_cap = run_cap + block_excl_scan<long long>(cap_sum, lds64, t_cap);
+    int o_chunk = run_chunk + block_excl_scan(chunk_sum, lds, t_chunk);
+    const long long o_t = block_excl_scan<long long>((long long)n1 | ((long long)n4 << 20) | ((long long)n16 << 40), lds64, t_tiers);
+    int o1 = run1 + (int)(o_t & 0xFFFFF), o4 = run4 + (int)((o_t >> 20) & 0xFFFFF), o16 = run16 + (int)(o_t >> 40);
+#pragma unroll
+    for (int i = 0; i < PLAN_PER; ++i) {
+        const int row = r0 + i;
+        if (row >= rows) continue;
+        const int nch = (cap[i] + CHUNK - 1) / CHUNK;
+        a.w.row_begin[row] = o_cap;
+        a.w.chunk_begin[row] = o_chunk;
+        if (!overflow) {
+            for (int j = 0; j < nch; ++j) a.w.chunk_row[o_chunk + j] = row;
+            if (rec[i].d <= T1_CAP) a.w.q1[o1++] = row;
+            else if (rec[i].d <= T4_CAP) a.w.q4[o4++] = row;
+            else a.w.q16[o16++] = row;
+        }
+        o_cap += cap[i];
+        o_chunk += nch;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        a.w.row_begin[rows] = all_cap;
+        a.w.chunk_begin[rows] = all_chunk;
+        a.w.counters[C_N1] = overflow ? 0 : all1;
+        a.w.counters[C_N4] = overflow ? 0 : all4;
+        a.w.counters[C_N16] = overflow ? 0 : all16;
+        a.w.counters[C_HEAD4] = 0;
+        a.w.counters[C_HEAD16] = 0;
+        a.w.counters[C_NCHUNK] = overflow ? 0 : all_chunk;
         if (overflow && a.status) atomicOr(a.status, (uint32_t)PCG_ST_SEL_OVERFLOW);
     }
 }
@@ -1022,8 +1143,17 @@ static Fork &fork_state() {
 static int launch_select(const ChooseArgs &a, hipStream_t st) {
     const pcg_graph_desc &g = a.g;
     const int rows = g.n_rel * a.B;
-    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(PLAN_THREADS), 0, st, a);
-    PCG_LAUNCH_CHECK();
+    if (rows <= PLAN_THREADS * PLAN_PER) {
+        hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(PLAN_THREADS), 0, st, a);
+        PCG_LAUNCH_CHECK();
+    } else {
+        const int nb = (rows + PLAN_THREADS * PLAN_PER - 1) / (PLAN_THREADS * PLAN_PER);
+        PlanTotals *tot = reinterpret_cast<PlanTotals *>(a.w.plan_totals);
+        hipLaunchKernelGGL(plan_count, dim3(nb), dim3(PLAN_THREADS), 0, st, a, tot);
+        PCG_LAUNCH_CHECK();
+        hipLaunchKernelGGL(plan_write, dim3(nb), dim3(PLAN_THREADS), 0, st, a, tot);
+        PCG_LAUNCH_CHECK();
+    }
     const bool wide16 = g.max_degree > T4_CAP, wide4 = g.max_degree > T1_CAP;
     Fork &f = fork_state();
     if (!f.ok) return PCG_E_LAUNCH;

@@ -157,21 +157,24 @@ __global__ void __launch_bounds__(DENSE_WAVES *PCG_WAVE) dense_step_kernel(const
 
     // ---- stage: weights (16-B global loads -> 16-B LDS stores), classifier weights, zeroed tiles, self rows
     if constexpr (WLDS) {
+        // thread -> (row, 16-B column chunk) fixed once: no per-element division, 4 rows in flight
         const int c4 = E >> 2;
-        for (int i = tid; i < K2 * c4; i += blockDim.x) {
-            const int rr = i / c4, cc = (i - rr * c4) * 4;
-            *reinterpret_cast<float4 *>(s_wi + rr * ldW + cc) = *reinterpret_cast<const float4 *>(a.W_inter + (size_t)rr * E + cc);
-        }
-        for (int i = tid; i < (K2p - K2) * E; i += blockDim.x) s_wi[(K2 + i / E) * ldW + i % E] = 0.f;
-        for (int r = 0; r < R; ++r) {
-            float *dst = s_wr + r * K1p * ldW;
-            const float *src = a.W_intra[r];
-            for (int i = tid; i < K1 * c4; i += blockDim.x) {
-                const int rr = i / c4, cc = (i - rr * c4) * 4;
-                *reinterpret_cast<float4 *>(dst + rr * ldW + cc) = *reinterpret_cast<const float4 *>(src + (size_t)rr * E + cc);
+        const int cc = (tid % c4) * 4, r0 = tid / c4, rstep = blockDim.x / c4;   // blockDim.x % c4 == 0 (host-checked)
+        auto stage = [&](float *dst, const float *__restrict__ src, int rows, int rows_pad) {
+            int rr = r0;
+            for (; rr + 3 * rstep < rows; rr += 4 * rstep) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4 *>(src + (size_t)(rr + u * rstep) * E + cc);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) *reinterpret_cast<float4 *>(dst + (rr + u * rstep) * ldW + cc) = v[u];
             }
-            for (int i = tid; i < (K1p - K1) * E; i += blockDim.x) dst[(K1 + i / E) * ldW + i % E] = 0.f;
-        }
+            for (; rr < rows; rr += rstep)
+                *reinterpret_cast<float4 *>(dst + rr * ldW + cc) = *reinterpret_cast<const float4 *>(src + (size_t)rr * E + cc);
+            for (int i = tid; i < (rows_pad - rows) * E; i += blockDim.x) dst[(rows + i / E) * ldW + i % E] = 0.f;
+        };
+        stage(s_wi, a.W_inter, K2, K2p);
+        for (int r = 0; r < R; ++r) stage(s_wr + r * K1p * ldW, a.W_intra[r], K1, K1p);
     }
     for (int i = tid; i < 2 * E; i += blockDim.x) s_wc[i] = a.W_cls[i];
     for (int i = tid; i < 2 * F; i += blockDim.x) s_wc[2 * E + i] = a.W_clf[i];
@@ -423,7 +426,7 @@ int pcg_dense_step(const pcg_graph_desc *g, const float *theta, int32_t emb, con
     if (emb < 16 || emb % 16 != 0 || g->n_rel < 1 || g->n_rel > PCG_MAX_REL) return PCG_E_UNSUPPORTED;
     if (slabs && !labels) return PCG_E_ARG;
     const int F = g->feat_dim, E = emb, R = g->n_rel;
-    const bool wlds = pcg::dense_smem_bytes(F, E, R, true) <= 160 * 1024;
+    const bool wlds = pcg::dense_smem_bytes(F, E, R, true) <= 160 * 1024 && (pcg::DENSE_WAVES * PCG_WAVE) % (E / 4) == 0;
     const size_t smem = pcg::dense_smem_bytes(F, E, R, wlds);
     if (smem > 160 * 1024) return PCG_E_UNSUPPORTED;
     pcg::DenseArgs a;

@@ -69,32 +69,37 @@ __global__ void __launch_bounds__(SORT_THREADS) bitonic_local_merge(uint64_t *__
 }
 
 // ---- rank sort: one launch, no step barriers (n_pos <= RANK_MAX) -------------------
-// Keys are unique, so rank(i) = #{j : key_j < key_i} is a permutation.  Every block
-// stages all keys in LDS, owns 64 of them (one per lane) and splits the j-range over
-// its 16 waves; LDS reads are wave-wide broadcasts.
-constexpr int RANK_MAX = 16384;
+// Keys are unique, so rank(i) = #{j : key_j < key_i} is a permutation.  Every block owns 64 keys
+// (one per lane), walks all keys in LDS tiles of RANK_TILE and splits each tile's j-range over its
+// 16 waves; LDS reads are wave-wide broadcasts.  O(P^2) compares, but embarrassingly parallel: it
+// beats the many-launch bitonic network up to a few 10^4 keys.
+constexpr int RANK_MAX = 65536;
+constexpr int RANK_TILE = 8192;
 constexpr int RANK_WAVES = 16;
 
 __global__ void __launch_bounds__(RANK_WAVES *PCG_WAVE) pos_rank_sort(const float *__restrict__ s0,
                                                                       const int32_t *__restrict__ train_pos,
                                                                       int n_pos, int cap, uint64_t *__restrict__ keys) {
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    uint64_t *sh = reinterpret_cast<uint64_t *>(smem_raw);
-    int *part = reinterpret_cast<int *>(sh + n_pos);          // [RANK_WAVES][64]
-    for (int t = threadIdx.x; t < n_pos; t += blockDim.x) sh[t] = make_pos_key(s0, train_pos, t, n_pos);
-    __syncthreads();
+    __shared__ uint64_t sh[RANK_TILE];
+    __shared__ int part[RANK_WAVES * PCG_WAVE];
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int i = blockIdx.x * PCG_WAVE + lane;
-    const uint64_t mine = i < n_pos ? sh[i] : ~0ull;
-    const int chunk = (n_pos + RANK_WAVES - 1) / RANK_WAVES;
-    const int j0 = wave * chunk, j1 = (j0 + chunk < n_pos) ? j0 + chunk : n_pos;
+    const uint64_t mine = make_pos_key(s0, train_pos, i, n_pos);          // ~0 when i >= n_pos
     int c = 0;
-    int j = j0;
-    for (; j + 4 <= j1; j += 4) {
-        const uint64_t a0 = sh[j], a1 = sh[j + 1], a2 = sh[j + 2], a3 = sh[j + 3];
-        c += (a0 < mine) + (a1 < mine) + (a2 < mine) + (a3 < mine);
+    for (int t0 = 0; t0 < n_pos; t0 += RANK_TILE) {
+        const int nt = (n_pos - t0 < RANK_TILE) ? n_pos - t0 : RANK_TILE;
+        __syncthreads();
+        for (int t = threadIdx.x; t < nt; t += blockDim.x) sh[t] = make_pos_key(s0, train_pos, t0 + t, n_pos);
+        __syncthreads();
+        const int chunk = (nt + RANK_WAVES - 1) / RANK_WAVES;
+        const int j0 = wave * chunk, j1 = (j0 + chunk < nt) ? j0 + chunk : nt;
+        int j = j0;
+        for (; j + 4 <= j1; j += 4) {
+            const uint64_t a0 = sh[j], a1 = sh[j + 1], a2 = sh[j + 2], a3 = sh[j + 3];
+            c += (a0 < mine) + (a1 < mine) + (a2 < mine) + (a3 < mine);
+        }
+        for (; j < j1; ++j) c += sh[j] < mine;
     }
-    for (; j < j1; ++j) c += sh[j] < mine;
     part[wave * PCG_WAVE + lane] = c;
     __syncthreads();
     if (wave == 0 && i < n_pos) {
@@ -125,16 +130,8 @@ int pcg_pos_sort(const pcg_graph_desc *g, const float *s0, uint64_t *keys, void 
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t cap = pcg::sort_capacity(g->n_pos);
     if (g->n_pos <= pcg::RANK_MAX) {
-        const size_t smem = sizeof(uint64_t) * g->n_pos + sizeof(int) * pcg::RANK_WAVES * PCG_WAVE;
-        static bool attr = false;
-        if (!attr) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(pcg::pos_rank_sort),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-                return PCG_E_LAUNCH;
-            attr = true;
-        }
         hipLaunchKernelGGL(pcg::pos_rank_sort, dim3((g->n_pos + PCG_WAVE - 1) / PCG_WAVE),
-                           dim3(pcg::RANK_WAVES * PCG_WAVE), smem, st, s0, g->train_pos, g->n_pos, (int)cap, keys);
+                           dim3(pcg::RANK_WAVES * PCG_WAVE), 0, st, s0, g->train_pos, g->n_pos, (int)cap, keys);
         PCG_LAUNCH_CHECK();
         return PCG_OK;
     }

@@ -9,6 +9,7 @@ symmetrised, de-duplicated, one self-loop per node.
     amazon_like  N=11,944 F=25  edges 175,608 / 3,566,479 / 1,036,737 pos 6.87 %, 3,305 unlabeled
     power_law    N, E free (BASELINE config 4: 10 M nodes / 200 M edges / 3 relations, pos 1 %)
 """
+import sys
 from dataclasses import dataclass, field
 from typing import List, Tuple
 
@@ -55,6 +56,12 @@ def _endpoints(rs, n, m, skew, max_share=None):
 
 
 def _homo_degree(n, csr):
+    """degree in the union graph.  Exact (set union) for graphs of dataset size; for very large synthetic
+    graphs the per-relation degrees are summed minus the shared self-loops (duplicate edges across relations
+    are negligible there and the pick weights only need the degree profile)."""
+    if sum(idx.shape[0] for _, idx in csr) > 100_000_000:
+        deg = sum(np.diff(ip) for ip, _ in csr) - (len(csr) - 1)
+        return deg.astype(np.int64)
     keys = []
     for indptr, idx in csr:
         rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(indptr))
@@ -83,10 +90,13 @@ def make_workload(name, n, feat, rel_edges, pos_rate, seed=0, skew=2.0, first_la
         X = (X / (X.sum(1, keepdims=True) + 0.01)).astype(np.float32)
     labels = (rs.rand(n) < pos_rate).astype(np.int64)
     csr = []
+    big = sum(rel_edges) >= 20_000_000
     for m in rel_edges:
         src = _endpoints(rs, n, m, skew, max_share)
         dst = rs.randint(0, n, size=m).astype(np.int64)
         csr.append(_csr_from_pairs(n, src, dst))
+        if big:     # long silent phases look like a hang to a watchdog: say what is going on
+            print(f"[synth] relation with {m} edges built ({csr[-1][1].shape[0]} CSR entries)", file=sys.stderr, flush=True)
     idx_train, train_pos = _split(rs, labels, first_labeled, train_ratio)
     return Workload(name, X, labels, csr, _homo_degree(n, csr), idx_train, train_pos,
                     {"n": n, "feat": feat, "rel_edges": list(rel_edges), "pos_rate": pos_rate, "seed": seed,
