@@ -37,8 +37,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s me
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=24)
     ap.add_argument("--workload", default="yelp", choices=["yelp", "amazon", "powerlaw"])
     ap.add_argument("--batch-size", type=int, default=None)
     ap.add_argument("--emb", type=int, default=64)
@@ -51,7 +51,7 @@ def parse():
                     "instead of staging the whole epoch (A/B switch)")
     ap.add_argument("--force-partitioned", action="store_true",
                     help="run the node-partitioned RCCL path even at world size 1 (rehearsal of the N>1 code)")
-    ap.add_argument("--event-every", type=int, default=4,
+    ap.add_argument("--event-every", type=int, default=10,
                     help="graph engine: bracket the choose+aggregate launch with HIP events on every Nth timed step")
     ap.add_argument("--engine", default=None, choices=["graph", "fused", "torch", "dp"],
                     help="graph: fused HIP step replayed from a hipGraph (default at 1 GPU); fused: same kernels "
@@ -290,7 +290,7 @@ def main():
                        "global_batch": B * world, "parallelism": "single" if world == 1 else f"dp{world}-replicated-graph",
                        "engine": engine,
                        "nodes_processed": int(nodes_total)},
-            "roofline": {"bound": "hbm", "kernel": "pcg_choose_aggregate (choose_agg_t1 + choose_agg_wide<4|16>)", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "pcg_choose_aggregate (plan + select_t1|wide<4>|wide<16> + gather_chunks + combine_rows)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": float(np.mean(abytes)),
                          "launches_timed": len(kern_ms)},

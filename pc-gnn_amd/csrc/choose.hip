@@ -784,8 +784,9 @@ __device__ __forceinline__ void select_row(const ChooseArgs &a, int row, uint32_
     }
     grp_sync<NW>();
     const uint32_t *sel = keys;
-    for (int i = tid; i < ns; i += NT) out[i] = (int32_t)sel[i];
     PCG_STAMP(3);
+    // (the kept ids are written to the list at the very end: vmcnt orders loads behind older stores, and the
+    //  minority search below is a chain of dependent loads that must not queue behind ~ns stores to fresh lines)
 
     // ---- 4. minority over-sampling (layers.py:675-691): slots out[ns .. ns + mt) -----------
     int mt = 0;        // slots used
@@ -829,7 +830,11 @@ __device__ __forceinline__ void select_row(const ChooseArgs &a, int row, uint32_
             // ties are [L2, L) and [R, R2); strictly nearer ones are [L, R)
             need_t = m - (R - L);
             const int T = (L - L2) + (R2 - R);
-            if (T > need_t) {  // take the need_t ties with the smallest train_pos position
+            if (T == need_t) {               // every tie is taken (the usual case): one contiguous, fully parallel range
+                L = L2;
+                R = R2;
+                need_t = 0;
+            } else if (T > PCG_WAVE) {       // many ties: threshold on the train_pos position by bisection
                 int plo = 0, phi = P - 1;
                 while (plo < phi) {
                     const int mid = (plo + phi) >> 1;
@@ -846,6 +851,17 @@ __device__ __forceinline__ void select_row(const ChooseArgs &a, int row, uint32_
                     else plo = mid + 1;
                 }
                 tau = plo;
+            } else {                          // a few ties: one per lane, the need_t smallest positions by in-register ranking
+                const int nl = L - L2;
+                const int ti = lane < nl ? L2 + lane : R + (lane - nl);
+                const bool tv = lane < T;
+                const int tp = tv ? (int)(uint32_t)pk[ti] : INT_MAX;
+                int rank = 0;
+                for (int j = 0; j < T; ++j) rank += __builtin_amdgcn_readlane(tp, j) < tp;
+                // tau = the need_t-th smallest position among the ties (positions are distinct)
+                const uint64_t hit = __ballot(tv && rank == need_t - 1);
+                const int src = __ffsll((unsigned long long)hit) - 1;
+                tau = __builtin_amdgcn_readlane(tp, src < 0 ? 0 : src);
             }
         }
         PCG_STAMP(4);
@@ -909,6 +925,7 @@ __device__ __forceinline__ void select_row(const ChooseArgs &a, int row, uint32_
     for (int o = 1; o < PCG_WAVE; o <<= 1) vsum += __shfl_xor(vsum, o);
     int vpre, vtot;
     grp_scan<NW>(vsum, wave, lane, red, vpre, vtot);
+    for (int i = tid; i < ns; i += NT) out[i] = (int32_t)sel[i];
     const int used = ns + mt + n_self;
     const int cap = (int)(a.w.row_begin[row + 1] - a.w.row_begin[row]);
     for (int i = used + tid; i < cap; i += NT) out[i] = -1;   // unused tail of the region: the whole list prefix stays clean

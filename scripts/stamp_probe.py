@@ -61,3 +61,15 @@ print("dense_step per tile (us):", "start skew %.1f" % (d[:,0].max()-d[:,0].min(
 for i in range(1, 8):
     dt = d[:, i] - d[:, i-1]
     print(f"   {names[i-1]:24s} mean {dt.mean():6.2f}  max {dt.max():6.2f}")
+
+# ---- the slowest T1 rows
+tot = st[:, 6] - st[:, 0]
+t1 = np.flatnonzero(deg <= 512)
+order = t1[np.argsort(-tot[t1])][:14]
+lab_h = lab.cpu().numpy()
+print("slowest T1 rows: row rel b deg label | start(us) keys kth compact search resolve tail | total")
+for rr in order:
+    r_, b_ = rr // B, rr % B
+    ph = [st[rr, i] - st[rr, i - 1] if st[rr, i] > 0 else 0.0 for i in range(1, 7)]
+    print(f"  {rr:5d} {r_} {b_:4d} {deg[rr]:4d} {lab_h[b_]} | {st[rr,0]-t0:6.1f} " + " ".join(f"{x:6.2f}" for x in ph) + f" | {tot[rr]:6.2f}")
+
