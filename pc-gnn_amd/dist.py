@@ -258,6 +258,10 @@ class DistributedPCGNN:
         self.sampler.cum_host = np.cumsum(sh["homo_deg_train"] / lf)
         self.sampler.cum = torch.from_numpy(self.sampler.cum_host).to(self.dev)
         self.B = B
+        self.ids_buf = torch.zeros(B, dtype=torch.int32, device=self.dev)
+        self.lab_buf = torch.zeros(B, dtype=torch.int32, device=self.dev)
+        self.center_buf = torch.zeros(B, dtype=torch.float32, device=self.dev)
+        self._graphs, self._ws_extra = {}, {}
 
     # -- collectives ----------------------------------------------------------------------------
     def _all_gather(self, out, inp):
@@ -277,41 +281,103 @@ class DistributedPCGNN:
             dist.all_reduce(t, group=self.group)
 
     # -- one step ---------------------------------------------------------------------------------
+    def _seg_select(self, ids_local, labels, B, train_flag):
+        """collective-free segment 1: train-pos sort, centre scores, plan + select (lists of global ids)."""
+        ops, g, part = self.ops, self.g, self.part
+        keys = ops.pos_sort(g, self.s0_full, self.keys) if (train_flag and g.n_pos) else None
+        self.center_buf[:B].copy_(self.s0_full[(ids_local.long() + part.lo)])
+        ops.choose_select(g, ids_local, labels if train_flag else None, self.s0_full, keys, self.thresholds, self.rho,
+                          train_flag, self._ws_of(B), self.cnt[:g.R * B], center_s0=self.center_buf[:B])
+
+    def _seg_dense(self, ids_local, labels, B):
+        """collective-free segment 2: gather + mean over the extended table, dense step, gradient reduction."""
+        ops, g, lib, _p = self.ops, self.g, self.lib, self.ops._p
+        agg = self.agg.view(-1)[:g.R * B * self.F].view(g.R, B, self.F)
+        ops.aggregate_lists(g, g.X, B, self._ws_of(B), self.cnt[:g.R * B], agg)
+        st = ops._stream(self.dev)
+        check, c = self._libmod.check, self.cfg
+        check(lib.pcg_dense_step(g.desc_ref(), _p(self.theta), self.E, _p(ids_local), _p(labels), B, _p(agg), agg.stride(1),
+                                 float(c["alpha"]), 1.0 / (B * self.world), _p(self.logits), _p(self.center), None,
+                                 _p(self.row_loss), _p(self.slabs), _p(self.step_counter), st), "pcg_dense_step")
+        check(lib.pcg_adam_step(_p(self.theta), _p(self.m), _p(self.v), _p(self.slabs), lib.pcg_dense_n_tiles(B),
+                                self.n_params, _p(self.step_counter), c["lr"], 0.9, 0.999, 1e-8, c["weight_decay"],
+                                _p(self.grad), 0, st), "pcg_adam_step")
+
+    def _ws_of(self, B):
+        if B == self.ws.B:
+            return self.ws
+        if B not in self._ws_extra:
+            self._ws_extra[B] = self.ops.ChooseWorkspace(self.g, B)
+        return self._ws_extra[B]
+
+    def _exchange(self, B):
+        ws = self._ws_of(B)
+        total_dev = ws.view(0, torch.int64, self.g.R * B + 1)[-1:]          # list entries in use: stays on the device
+        self.halo.fetch_and_remap_device(ws.view(2, torch.int32, ws.list_capacity), total_dev, self.g)
+
     def forward_sample(self, ids_local: torch.Tensor, labels: Optional[torch.Tensor], train_flag: bool = True):
         """steps 1-3 + aggregate: returns agg [R, B, F] for this rank's centres (local row numbers)."""
         ops, g, part = self.ops, self.g, self.part
         B = ids_local.numel()
         ops.score_table(g, self.w_clf, self.b_clf, out=self.s0_send, row_begin=0, row_end=part.n_local)
         self._all_gather(self.s0_full, self.s0_send)
-        keys = ops.pos_sort(g, self.s0_full, self.keys) if (train_flag and g.n_pos) else None
-        center = self.s0_full[(ids_local.long() + part.lo)]
-        ws = self.ws if B == self.ws.B else ops.ChooseWorkspace(g, B)
-        cnt = self.cnt[:g.R * B]
-        ops.choose_select(g, ids_local, labels if train_flag else None, self.s0_full, keys, self.thresholds, self.rho,
-                          train_flag, ws, cnt, center_s0=center)
-        total_dev = ws.view(0, torch.int64, g.R * B + 1)[-1:]               # list entries in use: stays on the device
-        self.halo.fetch_and_remap_device(ws.view(2, torch.int32, ws.list_capacity), total_dev, g)
+        self._seg_select(ids_local, labels, B, train_flag)
+        self._exchange(B)
         agg = self.agg.view(-1)[:g.R * B * self.F].view(g.R, B, self.F)
-        ops.aggregate_lists(g, g.X, B, ws, cnt, agg)
+        cnt = self.cnt[:g.R * B]
+        ops.aggregate_lists(g, g.X, B, self._ws_of(B), cnt, agg)
         return agg, cnt
 
-    def train_step(self, ids_local: torch.Tensor, labels: torch.Tensor):
-        ops, g, lib, _p = self.ops, self.g, self.lib, self.ops._p
+    def _graphs_for(self, B):
+        """hipGraphs of the two collective-free segments for batch size B (static id / label buffers)."""
+        gr = self._graphs.get(B)
+        if gr is not None:
+            return gr
+        ids, lab = self.ids_buf[:B], self.lab_buf[:B]
+        state = (self.theta.clone(), self.m.clone(), self.v.clone(), self.step_counter.clone())
+        s = torch.cuda.Stream(self.dev)            # warm-up: kernel attributes, auxiliary streams, workspaces
+        s.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(s):
+            self._seg_select(ids, lab, B, True)
+            self._seg_dense(ids, lab, B)
+        torch.cuda.current_stream(self.dev).wait_stream(s)
+        gr = {}
+        for name, fn in (("select", lambda: self._seg_select(ids, lab, B, True)), ("dense", lambda: self._seg_dense(ids, lab, B))):
+            g_ = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_):
+                fn()
+            gr[name] = g_
+        for dst, src in zip((self.theta, self.m, self.v, self.step_counter), state):
+            dst.copy_(src)
+        self._graphs[B] = gr
+        return gr
+
+    def train_step(self, ids_local: torch.Tensor, labels: torch.Tensor, use_graphs: bool = True):
+        """One training step of this rank: only the score all-gather, the halo exchange and the gradient
+        all-reduce are launched eagerly; the rest replays two captured graphs."""
+        ops, g, lib, _p, part = self.ops, self.g, self.lib, self.ops._p, self.part
         B = ids_local.numel()
-        agg, _ = self.forward_sample(ids_local, labels, True)
-        st = ops._stream(self.dev)
-        check = self._libmod.check
-        check(lib.pcg_dense_step(g.desc_ref(), _p(self.theta), self.E, _p(ids_local), _p(labels), B, _p(agg), agg.stride(1),
-                                 float(self.cfg["alpha"]), 1.0 / (B * self.world), _p(self.logits), _p(self.center), None,
-                                 _p(self.row_loss), _p(self.slabs), _p(self.step_counter), st), "pcg_dense_step")
-        c = self.cfg
-        check(lib.pcg_adam_step(_p(self.theta), _p(self.m), _p(self.v), _p(self.slabs), lib.pcg_dense_n_tiles(B),
-                                self.n_params, _p(self.step_counter), c["lr"], 0.9, 0.999, 1e-8, c["weight_decay"],
-                                _p(self.grad), 0, st), "pcg_adam_step")
+        if use_graphs:
+            gr = self._graphs_for(B)
+            self.ids_buf[:B].copy_(ids_local)
+            self.lab_buf[:B].copy_(labels)
+            ids_local, labels = self.ids_buf[:B], self.lab_buf[:B]
+        ops.score_table(g, self.w_clf, self.b_clf, out=self.s0_send, row_begin=0, row_end=part.n_local)
+        self._all_gather(self.s0_full, self.s0_send)
+        if use_graphs:
+            gr["select"].replay()
+        else:
+            self._seg_select(ids_local, labels, B, True)
+        self._exchange(B)
+        if use_graphs:
+            gr["dense"].replay()
+        else:
+            self._seg_dense(ids_local, labels, B)
         self._all_reduce(self.grad)
-        check(lib.pcg_adam_step(_p(self.theta), _p(self.m), _p(self.v), _p(self.grad), 1, self.n_params,
-                                _p(self.step_counter), c["lr"], 0.9, 0.999, 1e-8, c["weight_decay"], None, 1, st),
-              "pcg_adam_step")
+        c = self.cfg
+        self._libmod.check(lib.pcg_adam_step(_p(self.theta), _p(self.m), _p(self.v), _p(self.grad), 1, self.n_params,
+                                             _p(self.step_counter), c["lr"], 0.9, 0.999, 1e-8, c["weight_decay"], None, 1,
+                                             ops._stream(self.dev)), "pcg_adam_step")
 
     def pick_epoch(self, size: int, epoch: int) -> torch.Tensor:
         """this rank's share of the epoch's picks: local row numbers of owned training nodes."""

@@ -58,7 +58,7 @@ def _worker(rank, world, port, q):
         assert stats["halo_rows"] > 0 and stats["rows_served"] > 0
 
         # ---- one train step: gradient = all-reduced; compare with the single-GPU gradient on the global batch ----
-        d.train_step(ids_local, labels)
+        d.train_step(ids_local, labels, use_graphs=(rank == 0))     # one rank through the captured graphs, one eagerly
         torch.cuda.synchronize()
         all_ids = [torch.empty(B, dtype=torch.int32) for _ in range(world)]
         dist.all_gather(all_ids, gids.cpu())
