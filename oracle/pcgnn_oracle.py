@@ -232,7 +232,7 @@ def train_step(model: OraclePCGNN, opt: torch.optim.Optimizer, nodes, labels) ->
     loss = model.loss(nodes, labels)
     loss.backward()
     opt.step()
-    return float(loss)
+    return loss.item()
 
 
 def make_adam(model: OraclePCGNN, lr: float, weight_decay: float) -> torch.optim.Adam:

@@ -33,6 +33,7 @@ constexpr int T16_CAP = 12288;   // ... by a 16-wave workgroup with ids+keys in 
 constexpr int T1_WAVES_PER_BLOCK = 4;
 constexpr int N_T4_BLOCKS = 1024;
 constexpr int N_T16_BLOCKS = 256;
+constexpr int MID_NW = 8;        // waves per mid-degree row
 constexpr int CHUNK = 256;       // list entries per gather work item
 constexpr int UNROLL = 8;        // row-gather instructions in flight per wave
 constexpr int KEY_UNROLL = 4;    // neighbour-score gathers in flight per lane
@@ -951,7 +952,8 @@ __global__ void __launch_bounds__(T1_WAVES_PER_BLOCK *PCG_WAVE) select_t1(const 
 }
 
 // tiers 4 / 16: one workgroup per row, rows pulled from the tier's queue
-template <int NW, int CAP>
+// MID: the mid-degree queue (T1_CAP < deg <= T4_CAP) instead of the hub queue
+template <int NW, int CAP, bool MID>
 __global__ void __launch_bounds__(NW *PCG_WAVE) select_wide(const ChooseArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t *keys_lds = reinterpret_cast<uint32_t *>(smem);
@@ -960,9 +962,9 @@ __global__ void __launch_bounds__(NW *PCG_WAVE) select_wide(const ChooseArgs a) 
     uint32_t *cand = ckeys_lds + CAP;
     int *red = reinterpret_cast<int *>(cand + PCG_WAVE);
     int *qslot = red + 2 * NW + 2;
-    const int32_t *queue = (NW == 4) ? a.w.q4 : a.w.q16;
-    const uint32_t nq = a.w.counters[(NW == 4) ? C_N4 : C_N16];
-    uint32_t *head = &a.w.counters[(NW == 4) ? C_HEAD4 : C_HEAD16];
+    const int32_t *queue = MID ? a.w.q4 : a.w.q16;
+    const uint32_t nq = a.w.counters[MID ? C_N4 : C_N16];
+    uint32_t *head = &a.w.counters[MID ? C_HEAD4 : C_HEAD16];
     for (;;) {
         if (threadIdx.x == 0) *qslot = (int)atomicAdd(head, 1u);
         __syncthreads();
@@ -970,7 +972,7 @@ __global__ void __launch_bounds__(NW *PCG_WAVE) select_wide(const ChooseArgs a) 
         __syncthreads();
         if (qi >= nq) break;
         const int row = __builtin_amdgcn_readfirstlane(queue[qi]);  // one row per workgroup: scalar
-        if (NW == 16 && a.w.recs[row].d > CAP) {   // over-long hub row: ids + keys in global scratch
+        if (!MID && a.w.recs[row].d > CAP) {   // over-long hub row: ids + keys in global scratch
             uint32_t *gk = a.w.scratch + (size_t)blockIdx.x * 3 * a.g.max_degree;
             select_row<NW>(a, row, gk, gk + a.g.max_degree, gk + 2 * (size_t)a.g.max_degree, cand, red);
         } else {
@@ -1174,36 +1176,48 @@ static int launch_select(const ChooseArgs &a, hipStream_t st) {
     const bool wide16 = g.max_degree > T4_CAP, wide4 = g.max_degree > T1_CAP;
     Fork &f = fork_state();
     if (!f.ok) return PCG_E_LAUNCH;
-    if (wide4 || wide16)
-        if (hipEventRecord(f.fork, st) != hipSuccess) return PCG_E_LAUNCH;
+    // Hub rows are the long pole and need most of a CU's LDS: they go first, on the caller's stream, so they
+    // start without the fork latency and before tier-1 blocks have filled every CU.  The mid tier and tier 1
+    // are forked (with one tier only there is nothing to overlap and no fork).
+    const int t1_blocks = (rows + T1_WAVES_PER_BLOCK - 1) / T1_WAVES_PER_BLOCK;
+    if (!wide4) {
+        hipLaunchKernelGGL(select_t1, dim3(t1_blocks), dim3(T1_WAVES_PER_BLOCK * PCG_WAVE), 0, st, a);
+        PCG_LAUNCH_CHECK();
+        return PCG_OK;
+    }
+    if (hipEventRecord(f.fork, st) != hipSuccess) return PCG_E_LAUNCH;
     if (wide16) {
         const size_t smem = wide_smem_bytes(16, T16_CAP);
         static bool attr16 = false;
         if (!attr16) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(select_wide<16, T16_CAP>),
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(select_wide<16, T16_CAP, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
                 return PCG_E_LAUNCH;
             attr16 = true;
         }
-        if (hipStreamWaitEvent(f.aux[0], f.fork, 0) != hipSuccess) return PCG_E_LAUNCH;
         const int nb = rows < N_T16_BLOCKS ? rows : N_T16_BLOCKS;
-        hipLaunchKernelGGL((select_wide<16, T16_CAP>), dim3(nb), dim3(16 * PCG_WAVE), smem, f.aux[0], a);
+        hipLaunchKernelGGL((select_wide<16, T16_CAP, false>), dim3(nb), dim3(16 * PCG_WAVE), smem, st, a);
         PCG_LAUNCH_CHECK();
-        if (hipEventRecord(f.join[0], f.aux[0]) != hipSuccess) return PCG_E_LAUNCH;
     }
-    if (wide4) {
-        const size_t smem = wide_smem_bytes(4, T4_CAP);
+    {   // mid tier on aux[1]
+        const size_t smem = wide_smem_bytes(MID_NW, T4_CAP);
         if (hipStreamWaitEvent(f.aux[1], f.fork, 0) != hipSuccess) return PCG_E_LAUNCH;
         const int nb = rows < N_T4_BLOCKS ? rows : N_T4_BLOCKS;
-        hipLaunchKernelGGL((select_wide<4, T4_CAP>), dim3(nb), dim3(4 * PCG_WAVE), smem, f.aux[1], a);
+        hipLaunchKernelGGL((select_wide<MID_NW, T4_CAP, true>), dim3(nb), dim3(MID_NW * PCG_WAVE), smem, f.aux[1], a);
         PCG_LAUNCH_CHECK();
         if (hipEventRecord(f.join[1], f.aux[1]) != hipSuccess) return PCG_E_LAUNCH;
     }
-    const int blocks = (rows + T1_WAVES_PER_BLOCK - 1) / T1_WAVES_PER_BLOCK;
-    hipLaunchKernelGGL(select_t1, dim3(blocks), dim3(T1_WAVES_PER_BLOCK * PCG_WAVE), 0, st, a);
-    PCG_LAUNCH_CHECK();
-    if (wide16 && hipStreamWaitEvent(st, f.join[0], 0) != hipSuccess) return PCG_E_LAUNCH;
-    if (wide4 && hipStreamWaitEvent(st, f.join[1], 0) != hipSuccess) return PCG_E_LAUNCH;
+    if (wide16) {   // tier 1 on aux[0] (beside the hub tier)
+        if (hipStreamWaitEvent(f.aux[0], f.fork, 0) != hipSuccess) return PCG_E_LAUNCH;
+        hipLaunchKernelGGL(select_t1, dim3(t1_blocks), dim3(T1_WAVES_PER_BLOCK * PCG_WAVE), 0, f.aux[0], a);
+        PCG_LAUNCH_CHECK();
+        if (hipEventRecord(f.join[0], f.aux[0]) != hipSuccess) return PCG_E_LAUNCH;
+        if (hipStreamWaitEvent(st, f.join[0], 0) != hipSuccess) return PCG_E_LAUNCH;
+    } else {        // no hub rows: tier 1 stays on the caller's stream
+        hipLaunchKernelGGL(select_t1, dim3(t1_blocks), dim3(T1_WAVES_PER_BLOCK * PCG_WAVE), 0, st, a);
+        PCG_LAUNCH_CHECK();
+    }
+    if (hipStreamWaitEvent(st, f.join[1], 0) != hipSuccess) return PCG_E_LAUNCH;
     return PCG_OK;
 }
 

@@ -591,3 +591,25 @@ def test_large_batch_two_pass_plan(P):
     probe = list(range(0, B, 97))
     want = oracle_sets(csrs[1], n, nodes[probe].tolist(), lab[probe].tolist(), s0.cpu().numpy(), train_pos, 0.5, 0.5, True)
     assert [sets[1][b] for b in probe] == want
+
+
+def test_fused_trajectory_tracks_oracle(P, case):
+    """Four consecutive Adam steps: the HIP path's loss trajectory and parameters follow the CPU oracle's
+    (independent implementation: Python sets + torch.sort + dense-mask mean + torch autograd + torch Adam)."""
+    c = case
+    rho = c.rhos[0]
+    m, fz = fused_of(P, c, rho)
+    om = O.OraclePCGNN(torch.from_numpy(c.X), c.adj_lists(), c.train_pos, c.params(), rho, c.alpha, dense_mask=False)
+    opt = O.make_adam(om, c.lr, c.wd)
+    ids = torch.tensor(c.nodes, dtype=torch.int32, device=dev())
+    lab = torch.from_numpy(c.batch_labels.astype(np.int32)).cuda()
+    half = len(c.nodes) // 2
+    for step in range(4):
+        sl = slice(0, None) if step % 2 == 0 else slice(half // 2, half // 2 + half)
+        want = O.train_step(om, opt, c.nodes[sl], c.batch_labels[sl])
+        fz.train_step(ids[sl].contiguous(), lab[sl].contiguous())
+        got = float(fz.last_loss())
+        assert abs(got - want) < 2e-3 * max(1.0, abs(want)), (step, got, want)
+    sd = m.state_dict()
+    for k in PARAM_KEYS(c.R):
+        np.testing.assert_allclose(sd[k].cpu().numpy(), om.p[k].detach().numpy(), rtol=0, atol=c.lr * 0.3, err_msg=k)
