@@ -138,8 +138,10 @@ class HaloExchangeHip(HaloExchange):
         w = part.world
         self._last = torch.tensor([min((r + 1) * part.n_per, n_nodes) - 1 for r in range(w)], dtype=torch.long, device=dev)
         self._counts_all = torch.zeros(w * w, dtype=torch.int32, device=dev)
-        self._req = torch.empty(self.halo_cap, dtype=torch.int32, device=dev)
-        self._rows = torch.zeros(self.halo_cap, X_ext.shape[1], dtype=torch.float32, device=dev)
+        # what THIS rank may be asked for: every other rank can request each of its owned rows once per step
+        self.serve_cap = max(1, (w - 1) * part.n_local)
+        self._req = torch.empty(self.serve_cap, dtype=torch.int32, device=dev)
+        self._rows = torch.zeros(self.serve_cap, X_ext.shape[1], dtype=torch.float32, device=dev)
 
     def _gather_counts(self, out, inp):
         if self.stage_host:
@@ -163,8 +165,9 @@ class HaloExchangeHip(HaloExchange):
         mat = self._counts_all.view(w, w).cpu()                            # the step's single host sync
         sc, rc = mat[rank].tolist(), mat[:, rank].tolist()
         n_halo, n_req = sum(sc), sum(rc)
-        if n_halo > self.halo_cap or n_req > self.halo_cap:
-            raise RuntimeError(f"halo needs {max(n_halo, n_req)} rows but only {self.halo_cap} were reserved")
+        if n_halo > self.halo_cap or n_req > self.serve_cap:
+            raise RuntimeError(f"halo exchange: {n_halo} rows to fetch (capacity {self.halo_cap}), {n_req} to serve "
+                               f"(capacity {self.serve_cap})")
         self._lib.check(lib.pcg_halo_compact(_p(self.flag), _p(slot), self.n_nodes, _p(self.uniq), st), "pcg_halo_compact")
         req = self._req[:n_req]
         self._a2a(req, self.uniq[:n_halo], rc, sc)                         # all-to-all #1: requested ids
@@ -341,10 +344,12 @@ class DistributedPCGNN:
             self._seg_select(ids, lab, B, True)
             self._seg_dense(ids, lab, B)
         torch.cuda.current_stream(self.dev).wait_stream(s)
+        torch.cuda.synchronize(self.dev)           # no collective of ours is in flight while capturing
         gr = {}
         for name, fn in (("select", lambda: self._seg_select(ids, lab, B, True)), ("dense", lambda: self._seg_dense(ids, lab, B))):
             g_ = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_):
+            # thread_local: RCCL's watchdog thread may query events while this thread captures
+            with torch.cuda.graph(g_, capture_error_mode="thread_local"):
                 fn()
             gr[name] = g_
         for dst, src in zip((self.theta, self.m, self.v, self.step_counter), state):
