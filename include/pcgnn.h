@@ -86,8 +86,9 @@ int pcg_score_rows(const pcg_graph_desc *g, const float *W, const float *b,
 
 /* Sort the training positives by class-0 logit once per step; replaces the
  * per-centre torch.sort over all of pos_scores (layers.py:683-688).
- * keys [pcg_pos_sort_capacity(n_pos)] uint64: (orderable(s0[train_pos[p]]) << 32) | p,
- * ascending, padded with UINT64_MAX. */
+ * keys [pcg_pos_sort_capacity(n_pos)] uint64; on return its first ceil_pow2(max(n_pos, 4096)) entries hold
+ * (orderable(s0[train_pos[p]]) << 32) | p ascending, padded with UINT64_MAX (for n_pos > 16384 the capacity is twice
+ * that: the second half is scratch of the chunk-sort path). */
 int64_t pcg_pos_sort_capacity(int32_t n_pos);
 int pcg_pos_sort(const pcg_graph_desc *g, const float *s0, uint64_t *keys, void *stream);
 

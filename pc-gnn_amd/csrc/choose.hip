@@ -678,7 +678,7 @@ __device__ __forceinline__ void select_row(const ChooseArgs &a, int row, uint32_
                 p2 = (g2 > lv && g2 <= hv) ? __float_as_uint(g2) : hi + 1;    // hi + 1: no upper cut (keys < 2^31: no wrap)
                 if (p2 < p1) p2 = p1;
             }
-            const bool first = cur == keys;
+            const bool first = cur == keys && ckeys != nullptr;
             int c1, c2;
             count_pass<NW>(cur, n_cur, lo, hi, p1, p2, first ? ckeys : nullptr, wave, lane, red, c1, c2);
             if (below + c1 >= k) {              // k-th < p1
@@ -942,13 +942,14 @@ __device__ __forceinline__ void select_row(const ChooseArgs &a, int row, uint32_
 __global__ void __launch_bounds__(T1_WAVES_PER_BLOCK *PCG_WAVE) select_t1(const ChooseArgs a) {
     __shared__ uint32_t keys[T1_WAVES_PER_BLOCK][T1_CAP];
     __shared__ uint32_t ids[T1_WAVES_PER_BLOCK][T1_CAP];
-    __shared__ uint32_t ckeys[T1_WAVES_PER_BLOCK][T1_CAP];
     __shared__ uint32_t cand[T1_WAVES_PER_BLOCK][PCG_WAVE];
     const int w = threadIdx.x >> 6;
     const uint32_t qi = blockIdx.x * T1_WAVES_PER_BLOCK + w;
     if (qi >= a.w.counters[C_N1]) return;
     const int row = __builtin_amdgcn_readfirstlane(a.w.q1[qi]);     // one row per wave: make it scalar
-    select_row<1>(a, row, keys[w], ids[w], ckeys[w], cand[w], nullptr);
+    // no compaction buffer in this tier (rows <= 512: later passes just re-filter the keys): 17 KB of LDS
+    // per block instead of 25 KB => 8 row-waves more per CU
+    select_row<1>(a, row, keys[w], ids[w], nullptr, cand[w], nullptr);
 }
 
 // tiers 4 / 16: one workgroup per row, rows pulled from the tier's queue

@@ -65,8 +65,20 @@ __device__ __forceinline__ float score_partial(const float *__restrict__ xrow, c
     }
     return p;
 }
+// add the value of a DPP-selected neighbour lane (full-rate VALU, no LDS crossbar round trip)
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float p) {
+    return p + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(p), CTRL, 0xF, 0xF, false));
+}
+// Butterfly over the lpr lanes that share a row.  Steps 1, 2 use quad permutes; steps 4 and 8 use the
+// half-row / row mirror: after the previous steps every lane of a group holds its group's sum, so adding the
+// mirrored lane's value adds the neighbouring group's sum - the same two operands as the xor partner's.
 __device__ __forceinline__ float score_reduce(float p, int lpr) {
-    for (int o = 1; o < lpr; o <<= 1) p += __shfl_xor(p, o);
+    p = dpp_add<0xB1>(p);                 // quad_perm [1,0,3,2]  (lane ^ 1)
+    p = dpp_add<0x4E>(p);                 // quad_perm [2,3,0,1]  (lane ^ 2)
+    p = dpp_add<0x141>(p);                // row_half_mirror      (other quad of the 8-lane group)
+    if (lpr > 8) p = dpp_add<0x140>(p);   // row_mirror           (other half of the 16-lane row)
+    for (int o = 16; o < lpr; o <<= 1) p += __shfl_xor(p, o);
     return p;
 }
 

@@ -2,7 +2,8 @@
 // Replaces the per-centre torch.sort over all pos_scores (src/layers.py:683-688):
 // sorted once, every positive centre then finds its m nearest by a window search.
 // Keys are unique 64-bit (orderable(score) << 32 | position in train_pos), so the
-// bitonic network's result is a total order: equal scores stay in list order.
+// result is a total order: equal scores stay in list order.  Small P: one-launch rank sort;
+// large P: LDS bitonic sort of 4096-key chunks + one merge-by-ranks pass.
 #include "common.h"
 
 namespace pcg {
@@ -38,33 +39,12 @@ __device__ __forceinline__ void lds_steps(uint64_t *sh, int chunk_base, int k, i
 // build the keys and fully sort each SORT_CHUNK-sized chunk (alternating directions)
 __global__ void __launch_bounds__(SORT_THREADS) pos_sort_local(const float *__restrict__ s0,
                                                                const int32_t *__restrict__ train_pos, int n_pos,
-                                                               uint64_t *__restrict__ keys) {
+                                                               uint64_t *__restrict__ keys, int all_ascending) {
     __shared__ uint64_t sh[SORT_CHUNK];
     const int base = blockIdx.x * SORT_CHUNK;
     for (int t = threadIdx.x; t < SORT_CHUNK; t += SORT_THREADS) sh[t] = make_pos_key(s0, train_pos, base + t, n_pos);
     __syncthreads();
-    for (int k = 2; k <= SORT_CHUNK; k <<= 1) lds_steps(sh, base, k, k >> 1);
-    for (int t = threadIdx.x; t < SORT_CHUNK; t += SORT_THREADS) keys[base + t] = sh[t];
-}
-
-__global__ void __launch_bounds__(256) bitonic_global_step(uint64_t *__restrict__ keys, int64_t n_pairs, int j, int k) {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_pairs) return;
-    const int64_t i = 2 * (int64_t)j * (p / j) + (p % j);
-    uint64_t a = keys[i], b = keys[i + j];
-    const bool asc = ((i & k) == 0);
-    if ((a > b) == asc) {
-        keys[i] = b;
-        keys[i + j] = a;
-    }
-}
-
-__global__ void __launch_bounds__(SORT_THREADS) bitonic_local_merge(uint64_t *__restrict__ keys, int k) {
-    __shared__ uint64_t sh[SORT_CHUNK];
-    const int base = blockIdx.x * SORT_CHUNK;
-    for (int t = threadIdx.x; t < SORT_CHUNK; t += SORT_THREADS) sh[t] = keys[base + t];
-    __syncthreads();
-    lds_steps(sh, base, k, SORT_CHUNK >> 1);
+    for (int k = 2; k <= SORT_CHUNK; k <<= 1) lds_steps(sh, all_ascending ? 0 : base, k, k >> 1);
     for (int t = threadIdx.x; t < SORT_CHUNK; t += SORT_THREADS) keys[base + t] = sh[t];
 }
 
@@ -73,7 +53,7 @@ __global__ void __launch_bounds__(SORT_THREADS) bitonic_local_merge(uint64_t *__
 // (one per lane), walks all keys in LDS tiles of RANK_TILE and splits each tile's j-range over its
 // 16 waves; LDS reads are wave-wide broadcasts.  O(P^2) compares, but embarrassingly parallel: it
 // beats the many-launch bitonic network up to a few 10^4 keys.
-constexpr int RANK_MAX = 65536;
+constexpr int RANK_MAX = 16384;
 constexpr int RANK_TILE = 8192;
 constexpr int RANK_WAVES = 16;
 
@@ -112,6 +92,36 @@ __global__ void __launch_bounds__(RANK_WAVES *PCG_WAVE) pos_rank_sort(const floa
         for (int t = n_pos + threadIdx.x; t < cap; t += blockDim.x) keys[t] = ~0ull;
 }
 
+// ---- large n_pos: every 4096-chunk sorted in LDS, then one "merge by ranks" pass ----------------------
+// rank(e) = its index in its own chunk + sum over the other chunks of #keys smaller than e (binary search in
+// an LDS copy of that chunk).  Keys are unique, so the ranks are a permutation.  Work P * (P/4096) * 12 LDS
+// steps instead of the rank sort's P^2 compares.
+__global__ void __launch_bounds__(SORT_THREADS) pos_merge_rank(const uint64_t *__restrict__ chunks, int n_pos, int cap,
+                                                               uint64_t *__restrict__ out) {
+    __shared__ uint64_t sh[SORT_CHUNK];
+    const int n_chunks = cap / SORT_CHUNK;
+    const int e = blockIdx.x * SORT_THREADS + threadIdx.x;       // element handled by this thread
+    const bool real = e < cap;
+    const uint64_t mine = real ? chunks[e] : ~0ull;
+    const int my_chunk = e / SORT_CHUNK;
+    int rank = e - my_chunk * SORT_CHUNK;
+    for (int c = 0; c < n_chunks; ++c) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < SORT_CHUNK; t += SORT_THREADS) sh[t] = chunks[(size_t)c * SORT_CHUNK + t];
+        __syncthreads();
+        if (c == my_chunk) continue;
+        int lo = 0, hi = SORT_CHUNK;                              // #keys of chunk c smaller than mine
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (sh[mid] < mine) lo = mid + 1;
+            else hi = mid;
+        }
+        rank += lo;
+    }
+    if (real && mine != ~0ull) out[rank] = mine;                  // padding keys are not scattered ...
+    if (real && e >= n_pos) out[e] = ~0ull;                       // ... the tail [n_pos, cap) is filled directly
+}
+
 static int64_t sort_capacity(int32_t n_pos) {
     int64_t c = SORT_CHUNK;
     while (c < n_pos) c <<= 1;
@@ -122,33 +132,31 @@ static int64_t sort_capacity(int32_t n_pos) {
 
 extern "C" {
 
-int64_t pcg_pos_sort_capacity(int32_t n_pos) { return n_pos < 0 ? PCG_E_ARG : pcg::sort_capacity(n_pos); }
+int64_t pcg_pos_sort_capacity(int32_t n_pos) {
+    if (n_pos < 0) return PCG_E_ARG;
+    const int64_t cap = pcg::sort_capacity(n_pos);
+    return n_pos <= pcg::RANK_MAX ? cap : 2 * cap;     // the chunk-sort path needs a second buffer of the same size
+}
 
 int pcg_pos_sort(const pcg_graph_desc *g, const float *s0, uint64_t *keys, void *stream) {
     if (!g || !s0 || !keys || g->n_pos < 0 || (g->n_pos > 0 && !g->train_pos)) return PCG_E_ARG;
     if (g->n_pos == 0) return PCG_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t cap = pcg::sort_capacity(g->n_pos);
+    if (cap >= (1ll << 31)) return PCG_E_UNSUPPORTED;
     if (g->n_pos <= pcg::RANK_MAX) {
         hipLaunchKernelGGL(pcg::pos_rank_sort, dim3((g->n_pos + PCG_WAVE - 1) / PCG_WAVE),
                            dim3(pcg::RANK_WAVES * PCG_WAVE), 0, st, s0, g->train_pos, g->n_pos, (int)cap, keys);
         PCG_LAUNCH_CHECK();
         return PCG_OK;
     }
+    uint64_t *tmp = keys + cap;                         // second half of the caller's buffer
     const int chunks = (int)(cap / pcg::SORT_CHUNK);
-    hipLaunchKernelGGL(pcg::pos_sort_local, dim3(chunks), dim3(pcg::SORT_THREADS), 0, st, s0, g->train_pos, g->n_pos,
-                       keys);
+    hipLaunchKernelGGL(pcg::pos_sort_local, dim3(chunks), dim3(pcg::SORT_THREADS), 0, st, s0, g->train_pos, g->n_pos, tmp, 1);
     PCG_LAUNCH_CHECK();
-    for (int64_t k = 2 * pcg::SORT_CHUNK; k <= cap; k <<= 1) {
-        for (int64_t j = k >> 1; j >= pcg::SORT_CHUNK; j >>= 1) {
-            const int64_t pairs = cap / 2;
-            hipLaunchKernelGGL(pcg::bitonic_global_step, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, keys,
-                               pairs, (int)j, (int)k);
-            PCG_LAUNCH_CHECK();
-        }
-        hipLaunchKernelGGL(pcg::bitonic_local_merge, dim3(chunks), dim3(pcg::SORT_THREADS), 0, st, keys, (int)k);
-        PCG_LAUNCH_CHECK();
-    }
+    hipLaunchKernelGGL(pcg::pos_merge_rank, dim3((unsigned)(cap / pcg::SORT_THREADS)), dim3(pcg::SORT_THREADS), 0, st, tmp,
+                       g->n_pos, (int)cap, keys);
+    PCG_LAUNCH_CHECK();
     return PCG_OK;
 }
 

@@ -359,9 +359,9 @@ def test_intra_agg_reference_signature(P, case):
     np.testing.assert_allclose(feats.detach().cpu().numpy(), c.z["test_feats0"], rtol=0, atol=FEAT_TOL)
 
 
-@pytest.mark.parametrize("n_pos", [1, 63, 64, 65, 4096, 8192, 8193, 40000, 65536, 65537])
+@pytest.mark.parametrize("n_pos", [1, 63, 64, 65, 4096, 8192, 8193, 16384, 16385, 40000, 65536, 65537])
 def test_pos_sort_sizes(P, n_pos):
-    """rank sort (<= 65536, tiles of 8192) and bitonic (> 65536) paths, incl. duplicate scores."""
+    """rank sort (<= 16384, tiles of 8192) and chunk-sort + merge-rank (> 16384) paths, incl. duplicate scores."""
     ops = P.ops
     n = 80000
     rs = np.random.RandomState(n_pos)
@@ -377,7 +377,10 @@ def test_pos_sort_sizes(P, n_pos):
     bits = sc.view(np.uint32).astype(np.int64)
     ordk = np.where(bits & 0x80000000, (~bits) & 0xFFFFFFFF, bits | 0x80000000)
     assert np.array_equal(pos, np.lexsort((np.arange(n_pos), ordk)))
-    assert np.all(keys[n_pos:] == np.uint64(0xFFFFFFFFFFFFFFFF))
+    cap = 4096
+    while cap < n_pos:
+        cap *= 2
+    assert np.all(keys[n_pos:cap] == np.uint64(0xFFFFFFFFFFFFFFFF))
 
 
 # ---------------------------------------------------------------------------
