@@ -86,7 +86,7 @@ static int64_t carve(const pcg_graph_desc *g, int32_t B, int64_t list_capacity, 
     p = take(4 * rows);                            if (w) w->q4 = reinterpret_cast<int32_t *>(p);
     p = take(4 * rows);                            if (w) w->q16 = reinterpret_cast<int32_t *>(p);
     p = take(32 * rows);                           if (w) w->recs = reinterpret_cast<RowRec *>(p);
-    p = take(32 * (rows / (PLAN_THREADS * PLAN_PER) + 1));   if (w) w->plan_totals = p;
+    p = take(32 * (rows / PLAN_THREADS + 2));      if (w) w->plan_totals = p;
     p = take(4 * chunk_cap);                       if (w) w->chunk_row = reinterpret_cast<int32_t *>(p);
     p = take(4 * chunk_cap * g->feat_stride);      if (w) w->partial = reinterpret_cast<float *>(p);
     p = take(4 * list_capacity);                   if (w) w->list = reinterpret_cast<int32_t *>(p);
@@ -300,15 +300,16 @@ __device__ __forceinline__ int row_cap(const RowRec &p, int add_self) {
     return (p.keep_all ? p.d : p.k) + p.m + (add_self ? 1 : 0);
 }
 
+template <int PER>
 __global__ void __launch_bounds__(PLAN_THREADS) plan_count(const ChooseArgs a, PlanTotals *totals) {
     __shared__ int lds[PLAN_THREADS / PCG_WAVE];
     __shared__ long long lds64[PLAN_THREADS / PCG_WAVE];
     const int rows = a.g.n_rel * a.B;
-    const int r0 = (blockIdx.x * PLAN_THREADS + threadIdx.x) * PLAN_PER;
+    const int r0 = (blockIdx.x * PLAN_THREADS + threadIdx.x) * PER;
     long long cap_sum = 0;
     int chunk_sum = 0, n1 = 0, n4 = 0, n16 = 0;
 #pragma unroll
-    for (int i = 0; i < PLAN_PER; ++i) {
+    for (int i = 0; i < PER; ++i) {
         const int row = r0 + i;
         if (row < rows) {
             const RowRec p = row_plan(a, row);
@@ -337,6 +338,7 @@ __global__ void __launch_bounds__(PLAN_THREADS) plan_count(const ChooseArgs a, P
     }
 }
 
+template <int PER>
 __global__ void __launch_bounds__(PLAN_THREADS) plan_write(const ChooseArgs a, const PlanTotals *totals) {
     __shared__ int lds[PLAN_THREADS / PCG_WAVE];
     __shared__ long long lds64[PLAN_THREADS / PCG_WAVE];
@@ -351,13 +353,13 @@ __global__ void __launch_bounds__(PLAN_THREADS) plan_write(const ChooseArgs a, c
         all_cap += t.cap; all_chunk += t.chunk; all1 += t.n1; all4 += t.n4; all16 += t.n16;
     }
     const bool overflow = all_cap > a.w.list_capacity || (long long)all_chunk > a.w.chunk_cap;
-    const int r0 = (blockIdx.x * PLAN_THREADS + threadIdx.x) * PLAN_PER;
-    RowRec rec[PLAN_PER];
-    int cap[PLAN_PER];
+    const int r0 = (blockIdx.x * PLAN_THREADS + threadIdx.x) * PER;
+    RowRec rec[PER];
+    int cap[PER];
     long long cap_sum = 0;
     int chunk_sum = 0, n1 = 0, n4 = 0, n16 = 0;
 #pragma unroll
-    for (int i = 0; i < PLAN_PER; ++i) {
+    for (int i = 0; i < PER; ++i) {
         const int row = r0 + i;
         cap[i] = 0;
         if (row < rows) {
@@ -377,7 +379,7 @@ __global__ void __launch_bounds__(PLAN_THREADS) plan_write(const ChooseArgs a, c
     const long long o_t = block_excl_scan<long long>((long long)n1 | ((long long)n4 << 20) | ((long long)n16 << 40), lds64, t_tiers);
     int o1 = run1 + (int)(o_t & 0xFFFFF), o4 = run4 + (int)((o_t >> 20) & 0xFFFFF), o16 = run16 + (int)(o_t >> 40);
 #pragma unroll
-    for (int i = 0; i < PLAN_PER; ++i) {
+    for (int i = 0; i < PER; ++i) {
         const int row = r0 + i;
         if (row >= rows) continue;
         const int nch = (cap[i] + CHUNK - 1) / CHUNK;
@@ -1167,11 +1169,11 @@ static int launch_select(const ChooseArgs &a, hipStream_t st) {
         hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(PLAN_THREADS), 0, st, a);
         PCG_LAUNCH_CHECK();
     } else {
-        const int nb = (rows + PLAN_THREADS * PLAN_PER - 1) / (PLAN_THREADS * PLAN_PER);
+        const int nb = (rows + PLAN_THREADS - 1) / PLAN_THREADS;       // one row per thread: spread over many CUs
         PlanTotals *tot = reinterpret_cast<PlanTotals *>(a.w.plan_totals);
-        hipLaunchKernelGGL(plan_count, dim3(nb), dim3(PLAN_THREADS), 0, st, a, tot);
+        hipLaunchKernelGGL(plan_count<1>, dim3(nb), dim3(PLAN_THREADS), 0, st, a, tot);
         PCG_LAUNCH_CHECK();
-        hipLaunchKernelGGL(plan_write, dim3(nb), dim3(PLAN_THREADS), 0, st, a, tot);
+        hipLaunchKernelGGL(plan_write<1>, dim3(nb), dim3(PLAN_THREADS), 0, st, a, tot);
         PCG_LAUNCH_CHECK();
     }
     const bool wide16 = g.max_degree > T4_CAP, wide4 = g.max_degree > T1_CAP;

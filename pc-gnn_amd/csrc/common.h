@@ -48,11 +48,17 @@ __host__ __device__ __forceinline__ int lanes_per_row(int stride) {
 // of `lpr` walks float4 chunks sub, sub+lpr, ...; inside a chunk a 4-long fma chain.
 // The cross-lane butterfly that finishes it is in score_reduce().  Both score
 // kernels use exactly these two functions, so their column 0 agrees bit for bit.
+template <bool STREAM = false>
 __device__ __forceinline__ float score_partial(const float *__restrict__ xrow, const float *__restrict__ w,
                                                int feat_dim, int stride, int sub, int lpr) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
     float p = 0.f;
     for (int ch = sub; ch < (stride >> 2); ch += lpr) {
-        const float4 x = *reinterpret_cast<const float4 *>(xrow + 4 * ch);
+        // STREAM: the whole table is read once per step - non-temporal, so it does not evict what the
+        // following kernels re-use from L2 / Infinity Cache
+        const f4 xv = STREAM ? __builtin_nontemporal_load(reinterpret_cast<const f4 *>(xrow + 4 * ch))
+                             : *reinterpret_cast<const f4 *>(xrow + 4 * ch);
+        const float4 x = make_float4(xv.x, xv.y, xv.z, xv.w);
         const int f = 4 * ch;
         const float w0 = (f + 0 < feat_dim) ? w[f + 0] : 0.f;
         const float w1 = (f + 1 < feat_dim) ? w[f + 1] : 0.f;

@@ -6,7 +6,7 @@
 
 namespace pcg {
 
-constexpr int SCORE_UNROLL = 4;
+constexpr int SCORE_UNROLL = 8;
 
 __global__ void __launch_bounds__(256) score_table_kernel(const float *__restrict__ X, int feat_dim, int stride,
                                                           const float *__restrict__ W, const float *__restrict__ bias,
@@ -24,13 +24,19 @@ __global__ void __launch_bounds__(256) score_table_kernel(const float *__restric
 #pragma unroll
         for (int u = 0; u < SCORE_UNROLL; ++u) {
             const int64_t row = base + (int64_t)u * rpw + slot;
-            p[u] = row < row_end ? score_partial(X + row * stride, W, feat_dim, stride, sub, lpr) : 0.f;
+            p[u] = row < row_end ? score_partial<true>(X + row * stride, W, feat_dim, stride, sub, lpr) : 0.f;
         }
+        // after the butterfly every lane of a row-group holds that row's sum: lane `sub` keeps the result of
+        // unrolled row `sub`, so the wave writes its rpw * SCORE_UNROLL consecutive scores in ONE store
+        float mine = 0.f;
 #pragma unroll
         for (int u = 0; u < SCORE_UNROLL; ++u) {
             const float s = score_reduce(p[u], lpr);
-            const int64_t row = base + (int64_t)u * rpw + slot;
-            if (row < row_end && sub == 0) s0[row] = s + b0;
+            if (sub == u) mine = s;
+        }
+        if (sub < SCORE_UNROLL) {
+            const int64_t row = base + (int64_t)sub * rpw + slot;
+            if (row < row_end) s0[row] = mine + b0;
         }
     }
 }
