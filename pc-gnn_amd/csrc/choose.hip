@@ -4,7 +4,7 @@
 //            cap = (deg > k+1 ? k : deg) + m (+1), exclusive offsets into the selection
 //            list, the degree-tier queues and the 256-entry chunk table of the gather.
 //   select   one group per row, group size by row length (<=512: one wave, <=4096: a
-//            256-thread workgroup, longer: 1024 threads; > 12288 via global scratch):
+//            512-thread workgroup, longer: 1024 threads; > 8192 via global scratch):
 //              1. neighbour ids + distance keys |s0[c] - s0[j]| -> LDS (4 gathers in flight)
 //              2. exact k-th smallest key by a bracketed counting search (interpolation in
 //                 value space alternating with bit-space bisection; <= 64 survivors are
@@ -29,10 +29,11 @@ namespace pcg {
 
 constexpr int T1_CAP = 512;      // row length handled by a single wave
 constexpr int T4_CAP = 4096;     // ... by a 4-wave workgroup
-constexpr int T16_CAP = 12288;   // ... by a 16-wave workgroup with ids+keys in LDS; longer rows: global scratch
+constexpr int T16_CAP = 8192;    // ... by a 16-wave workgroup with ids+keys in LDS (64 KB: leaves room for the other tiers'
+                                 // blocks on the same CU); its compaction buffer and longer rows live in global scratch
 constexpr int T1_WAVES_PER_BLOCK = 4;
 constexpr int N_T4_BLOCKS = 1024;
-constexpr int N_T16_BLOCKS = 256;
+constexpr int N_T16_BLOCKS = 128;
 constexpr int MID_NW = 8;        // waves per mid-degree row
 constexpr int CHUNK = 256;       // list entries per gather work item
 constexpr int UNROLL = 8;        // row-gather instructions in flight per wave
@@ -62,7 +63,7 @@ struct Workspace {
     int32_t *chunk_row;    // [chunk_cap]
     float *partial;        // [chunk_cap, feat_stride]
     int32_t *list;         // [list_capacity]  chosen ids; -1 = hole
-    uint32_t *scratch;     // [N_T16_BLOCKS * 3 * max_degree] when max_degree > T16_CAP
+    uint32_t *scratch;     // [N_T16_BLOCKS * 3 * max_degree] when the hub tier exists (max_degree > T4_CAP)
     int64_t list_capacity, chunk_cap;
 };
 
@@ -90,7 +91,7 @@ static int64_t carve(const pcg_graph_desc *g, int32_t B, int64_t list_capacity, 
     p = take(4 * chunk_cap);                       if (w) w->chunk_row = reinterpret_cast<int32_t *>(p);
     p = take(4 * chunk_cap * g->feat_stride);      if (w) w->partial = reinterpret_cast<float *>(p);
     p = take(4 * list_capacity);                   if (w) w->list = reinterpret_cast<int32_t *>(p);
-    p = take(g->max_degree > T16_CAP ? (int64_t)N_T16_BLOCKS * 3 * g->max_degree * 4 : 0);
+    p = take(g->max_degree > T4_CAP ? (int64_t)N_T16_BLOCKS * 3 * g->max_degree * 4 : 0);
     if (w) {
         w->scratch = reinterpret_cast<uint32_t *>(p);
         w->list_capacity = list_capacity;
@@ -961,8 +962,8 @@ __global__ void __launch_bounds__(NW *PCG_WAVE) select_wide(const ChooseArgs a) 
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t *keys_lds = reinterpret_cast<uint32_t *>(smem);
     uint32_t *ids_lds = keys_lds + CAP;
-    uint32_t *ckeys_lds = ids_lds + CAP;
-    uint32_t *cand = ckeys_lds + CAP;
+    uint32_t *ckeys_lds = ids_lds + CAP;                 // mid tier only
+    uint32_t *cand = MID ? ckeys_lds + CAP : ids_lds + CAP;
     int *red = reinterpret_cast<int *>(cand + PCG_WAVE);
     int *qslot = red + 2 * NW + 2;
     const int32_t *queue = MID ? a.w.q4 : a.w.q16;
@@ -975,17 +976,20 @@ __global__ void __launch_bounds__(NW *PCG_WAVE) select_wide(const ChooseArgs a) 
         __syncthreads();
         if (qi >= nq) break;
         const int row = __builtin_amdgcn_readfirstlane(queue[qi]);  // one row per workgroup: scalar
-        if (!MID && a.w.recs[row].d > CAP) {   // over-long hub row: ids + keys in global scratch
-            uint32_t *gk = a.w.scratch + (size_t)blockIdx.x * 3 * a.g.max_degree;
-            select_row<NW>(a, row, gk, gk + a.g.max_degree, gk + 2 * (size_t)a.g.max_degree, cand, red);
-        } else {
+        if constexpr (MID) {
             select_row<NW>(a, row, keys_lds, ids_lds, ckeys_lds, cand, red);
+        } else {
+            uint32_t *gk = a.w.scratch + (size_t)blockIdx.x * 3 * a.g.max_degree;
+            if (a.w.recs[row].d > CAP)   // over-long hub row: ids + keys in global scratch too
+                select_row<NW>(a, row, gk, gk + a.g.max_degree, gk + 2 * (size_t)a.g.max_degree, cand, red);
+            else                          // ids + keys in LDS, the first-pass survivors in global scratch
+                select_row<NW>(a, row, keys_lds, ids_lds, gk + 2 * (size_t)a.g.max_degree, cand, red);
         }
     }
 }
 
-static size_t wide_smem_bytes(int nw, int cap) {
-    return sizeof(uint32_t) * (3 * cap + PCG_WAVE) + sizeof(int) * (2 * nw + 2 + 2);
+static size_t wide_smem_bytes(int nw, int cap, bool mid) {
+    return sizeof(uint32_t) * ((mid ? 3 : 2) * cap + PCG_WAVE) + sizeof(int) * (2 * nw + 2 + 2);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1190,7 +1194,7 @@ static int launch_select(const ChooseArgs &a, hipStream_t st) {
     }
     if (hipEventRecord(f.fork, st) != hipSuccess) return PCG_E_LAUNCH;
     if (wide16) {
-        const size_t smem = wide_smem_bytes(16, T16_CAP);
+        const size_t smem = wide_smem_bytes(16, T16_CAP, false);
         static bool attr16 = false;
         if (!attr16) {
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(select_wide<16, T16_CAP, false>),
@@ -1203,7 +1207,7 @@ static int launch_select(const ChooseArgs &a, hipStream_t st) {
         PCG_LAUNCH_CHECK();
     }
     {   // mid tier on aux[1]
-        const size_t smem = wide_smem_bytes(MID_NW, T4_CAP);
+        const size_t smem = wide_smem_bytes(MID_NW, T4_CAP, true);
         if (hipStreamWaitEvent(f.aux[1], f.fork, 0) != hipSuccess) return PCG_E_LAUNCH;
         const int nb = rows < N_T4_BLOCKS ? rows : N_T4_BLOCKS;
         hipLaunchKernelGGL((select_wide<MID_NW, T4_CAP, true>), dim3(nb), dim3(MID_NW * PCG_WAVE), smem, f.aux[1], a);

@@ -219,7 +219,7 @@ def oracle_sets(csr, n, nodes, labels, s0, train_pos, thr, rho, train):
 
 def hub_graph(seed, n, hub_degs, base_deg=6.0, feat=32):
     """Graph with explicit hub rows (node i gets hub_degs[i] neighbours) to drive the
-    4-wave / 16-wave tiers (deg > 512 / > 4096), the global-scratch path (deg > 12288) and multi-chunk gathers."""
+    4-wave / 16-wave tiers (deg > 512 / > 4096), the global-scratch path (deg > 8192) and multi-chunk gathers."""
     X, labels, csrs = synth_graph(seed, n, feat, (base_deg,), 0.1, hub=False)
     indptr, idx = csrs[0]
     rs = np.random.RandomState(seed + 1)
@@ -235,7 +235,7 @@ def hub_graph(seed, n, hub_degs, base_deg=6.0, feat=32):
 def test_hub_rows_block_and_scratch_paths(P, quantize):
     ops = P.ops
     n = 60000
-    hub_degs = [30000, 13000, 12289, 12288, 12287, 9000, 4097, 4096, 4095, 2500, 513, 512, 511, 257, 256, 255, 65, 64, 63]
+    hub_degs = [30000, 13000, 8193, 8192, 8191, 6000, 4097, 4096, 4095, 2500, 513, 512, 511, 257, 256, 255, 65, 64, 63]
     X, labels, csr = hub_graph(11, n, hub_degs)
     if quantize:   # many exact distance ties: the positional tie-break must match the oracle
         X = np.round(X * 2) / 2
