@@ -27,14 +27,13 @@
 
 namespace pcg {
 
-constexpr int T1_CAP = 512;      // row length handled by a single wave
-constexpr int T4_CAP = 4096;     // ... by a 4-wave workgroup
-constexpr int T16_CAP = 8192;    // ... by a 16-wave workgroup with ids+keys in LDS (64 KB: leaves room for the other tiers'
-                                 // blocks on the same CU); its compaction buffer and longer rows live in global scratch
-constexpr int T1_WAVES_PER_BLOCK = 4;
-constexpr int N_T4_BLOCKS = 1024;
-constexpr int N_T16_BLOCKS = 128;
-constexpr int MID_NW = 8;        // waves per mid-degree row
+constexpr int T0_CAP = 128;      // short rows: one wave per row, taken last
+constexpr int T1_CAP = 512;      // row length handled by a single wave (keys + ids: 4 KB of LDS)
+constexpr int T4_CAP = 4096;     // ... by a whole 8-wave workgroup with keys, ids and first-pass survivors in LDS (48 KB)
+constexpr int HUB_LDS_CAP = 6144;  // hub row whose keys + ids still fit the 48 KB (survivors in global scratch); longer: all in scratch
+constexpr int SEL_NW = 8;        // waves per select workgroup
+constexpr int SEL_BLOCKS = 768;  // persistent select workgroups: 3 per CU
+constexpr int SEL_LDS_WORDS = 3 * T4_CAP;
 constexpr int CHUNK = 256;       // list entries per gather work item
 constexpr int UNROLL = 8;        // row-gather instructions in flight per wave
 constexpr int KEY_UNROLL = 4;    // neighbour-score gathers in flight per lane
@@ -43,7 +42,7 @@ constexpr int PLAN_PER = 4;      // rows per plan thread per tile
 constexpr int GATHER_BLOCKS = 2048;
 
 // counters (uint32) at the head of the workspace
-enum { C_N1 = 0, C_N4 = 1, C_N16 = 2, C_HEAD4 = 3, C_HEAD16 = 4, C_NCHUNK = 5, C_TOTAL_LO = 6, C_TOTAL_HI = 7 };
+enum { C_N1 = 0, C_N4 = 1, C_N16 = 2, C_HEAD4 = 3, C_HEAD16 = 4, C_NCHUNK = 5, C_TOTAL_LO = 6, C_TOTAL_HI = 7, C_N0 = 8, C_HEAD1 = 9, C_HEAD0 = 10 };
 
 struct RowRec {            // 32 bytes, written by plan, read by select (one 32-B load instead of a 3-deep chain)
     int64_t start;         // offset of the row in indices[r]
@@ -57,13 +56,13 @@ struct Workspace {
     int64_t *row_begin;    // [rows + 1] start of every row's region in list
     int32_t *chunk_begin;  // [rows + 1]
     int32_t *len;          // [rows]     entries (holes included) actually written
-    int32_t *q1, *q4, *q16;  // [rows] each
+    int32_t *q0, *q1, *q4, *q16;  // [rows] each: the rows of every degree tier
     struct RowRec *recs;   // [rows] what plan worked out per row
     unsigned char *plan_totals;   // [blocks of the two-pass plan] PlanTotals
     int32_t *chunk_row;    // [chunk_cap]
     float *partial;        // [chunk_cap, feat_stride]
     int32_t *list;         // [list_capacity]  chosen ids; -1 = hole
-    uint32_t *scratch;     // [N_T16_BLOCKS * 3 * max_degree] when the hub tier exists (max_degree > T4_CAP)
+    uint32_t *scratch;     // [SEL_BLOCKS * 3 * max_degree] when hub rows exist (max_degree > T4_CAP)
     int64_t list_capacity, chunk_cap;
 };
 
@@ -83,15 +82,16 @@ static int64_t carve(const pcg_graph_desc *g, int32_t B, int64_t list_capacity, 
     p = take(8 * (rows + 1));                      if (w) w->row_begin = reinterpret_cast<int64_t *>(p);
     p = take(4 * (rows + 1));                      if (w) w->chunk_begin = reinterpret_cast<int32_t *>(p);
     p = take(4 * rows);                            if (w) w->len = reinterpret_cast<int32_t *>(p);
+    p = take(4 * rows);                            if (w) w->q0 = reinterpret_cast<int32_t *>(p);
     p = take(4 * rows);                            if (w) w->q1 = reinterpret_cast<int32_t *>(p);
     p = take(4 * rows);                            if (w) w->q4 = reinterpret_cast<int32_t *>(p);
     p = take(4 * rows);                            if (w) w->q16 = reinterpret_cast<int32_t *>(p);
     p = take(32 * rows);                           if (w) w->recs = reinterpret_cast<RowRec *>(p);
-    p = take(32 * (rows / PLAN_THREADS + 2));      if (w) w->plan_totals = p;
+    p = take(64 * (rows / PLAN_THREADS + 2));      if (w) w->plan_totals = p;   // PlanTotals, <= 64 B each
     p = take(4 * chunk_cap);                       if (w) w->chunk_row = reinterpret_cast<int32_t *>(p);
     p = take(4 * chunk_cap * g->feat_stride);      if (w) w->partial = reinterpret_cast<float *>(p);
     p = take(4 * list_capacity);                   if (w) w->list = reinterpret_cast<int32_t *>(p);
-    p = take(g->max_degree > T4_CAP ? (int64_t)N_T16_BLOCKS * 3 * g->max_degree * 4 : 0);
+    p = take(g->max_degree > T4_CAP ? (int64_t)SEL_BLOCKS * 3 * g->max_degree * 4 : 0);
     if (w) {
         w->scratch = reinterpret_cast<uint32_t *>(p);
         w->list_capacity = list_capacity;
@@ -143,6 +143,37 @@ __device__ __forceinline__ RowRec row_plan(const ChooseArgs &a, int row) {
 // ---------------------------------------------------------------------------------------------
 // plan
 // ---------------------------------------------------------------------------------------------
+// the four tier counts of a thread / tile (each <= 4096) share one 64-bit word, 16 bits each: one scan
+__device__ __forceinline__ long long tier_word(int d) {
+    return d <= T0_CAP ? 1ll : d <= T1_CAP ? (1ll << 16) : d <= T4_CAP ? (1ll << 32) : (1ll << 48);
+}
+struct TierCounts {
+    int n0, n1, n4, n16;
+};
+__device__ __forceinline__ TierCounts tier_unpack(long long w) {
+    TierCounts t;
+    t.n0 = (int)(w & 0xFFFF);
+    t.n1 = (int)((w >> 16) & 0xFFFF);
+    t.n4 = (int)((w >> 32) & 0xFFFF);
+    t.n16 = (int)((w >> 48) & 0xFFFF);
+    return t;
+}
+__device__ __forceinline__ void tier_push(const Workspace &w, int d, int row, TierCounts &o) {
+    if (d <= T0_CAP) w.q0[o.n0++] = row;
+    else if (d <= T1_CAP) w.q1[o.n1++] = row;
+    else if (d <= T4_CAP) w.q4[o.n4++] = row;
+    else w.q16[o.n16++] = row;
+}
+__device__ __forceinline__ void tier_finish(const Workspace &w, const TierCounts &t, bool overflow) {
+    w.counters[C_N0] = overflow ? 0 : t.n0;
+    w.counters[C_N1] = overflow ? 0 : t.n1;
+    w.counters[C_N4] = overflow ? 0 : t.n4;
+    w.counters[C_N16] = overflow ? 0 : t.n16;
+    w.counters[C_HEAD0] = 0;
+    w.counters[C_HEAD1] = 0;
+    w.counters[C_HEAD4] = 0;
+    w.counters[C_HEAD16] = 0;
+}
 // exclusive scan of one value per thread over the block; returns the block total through `total`
 template <typename T>
 __device__ __forceinline__ T block_excl_scan(T v, T *lds /* >= waves */, T &total) {
@@ -188,14 +219,16 @@ __global__ void __launch_bounds__(PLAN_THREADS) plan_kernel(const ChooseArgs a) 
 #define PLAN_STAMP(slot) do { if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)rows * 8 + (slot)] = wall_clock64(); } while (0)
     PLAN_STAMP(0);
     long long run_cap = 0;
-    int run_chunk = 0, run1 = 0, run4 = 0, run16 = 0;
+    int run_chunk = 0;
+    TierCounts run = {0, 0, 0, 0};
     bool overflow = false;
     for (int tile0 = 0; tile0 < rows; tile0 += PLAN_THREADS * PLAN_PER) {
         const int r0 = tile0 + threadIdx.x * PLAN_PER;
         RowRec rec[PLAN_PER];
         int cap[PLAN_PER];
         long long cap_sum = 0;
-        int chunk_sum = 0, n1 = 0, n4 = 0, n16 = 0;
+        int chunk_sum = 0;
+        long long tiers = 0;
         // the dependent loads of the 4 rows are issued level by level, not row by row
         int nodev[PLAN_PER], labv[PLAN_PER], rel[PLAN_PER], bidx[PLAN_PER];
         long long s0v[PLAN_PER], s1v[PLAN_PER];
@@ -237,22 +270,20 @@ __global__ void __launch_bounds__(PLAN_THREADS) plan_kernel(const ChooseArgs a) 
                 cap[i] = (p.keep_all ? p.d : p.k) + p.m + (a.add_self ? 1 : 0);
                 cap_sum += cap[i];
                 chunk_sum += (cap[i] + CHUNK - 1) / CHUNK;
-                n1 += p.d <= T1_CAP;
-                n4 += p.d > T1_CAP && p.d <= T4_CAP;
-                n16 += p.d > T4_CAP;
+                tiers += tier_word(p.d);
             }
         }
         PLAN_STAMP(1);
-        // three scans instead of five: the tier counts (each <= 4 per thread, <= 4096 per tile) share one word
+        // three scans: the tier counts (each <= 4 per thread, <= 4096 per tile) share one word
         long long t_cap, t_tiers;
         int t_chunk;
         long long o_cap = run_cap + block_excl_scan<long long>(cap_sum, lds64, t_cap);
         int o_chunk = run_chunk + block_excl_scan(chunk_sum, lds, t_chunk);
-        const long long packed = (long long)n1 | ((long long)n4 << 20) | ((long long)n16 << 40);
-        const long long o_t = block_excl_scan<long long>(packed, lds64, t_tiers);
-        int o1 = run1 + (int)(o_t & 0xFFFFF), o4 = run4 + (int)((o_t >> 20) & 0xFFFFF), o16 = run16 + (int)(o_t >> 40);
-        const int t1 = (int)(t_tiers & 0xFFFFF), t4 = (int)((t_tiers >> 20) & 0xFFFFF), t16 = (int)(t_tiers >> 40);
-        run_cap += t_cap; run_chunk += t_chunk; run1 += t1; run4 += t4; run16 += t16;
+        TierCounts o = tier_unpack(block_excl_scan<long long>(tiers, lds64, t_tiers));
+        o.n0 += run.n0; o.n1 += run.n1; o.n4 += run.n4; o.n16 += run.n16;
+        const TierCounts tt = tier_unpack(t_tiers);
+        run_cap += t_cap; run_chunk += t_chunk;
+        run.n0 += tt.n0; run.n1 += tt.n1; run.n4 += tt.n4; run.n16 += tt.n16;
         overflow = overflow || run_cap > a.w.list_capacity || (long long)run_chunk > a.w.chunk_cap;
         PLAN_STAMP(2);
 #pragma unroll
@@ -265,9 +296,7 @@ __global__ void __launch_bounds__(PLAN_THREADS) plan_kernel(const ChooseArgs a) 
             a.w.recs[row] = rec[i];
             if (!overflow) {
                 for (int j = 0; j < nch; ++j) a.w.chunk_row[o_chunk + j] = row;
-                if (rec[i].d <= T1_CAP) a.w.q1[o1++] = row;
-                else if (rec[i].d <= T4_CAP) a.w.q4[o4++] = row;
-                else a.w.q16[o16++] = row;
+                tier_push(a.w, rec[i].d, row, o);
             }
             o_cap += cap[i];
             o_chunk += nch;
@@ -277,11 +306,7 @@ __global__ void __launch_bounds__(PLAN_THREADS) plan_kernel(const ChooseArgs a) 
     if (threadIdx.x == 0) {
         a.w.row_begin[rows] = run_cap;
         a.w.chunk_begin[rows] = run_chunk;
-        a.w.counters[C_N1] = overflow ? 0 : run1;
-        a.w.counters[C_N4] = overflow ? 0 : run4;
-        a.w.counters[C_N16] = overflow ? 0 : run16;
-        a.w.counters[C_HEAD4] = 0;
-        a.w.counters[C_HEAD16] = 0;
+        tier_finish(a.w, run, overflow);
         a.w.counters[C_NCHUNK] = overflow ? 0 : run_chunk;
         if (overflow && a.status) atomicOr(a.status, (uint32_t)PCG_ST_SEL_OVERFLOW);
     }
@@ -293,9 +318,10 @@ __global__ void __launch_bounds__(PLAN_THREADS) plan_kernel(const ChooseArgs a) 
 //                own rows and writes offsets / queues / chunk table exactly as the single-block kernel does
 struct PlanTotals {
     long long cap;
-    int chunk, n1, n4, n16;
+    int chunk, n0, n1, n4, n16;
     int pad[3];
 };
+static_assert(sizeof(PlanTotals) <= 64, "the workspace carve reserves 64 bytes per plan block");
 
 __device__ __forceinline__ int row_cap(const RowRec &p, int add_self) {
     return (p.keep_all ? p.d : p.k) + p.m + (add_self ? 1 : 0);
@@ -308,7 +334,8 @@ __global__ void __launch_bounds__(PLAN_THREADS) plan_count(const ChooseArgs a, P
     const int rows = a.g.n_rel * a.B;
     const int r0 = (blockIdx.x * PLAN_THREADS + threadIdx.x) * PER;
     long long cap_sum = 0;
-    int chunk_sum = 0, n1 = 0, n4 = 0, n16 = 0;
+    int chunk_sum = 0;
+    long long tiers = 0;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int row = r0 + i;
@@ -318,23 +345,21 @@ __global__ void __launch_bounds__(PLAN_THREADS) plan_count(const ChooseArgs a, P
             const int cap = row_cap(p, a.add_self);
             cap_sum += cap;
             chunk_sum += (cap + CHUNK - 1) / CHUNK;
-            n1 += p.d <= T1_CAP;
-            n4 += p.d > T1_CAP && p.d <= T4_CAP;
-            n16 += p.d > T4_CAP;
+            tiers += tier_word(p.d);
         }
     }
     long long t_cap, t_tiers;
     int t_chunk;
     block_excl_scan<long long>(cap_sum, lds64, t_cap);
     block_excl_scan(chunk_sum, lds, t_chunk);
-    block_excl_scan<long long>((long long)n1 | ((long long)n4 << 20) | ((long long)n16 << 40), lds64, t_tiers);
+    block_excl_scan<long long>(tiers, lds64, t_tiers);
     if (threadIdx.x == 0) {
+        const TierCounts tt = tier_unpack(t_tiers);
         PlanTotals t;
         t.cap = t_cap;
         t.chunk = t_chunk;
-        t.n1 = (int)(t_tiers & 0xFFFFF);
-        t.n4 = (int)((t_tiers >> 20) & 0xFFFFF);
-        t.n16 = (int)(t_tiers >> 40);
+        t.n0 = tt.n0; t.n1 = tt.n1; t.n4 = tt.n4; t.n16 = tt.n16;
+        t.pad[0] = t.pad[1] = t.pad[2] = 0;
         totals[blockIdx.x] = t;
     }
 }
@@ -345,20 +370,24 @@ __global__ void __launch_bounds__(PLAN_THREADS) plan_write(const ChooseArgs a, c
     __shared__ long long lds64[PLAN_THREADS / PCG_WAVE];
     const int rows = a.g.n_rel * a.B;
     long long run_cap = 0, all_cap = 0;
-    int run_chunk = 0, run1 = 0, run4 = 0, run16 = 0, all_chunk = 0, all1 = 0, all4 = 0, all16 = 0;
-    for (int bk = 0; bk < (int)gridDim.x; ++bk) {       // gridDim.x is small (rows / 4096)
+    int run_chunk = 0, all_chunk = 0;
+    TierCounts run = {0, 0, 0, 0}, all = {0, 0, 0, 0};
+    for (int bk = 0; bk < (int)gridDim.x; ++bk) {       // gridDim.x is small (rows / 1024)
         const PlanTotals t = totals[bk];
         if (bk < (int)blockIdx.x) {
-            run_cap += t.cap; run_chunk += t.chunk; run1 += t.n1; run4 += t.n4; run16 += t.n16;
+            run_cap += t.cap; run_chunk += t.chunk;
+            run.n0 += t.n0; run.n1 += t.n1; run.n4 += t.n4; run.n16 += t.n16;
         }
-        all_cap += t.cap; all_chunk += t.chunk; all1 += t.n1; all4 += t.n4; all16 += t.n16;
+        all_cap += t.cap; all_chunk += t.chunk;
+        all.n0 += t.n0; all.n1 += t.n1; all.n4 += t.n4; all.n16 += t.n16;
     }
     const bool overflow = all_cap > a.w.list_capacity || (long long)all_chunk > a.w.chunk_cap;
     const int r0 = (blockIdx.x * PLAN_THREADS + threadIdx.x) * PER;
     RowRec rec[PER];
     int cap[PER];
     long long cap_sum = 0;
-    int chunk_sum = 0, n1 = 0, n4 = 0, n16 = 0;
+    int chunk_sum = 0;
+    long long tiers = 0;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int row = r0 + i;
@@ -368,17 +397,15 @@ __global__ void __launch_bounds__(PLAN_THREADS) plan_write(const ChooseArgs a, c
             cap[i] = row_cap(rec[i], a.add_self);
             cap_sum += cap[i];
             chunk_sum += (cap[i] + CHUNK - 1) / CHUNK;
-            n1 += rec[i].d <= T1_CAP;
-            n4 += rec[i].d > T1_CAP && rec[i].d <= T4_CAP;
-            n16 += rec[i].d > T4_CAP;
+            tiers += tier_word(rec[i].d);
         }
     }
     long long t_cap, t_tiers;
     int t_chunk;
     long long o_cap = run_cap + block_excl_scan<long long>(cap_sum, lds64, t_cap);
     int o_chunk = run_chunk + block_excl_scan(chunk_sum, lds, t_chunk);
-    const long long o_t = block_excl_scan<long long>((long long)n1 | ((long long)n4 << 20) | ((long long)n16 << 40), lds64, t_tiers);
-    int o1 = run1 + (int)(o_t & 0xFFFFF), o4 = run4 + (int)((o_t >> 20) & 0xFFFFF), o16 = run16 + (int)(o_t >> 40);
+    TierCounts o = tier_unpack(block_excl_scan<long long>(tiers, lds64, t_tiers));
+    o.n0 += run.n0; o.n1 += run.n1; o.n4 += run.n4; o.n16 += run.n16;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int row = r0 + i;
@@ -388,9 +415,7 @@ __global__ void __launch_bounds__(PLAN_THREADS) plan_write(const ChooseArgs a, c
         a.w.chunk_begin[row] = o_chunk;
         if (!overflow) {
             for (int j = 0; j < nch; ++j) a.w.chunk_row[o_chunk + j] = row;
-            if (rec[i].d <= T1_CAP) a.w.q1[o1++] = row;
-            else if (rec[i].d <= T4_CAP) a.w.q4[o4++] = row;
-            else a.w.q16[o16++] = row;
+            tier_push(a.w, rec[i].d, row, o);
         }
         o_cap += cap[i];
         o_chunk += nch;
@@ -398,11 +423,7 @@ __global__ void __launch_bounds__(PLAN_THREADS) plan_write(const ChooseArgs a, c
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         a.w.row_begin[rows] = all_cap;
         a.w.chunk_begin[rows] = all_chunk;
-        a.w.counters[C_N1] = overflow ? 0 : all1;
-        a.w.counters[C_N4] = overflow ? 0 : all4;
-        a.w.counters[C_N16] = overflow ? 0 : all16;
-        a.w.counters[C_HEAD4] = 0;
-        a.w.counters[C_HEAD16] = 0;
+        tier_finish(a.w, all, overflow);
         a.w.counters[C_NCHUNK] = overflow ? 0 : all_chunk;
         if (overflow && a.status) atomicOr(a.status, (uint32_t)PCG_ST_SEL_OVERFLOW);
     }
@@ -941,55 +962,49 @@ __device__ __forceinline__ void select_row(const ChooseArgs &a, int row, uint32_
     PCG_STAMP(6);
 }
 
-// tier 1: one wave per row, 4 rows per block
-__global__ void __launch_bounds__(T1_WAVES_PER_BLOCK *PCG_WAVE) select_t1(const ChooseArgs a) {
-    __shared__ uint32_t keys[T1_WAVES_PER_BLOCK][T1_CAP];
-    __shared__ uint32_t ids[T1_WAVES_PER_BLOCK][T1_CAP];
-    __shared__ uint32_t cand[T1_WAVES_PER_BLOCK][PCG_WAVE];
-    const int w = threadIdx.x >> 6;
-    const uint32_t qi = blockIdx.x * T1_WAVES_PER_BLOCK + w;
-    if (qi >= a.w.counters[C_N1]) return;
-    const int row = __builtin_amdgcn_readfirstlane(a.w.q1[qi]);     // one row per wave: make it scalar
-    // no compaction buffer in this tier (rows <= 512: later passes just re-filter the keys): 17 KB of LDS
-    // per block instead of 25 KB => 8 row-waves more per CU
-    select_row<1>(a, row, keys[w], ids[w], nullptr, cand[w], nullptr);
-}
-
-// tiers 4 / 16: one workgroup per row, rows pulled from the tier's queue
-// MID: the mid-degree queue (T1_CAP < deg <= T4_CAP) instead of the hub queue
-template <int NW, int CAP, bool MID>
-__global__ void __launch_bounds__(NW *PCG_WAVE) select_wide(const ChooseArgs a) {
+// One persistent launch selects every row of the batch, longest rows first:
+//   1. hub rows (deg > 4096): the whole 8-wave workgroup per row; keys + ids in LDS up to 6144 neighbours with the
+//      first-pass survivors in global scratch, everything in this workgroup's scratch beyond that
+//   2. mid rows (512 < deg <= 4096): the whole workgroup per row, keys + ids + survivors in LDS
+//   3. rows of 129..512, then rows of <= 128 neighbours: one wave per row
+// Every workgroup walks the four queues in this order, so the long poles start first and the short rows fill in
+// behind them on whatever wave slots are free - without the cross-stream fork / join this used to take (inside a
+// captured step the branches cost more than they overlapped: 0.43 -> 0.36 ms per step on the 2 M-node graph).
+__global__ void __launch_bounds__(SEL_NW *PCG_WAVE) __attribute__((amdgpu_waves_per_eu(6, 8))) select_rows(const ChooseArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
-    uint32_t *keys_lds = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *ids_lds = keys_lds + CAP;
-    uint32_t *ckeys_lds = ids_lds + CAP;                 // mid tier only
-    uint32_t *cand = MID ? ckeys_lds + CAP : ids_lds + CAP;
-    int *red = reinterpret_cast<int *>(cand + PCG_WAVE);
-    int *qslot = red + 2 * NW + 2;
-    const int32_t *queue = MID ? a.w.q4 : a.w.q16;
-    const uint32_t nq = a.w.counters[MID ? C_N4 : C_N16];
-    uint32_t *head = &a.w.counters[MID ? C_HEAD4 : C_HEAD16];
-    for (;;) {
-        if (threadIdx.x == 0) *qslot = (int)atomicAdd(head, 1u);
-        __syncthreads();
-        const uint32_t qi = (uint32_t)*qslot;
-        __syncthreads();
-        if (qi >= nq) break;
-        const int row = __builtin_amdgcn_readfirstlane(queue[qi]);  // one row per workgroup: scalar
-        if constexpr (MID) {
-            select_row<NW>(a, row, keys_lds, ids_lds, ckeys_lds, cand, red);
+    uint32_t *lds = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *cand = lds + SEL_LDS_WORDS;                        // [SEL_NW][64]
+    int *red = reinterpret_cast<int *>(cand + SEL_NW * PCG_WAVE);
+    const int wave = threadIdx.x >> 6;
+    // Rows are assigned statically - a queue head bumped by every wave is thousands of same-address device-scope
+    // atomics from 8 XCDs, which serialise at the memory side (measured: 590 us instead of 60).
+    // wide rows: the virtual queue [hub rows | mid rows], strided over the workgroups from the first one on
+    const int n16 = (int)a.w.counters[C_N16], n4 = (int)a.w.counters[C_N4];
+    const size_t md = (size_t)a.g.max_degree;
+    uint32_t *gk = a.w.scratch + (size_t)blockIdx.x * 3 * md;     // only touched when hub rows exist (then it is allocated)
+    for (int j = (int)blockIdx.x; j < n16 + n4; j += SEL_BLOCKS) {
+        if (j < n16) {
+            const int row = __builtin_amdgcn_readfirstlane(a.w.q16[j]);     // one row per workgroup: scalar
+            if (a.w.recs[row].d > HUB_LDS_CAP) select_row<SEL_NW>(a, row, gk, gk + md, gk + 2 * md, cand, red);
+            else select_row<SEL_NW>(a, row, lds, lds + HUB_LDS_CAP, gk + 2 * md, cand, red);
         } else {
-            uint32_t *gk = a.w.scratch + (size_t)blockIdx.x * 3 * a.g.max_degree;
-            if (a.w.recs[row].d > CAP)   // over-long hub row: ids + keys in global scratch too
-                select_row<NW>(a, row, gk, gk + a.g.max_degree, gk + 2 * (size_t)a.g.max_degree, cand, red);
-            else                          // ids + keys in LDS, the first-pass survivors in global scratch
-                select_row<NW>(a, row, keys_lds, ids_lds, gk + 2 * (size_t)a.g.max_degree, cand, red);
+            const int row = __builtin_amdgcn_readfirstlane(a.w.q4[j - n16]);
+            select_row<SEL_NW>(a, row, lds, lds + T4_CAP, lds + 2 * T4_CAP, cand, red);
         }
+    }
+    // single-wave rows: the virtual queue [129..512 | <= 128], strided over the waves from the LAST workgroup on, so that
+    // with few wide rows the workgroups holding those are not the ones holding short rows too.
+    // No compaction buffer here (rows <= 512: later passes just re-filter the keys).
+    const int n1 = (int)a.w.counters[C_N1], n0 = (int)a.w.counters[C_N0];
+    uint32_t *wk = lds + wave * (2 * T1_CAP);
+    for (int j = (SEL_BLOCKS - 1 - (int)blockIdx.x) * SEL_NW + wave; j < n1 + n0; j += SEL_BLOCKS * SEL_NW) {
+        const int row = __builtin_amdgcn_readfirstlane(j < n1 ? a.w.q1[j] : a.w.q0[j - n1]);
+        select_row<1>(a, row, wk, wk + T1_CAP, nullptr, cand + wave * PCG_WAVE, nullptr);
     }
 }
 
-static size_t wide_smem_bytes(int nw, int cap, bool mid) {
-    return sizeof(uint32_t) * ((mid ? 3 : 2) * cap + PCG_WAVE) + sizeof(int) * (2 * nw + 2 + 2);
+static size_t select_smem_bytes() {
+    return sizeof(uint32_t) * (SEL_LDS_WORDS + SEL_NW * PCG_WAVE) + sizeof(int) * (2 * SEL_NW + 2);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1142,30 +1157,6 @@ __global__ void __launch_bounds__(256) combine_rows(const AggArgs a) {
     store_row<NACC>(a.agg + (size_t)row * a.agg_stride, acc, q, a.feat_dim, den);
 }
 
-// The three tier kernels are independent once plan has run: the two wide tiers are forked
-// onto auxiliary streams (joined back before the gather), so the step's critical path is the
-// slowest tier, not their sum.  The fork/join is a cross-stream dependency pattern that
-// stream capture turns into parallel graph branches.  One process drives one GPU, so the
-// auxiliary streams / events are process-wide and created on first use.
-struct Fork {
-    hipStream_t aux[2];
-    hipEvent_t fork, join[2];
-    bool ok = false;
-};
-static Fork &fork_state() {
-    static Fork f;
-    if (!f.ok) {
-        bool good = true;
-        for (int i = 0; i < 2; ++i) {
-            good = good && hipStreamCreateWithFlags(&f.aux[i], hipStreamNonBlocking) == hipSuccess;
-            good = good && hipEventCreateWithFlags(&f.join[i], hipEventDisableTiming) == hipSuccess;
-        }
-        good = good && hipEventCreateWithFlags(&f.fork, hipEventDisableTiming) == hipSuccess;
-        f.ok = good;
-    }
-    return f;
-}
-
 static int launch_select(const ChooseArgs &a, hipStream_t st) {
     const pcg_graph_desc &g = a.g;
     const int rows = g.n_rel * a.B;
@@ -1180,51 +1171,8 @@ static int launch_select(const ChooseArgs &a, hipStream_t st) {
         hipLaunchKernelGGL(plan_write<1>, dim3(nb), dim3(PLAN_THREADS), 0, st, a, tot);
         PCG_LAUNCH_CHECK();
     }
-    const bool wide16 = g.max_degree > T4_CAP, wide4 = g.max_degree > T1_CAP;
-    Fork &f = fork_state();
-    if (!f.ok) return PCG_E_LAUNCH;
-    // Hub rows are the long pole and need most of a CU's LDS: they go first, on the caller's stream, so they
-    // start without the fork latency and before tier-1 blocks have filled every CU.  The mid tier and tier 1
-    // are forked (with one tier only there is nothing to overlap and no fork).
-    const int t1_blocks = (rows + T1_WAVES_PER_BLOCK - 1) / T1_WAVES_PER_BLOCK;
-    if (!wide4) {
-        hipLaunchKernelGGL(select_t1, dim3(t1_blocks), dim3(T1_WAVES_PER_BLOCK * PCG_WAVE), 0, st, a);
-        PCG_LAUNCH_CHECK();
-        return PCG_OK;
-    }
-    if (hipEventRecord(f.fork, st) != hipSuccess) return PCG_E_LAUNCH;
-    if (wide16) {
-        const size_t smem = wide_smem_bytes(16, T16_CAP, false);
-        static bool attr16 = false;
-        if (!attr16) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(select_wide<16, T16_CAP, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-                return PCG_E_LAUNCH;
-            attr16 = true;
-        }
-        const int nb = rows < N_T16_BLOCKS ? rows : N_T16_BLOCKS;
-        hipLaunchKernelGGL((select_wide<16, T16_CAP, false>), dim3(nb), dim3(16 * PCG_WAVE), smem, st, a);
-        PCG_LAUNCH_CHECK();
-    }
-    {   // mid tier on aux[1]
-        const size_t smem = wide_smem_bytes(MID_NW, T4_CAP, true);
-        if (hipStreamWaitEvent(f.aux[1], f.fork, 0) != hipSuccess) return PCG_E_LAUNCH;
-        const int nb = rows < N_T4_BLOCKS ? rows : N_T4_BLOCKS;
-        hipLaunchKernelGGL((select_wide<MID_NW, T4_CAP, true>), dim3(nb), dim3(MID_NW * PCG_WAVE), smem, f.aux[1], a);
-        PCG_LAUNCH_CHECK();
-        if (hipEventRecord(f.join[1], f.aux[1]) != hipSuccess) return PCG_E_LAUNCH;
-    }
-    if (wide16) {   // tier 1 on aux[0] (beside the hub tier)
-        if (hipStreamWaitEvent(f.aux[0], f.fork, 0) != hipSuccess) return PCG_E_LAUNCH;
-        hipLaunchKernelGGL(select_t1, dim3(t1_blocks), dim3(T1_WAVES_PER_BLOCK * PCG_WAVE), 0, f.aux[0], a);
-        PCG_LAUNCH_CHECK();
-        if (hipEventRecord(f.join[0], f.aux[0]) != hipSuccess) return PCG_E_LAUNCH;
-        if (hipStreamWaitEvent(st, f.join[0], 0) != hipSuccess) return PCG_E_LAUNCH;
-    } else {        // no hub rows: tier 1 stays on the caller's stream
-        hipLaunchKernelGGL(select_t1, dim3(t1_blocks), dim3(T1_WAVES_PER_BLOCK * PCG_WAVE), 0, st, a);
-        PCG_LAUNCH_CHECK();
-    }
-    if (hipStreamWaitEvent(st, f.join[1], 0) != hipSuccess) return PCG_E_LAUNCH;
+    hipLaunchKernelGGL(select_rows, dim3(SEL_BLOCKS), dim3(SEL_NW * PCG_WAVE), select_smem_bytes(), st, a);
+    PCG_LAUNCH_CHECK();
     return PCG_OK;
 }
 
