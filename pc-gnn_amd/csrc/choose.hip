@@ -30,11 +30,11 @@ namespace pcg {
 constexpr int T0_CAP = 128;      // short rows: one wave per row, taken last
 constexpr int T1_CAP = 512;      // row length handled by a single wave (keys + ids: 4 KB of LDS)
 constexpr int T4_CAP = 4096;     // ... by a whole 8-wave workgroup with keys, ids and first-pass survivors in LDS (48 KB)
-constexpr int HUB_LDS_CAP = 6144;  // hub row whose keys + ids still fit the 48 KB (survivors in global scratch); longer: all in scratch
+constexpr int HUB_LDS_CAP = 6144;  // hub row whose keys + first-pass survivors fit the 48 KB (ids re-read from the CSR)
 constexpr int SEL_NW = 8;        // waves per select workgroup
 constexpr int SEL_BLOCKS = 768;  // persistent select workgroups: 3 per CU
 constexpr int SEL_LDS_WORDS = 3 * T4_CAP;
-constexpr int CHUNK = 256;       // list entries per gather work item
+constexpr int CHUNK = 128;       // list entries per gather work item
 constexpr int UNROLL = 8;        // row-gather instructions in flight per wave
 constexpr int KEY_UNROLL = 4;    // neighbour-score gathers in flight per lane
 constexpr int PLAN_THREADS = 1024;
@@ -62,7 +62,7 @@ struct Workspace {
     int32_t *chunk_row;    // [chunk_cap]
     float *partial;        // [chunk_cap, feat_stride]
     int32_t *list;         // [list_capacity]  chosen ids; -1 = hole
-    uint32_t *scratch;     // [SEL_BLOCKS * 3 * max_degree] when hub rows exist (max_degree > T4_CAP)
+    uint32_t *scratch;     // [SEL_BLOCKS * 2 * max_degree] when rows beyond the LDS tiers exist (max_degree > HUB_LDS_CAP)
     int64_t list_capacity, chunk_cap;
 };
 
@@ -91,7 +91,7 @@ static int64_t carve(const pcg_graph_desc *g, int32_t B, int64_t list_capacity, 
     p = take(4 * chunk_cap);                       if (w) w->chunk_row = reinterpret_cast<int32_t *>(p);
     p = take(4 * chunk_cap * g->feat_stride);      if (w) w->partial = reinterpret_cast<float *>(p);
     p = take(4 * list_capacity);                   if (w) w->list = reinterpret_cast<int32_t *>(p);
-    p = take(g->max_degree > T4_CAP ? (int64_t)SEL_BLOCKS * 3 * g->max_degree * 4 : 0);
+    p = take(g->max_degree > HUB_LDS_CAP ? (int64_t)SEL_BLOCKS * 2 * g->max_degree * 4 : 0);
     if (w) {
         w->scratch = reinterpret_cast<uint32_t *>(p);
         w->list_capacity = list_capacity;
@@ -561,39 +561,24 @@ __device__ __forceinline__ uint32_t wave_order_stat(uint32_t v, bool valid, int 
 }
 
 // One counting pass over cur[0..n): c1 = #keys in [lo, p1), c2 = #keys in [lo, p2) (p1 <= p2 <= hi+1);
-// if `mid` is given, the keys in [p1, p2) are also copied there (any order) - the survivors if the
-// wanted rank falls between the pivots.  cnts: 3 LDS ints (NW > 1).
+// mid_wave = this wave's share of the keys in [p1, p2).  cnts: 2 LDS ints (NW > 1).
 template <int NW>
 __device__ __forceinline__ void count_pass(const uint32_t *cur, int n, uint32_t lo, uint32_t hi, uint32_t p1,
-                                           uint32_t p2, uint32_t *mid, int wave, int lane, int *cnts, int &c1,
-                                           int &c2) {
+                                           uint32_t p2, int wave, int lane, int *cnts, int &c1, int &c2, int &mid_wave) {
     constexpr int NT = NW * PCG_WAVE;
     if constexpr (NW > 1) {
-        if (threadIdx.x < 3) cnts[threadIdx.x] = 0;
+        if (threadIdx.x < 2) cnts[threadIdx.x] = 0;
         __syncthreads();
     }
-    int a1 = 0, a2 = 0, nm = 0;
+    int a1 = 0, a2 = 0;
     for (int base = wave * PCG_WAVE; base < n; base += NT) {   // wave-uniform trip count
         const int i = base + lane;
         const uint32_t key = i < n ? cur[i] : 0xFFFFFFFFu;
         const bool in = i < n && key >= lo && key <= hi;
-        const bool b1 = in && key < p1, b2 = in && key < p2;
-        a1 += wave_count(b1);
-        const uint64_t m2 = __ballot(b2);
-        a2 += __popcll(m2);
-        if (mid) {
-            const uint64_t mm = __ballot(b2 && !b1);
-            const int c = __popcll(mm);
-            int at = nm;
-            if constexpr (NW > 1) {
-                int o = 0;
-                if (lane == 0 && c) o = atomicAdd(&cnts[2], c);
-                at = __builtin_amdgcn_readfirstlane(o);
-            }
-            if (b2 && !b1) mid[at + __popcll(mm & lanemask_lt())] = key;
-            nm += c;
-        }
+        a1 += wave_count(in && key < p1);
+        a2 += wave_count(in && key < p2);
     }
+    mid_wave = a2 - a1;
     if constexpr (NW == 1) {
         c1 = a1;
         c2 = a2;
@@ -609,13 +594,35 @@ __device__ __forceinline__ void count_pass(const uint32_t *cur, int n, uint32_t 
     }
 }
 
+// Copies the keys of cur[0..n) that lie in [lo, hi] to dst (wave by wave, in order); `mine` = how many of them this
+// wave's iterations hold (count_pass's mid_wave for the same bracket).  One scan instead of an atomic per iteration.
+template <int NW>
+__device__ __forceinline__ void compact_range(const uint32_t *cur, int n, uint32_t lo, uint32_t hi, uint32_t *dst,
+                                              int mine, int wave, int lane, int *red) {
+    constexpr int NT = NW * PCG_WAVE;
+    int run, tot;
+    grp_scan<NW>(mine, wave, lane, red, run, tot);
+    for (int base = wave * PCG_WAVE; base < n; base += NT) {
+        const int i = base + lane;
+        const uint32_t key = i < n ? cur[i] : 0xFFFFFFFFu;
+        const bool b = i < n && key >= lo && key <= hi;
+        const uint64_t mm = __ballot(b);
+        if (b) dst[run + __popcll(mm & lanemask_lt())] = key;
+        run += __popcll(mm);
+    }
+    grp_sync<NW>();
+}
+
 // ---------------------------------------------------------------------------
 // One (relation, centre) row: choose; write the row's region of the list.
 // ---------------------------------------------------------------------------
-// keys: >= deg uint32, distance keys, later the kept ids (compacted, ascending); ids: >= deg, the row's
-// neighbour ids; ckeys: >= deg, survivors of the first counting pass; cand: 64; red: 2*NW+2 ints (NW > 1).  All LDS, except keys/ids of an over-long hub row
-// (global scratch) - a separate instantiation, so that the LDS ones compile to ds_* instructions.
-template <int NW>
+// keys: >= deg uint32 distance keys (one wave: later the kept ids, compacted in place); ids: >= deg, the row's neighbour
+// ids; ckeys: >= deg, survivors of the first bracketing pass, later the kept ids of a workgroup row (null for one wave);
+// cand: 64; red: 2*NW+2 ints (NW > 1).  LDS or, for over-long hub rows, global scratch - separate instantiations, so that
+// the LDS ones compile to ds_* instructions.
+// CSR_IDS: the neighbour ids are not staged (ids unused) but read again from the CSR row when the kept ones are
+// compacted - for hub rows, where the LDS is better spent on keys and survivors and the re-read is coalesced and L2-hot.
+template <int NW, bool CSR_IDS = false>
 __device__ __forceinline__ void select_row(const ChooseArgs &a, int row, uint32_t *keys, uint32_t *ids, uint32_t *ckeys,
                                            uint32_t *cand, int *red) {
     const int lane = lane_id();
@@ -648,7 +655,7 @@ __device__ __forceinline__ void select_row(const ChooseArgs &a, int row, uint32_
         for (int u = 0; u < KEY_UNROLL; ++u) {
             const int i = base + u * NT;
             if (i < d) {
-                ids[i] = id[u];
+                if constexpr (!CSR_IDS) ids[i] = id[u];
                 if (!keep_all) {
                     const uint32_t key = dist_key(c, sc[u]);
                     keys[i] = key;
@@ -703,8 +710,8 @@ __device__ __forceinline__ void select_row(const ChooseArgs &a, int row, uint32_
                 if (p2 < p1) p2 = p1;
             }
             const bool first = cur == keys && ckeys != nullptr;
-            int c1, c2;
-            count_pass<NW>(cur, n_cur, lo, hi, p1, p2, first ? ckeys : nullptr, wave, lane, red, c1, c2);
+            int c1, c2, mid_wave;
+            count_pass<NW>(cur, n_cur, lo, hi, p1, p2, wave, lane, red, c1, c2, mid_wave);
             if (below + c1 >= k) {              // k-th < p1
                 hi = p1 - 1;
                 ncand = c1;
@@ -713,7 +720,8 @@ __device__ __forceinline__ void select_row(const ChooseArgs &a, int row, uint32_
                 hi = p2 - 1;
                 below += c1;
                 ncand = c2 - c1;
-                if (first) {                    // the survivors were compacted on the way: later passes are short
+                if (first) {                    // compact the survivors: later passes are short
+                    compact_range<NW>(cur, n_cur, lo, hi, ckeys, mid_wave, wave, lane, red);
                     cur = ckeys;
                     n_cur = ncand;
                 }
@@ -731,29 +739,31 @@ __device__ __forceinline__ void select_row(const ChooseArgs &a, int row, uint32_
             n_equal = ncand;
         } else {
             // <= 64 survivors: one per lane, ranked in-wave
-            if constexpr (NW > 1) {
+            constexpr bool coop = NW > 1;
+            uint32_t *cd = cand;
+            if (coop) {
                 if (threadIdx.x == 0) red[2] = 0;
                 __syncthreads();
             }
             int seen = 0;
-            for (int base = wave * PCG_WAVE; base < n_cur; base += NT) {
+            for (int base = coop ? wave * PCG_WAVE : 0; base < n_cur; base += coop ? NT : PCG_WAVE) {
                 const int i = base + lane;
                 const uint32_t key = i < n_cur ? cur[i] : 0u;
                 const bool isc = i < n_cur && key >= lo && key <= hi;
                 const uint64_t bm = __ballot(isc);
                 const int cn = __popcll(bm);
                 int at = seen;
-                if constexpr (NW > 1) {
+                if (coop) {
                     int o = 0;
                     if (lane == 0 && cn) o = atomicAdd(&red[2], cn);
                     at = __builtin_amdgcn_readfirstlane(o);
                 }
-                if (isc) cand[at + __popcll(bm & lanemask_lt())] = key;
+                if (isc) cd[at + __popcll(bm & lanemask_lt())] = key;
                 seen += cn;
             }
-            grp_sync<NW>();
+            if (coop) __syncthreads();
             const bool have = lane < ncand;
-            const uint32_t ck = have ? cand[lane] : 0xFFFFFFFFu;
+            const uint32_t ck = have ? cd[lane] : 0xFFFFFFFFu;
             // MSB-first bisection on one register per lane, from the first bit in which lo and hi differ
             int remaining = k - below, nc = ncand;
             int bit = 31 - __clz((int)(lo ^ hi));
@@ -777,19 +787,22 @@ __device__ __forceinline__ void select_row(const ChooseArgs &a, int row, uint32_
     }
 
     PCG_STAMP(2);
-    // ---- 3. compaction of kept ids, ascending, into keys[] --------------------------
+    // ---- 3. compaction of kept ids, ascending: in place into keys[] (one wave), into ckeys[] (workgroup: the
+    //         survivors are dead by now, and a separate target lets every wave own a contiguous stretch of the row) ---
+    uint32_t *selbuf = (NW > 1) ? ckeys : keys;
+    auto nbr_id = [&](int i) { return CSR_IDS ? (uint32_t)nbr[i] : ids[i]; };
     int ns = 0;
+    const bool ranked_ties = n_equal != need;   // some, not all, of the equal keys are kept
     if (keep_all) {
         ns = d;
-        for (int i = tid; i < d; i += NT) keys[i] = ids[i];
-    } else {
-        const bool ranked_ties = n_equal != need;   // some, not all, of the equal keys are kept
+        for (int i = tid; i < d; i += NT) selbuf[i] = nbr_id(i);
+    } else if (NW == 1 || ranked_ties) {
         int ties_seen = 0;
         for (int base = 0; base < d; base += NT) {
             const int i = base + tid;
             const bool in = i < d;
             const uint32_t key = in ? keys[i] : 0u;
-            const uint32_t id = in ? ids[i] : 0u;
+            const uint32_t id = in ? nbr_id(i) : 0u;
             bool sel = in && key <= kstar;
             if (ranked_ties) {
                 const bool tie = in && key == kstar;
@@ -802,13 +815,33 @@ __device__ __forceinline__ void select_row(const ChooseArgs &a, int row, uint32_
             }
             const uint64_t sm = __ballot(sel);
             int spre, stot;
-            grp_scan<NW>(__popcll(sm), wave, lane, red, spre, stot);   // its barriers order the reads above before the writes below
-            if (sel) keys[ns + spre + __popcll(sm & lanemask_lt())] = id;
+            grp_scan<NW>(__popcll(sm), wave, lane, red, spre, stot);
+            if (sel) selbuf[ns + spre + __popcll(sm & lanemask_lt())] = id;   // one wave, in place: slot <= i, read above
             ns += stot;
+        }
+    } else {
+        // every key <= kstar is kept: count per contiguous stretch, one scan, then write - 2 barriers per row
+        const int seg = (((d + NW - 1) / NW) + PCG_WAVE - 1) & ~(PCG_WAVE - 1);
+        const int b0 = wave * seg;
+        const int e0 = b0 + seg < d ? b0 + seg : d;
+        int mine = 0;
+        for (int i0 = b0; i0 < e0; i0 += PCG_WAVE) {
+            const int i = i0 + lane;
+            mine += wave_count(i < e0 && keys[i] <= kstar);
+        }
+        int run;
+        grp_scan<NW>(mine, wave, lane, red, run, ns);
+        for (int i0 = b0; i0 < e0; i0 += PCG_WAVE) {
+            const int i = i0 + lane;
+            const bool sel = i < e0 && keys[i] <= kstar;
+            const uint32_t id = i < e0 ? nbr_id(i) : 0u;
+            const uint64_t sm = __ballot(sel);
+            if (sel) selbuf[run + __popcll(sm & lanemask_lt())] = id;
+            run += __popcll(sm);
         }
     }
     grp_sync<NW>();
-    const uint32_t *sel = keys;
+    const uint32_t *sel = selbuf;
     PCG_STAMP(3);
     // (the kept ids are written to the list at the very end: vmcnt orders loads behind older stores, and the
     //  minority search below is a chain of dependent loads that must not queue behind ~ns stores to fresh lines)
@@ -963,8 +996,9 @@ __device__ __forceinline__ void select_row(const ChooseArgs &a, int row, uint32_
 }
 
 // One persistent launch selects every row of the batch, longest rows first:
-//   1. hub rows (deg > 4096): the whole 8-wave workgroup per row; keys + ids in LDS up to 6144 neighbours with the
-//      first-pass survivors in global scratch, everything in this workgroup's scratch beyond that
+//   1. hub rows (deg > 4096): the whole 8-wave workgroup per row, neighbour ids re-read from the CSR row; up to 6144
+//      neighbours keys + first-pass survivors in LDS, up to 12288 keys in LDS and survivors in this workgroup's global
+//      scratch, everything in scratch beyond that
 //   2. mid rows (512 < deg <= 4096): the whole workgroup per row, keys + ids + survivors in LDS
 //   3. rows of 129..512, then rows of <= 128 neighbours: one wave per row
 // Every workgroup walks the four queues in this order, so the long poles start first and the short rows fill in
@@ -981,12 +1015,14 @@ __global__ void __launch_bounds__(SEL_NW *PCG_WAVE) __attribute__((amdgpu_waves_
     // wide rows: the virtual queue [hub rows | mid rows], strided over the workgroups from the first one on
     const int n16 = (int)a.w.counters[C_N16], n4 = (int)a.w.counters[C_N4];
     const size_t md = (size_t)a.g.max_degree;
-    uint32_t *gk = a.w.scratch + (size_t)blockIdx.x * 3 * md;     // only touched when hub rows exist (then it is allocated)
+    uint32_t *gk = a.w.scratch + (size_t)blockIdx.x * 2 * md;     // only touched when hub rows exist (then it is allocated)
     for (int j = (int)blockIdx.x; j < n16 + n4; j += SEL_BLOCKS) {
         if (j < n16) {
             const int row = __builtin_amdgcn_readfirstlane(a.w.q16[j]);     // one row per workgroup: scalar
-            if (a.w.recs[row].d > HUB_LDS_CAP) select_row<SEL_NW>(a, row, gk, gk + md, gk + 2 * md, cand, red);
-            else select_row<SEL_NW>(a, row, lds, lds + HUB_LDS_CAP, gk + 2 * md, cand, red);
+            const int d = a.w.recs[row].d;
+            if (d <= HUB_LDS_CAP) select_row<SEL_NW, true>(a, row, lds, nullptr, lds + HUB_LDS_CAP, cand, red);       // keys + survivors in LDS
+            else if (d <= SEL_LDS_WORDS) select_row<SEL_NW, true>(a, row, lds, nullptr, gk, cand, red);            // keys in LDS
+            else select_row<SEL_NW, true>(a, row, gk, nullptr, gk + md, cand, red);                                // all in scratch
         } else {
             const int row = __builtin_amdgcn_readfirstlane(a.w.q4[j - n16]);
             select_row<SEL_NW>(a, row, lds, lds + T4_CAP, lds + 2 * T4_CAP, cand, red);
