@@ -144,6 +144,28 @@ int pcg_choose_aggregate(const pcg_graph_desc *g, const int32_t *nodes, const in
                          int32_t norm, int32_t add_self, float *agg, int32_t agg_stride, int32_t *cnt,
                          void *workspace, int64_t list_capacity, uint32_t *status, void *stream);
 
+/* The front of a training step in two launches instead of four.  Equivalent to
+ *   pcg_score_table(g, W, b, 0, n_nodes, s0);  pcg_pos_sort(g, s0, pos_keys)  [if train_flag and n_pos > 0];
+ *   + the plan (row records, list offsets, tier queues, chunk table) that pcg_choose_select / pcg_choose_aggregate
+ *     would compute first for this (nodes, labels, B, thresholds, rho, train_flag, add_self, workspace, list_capacity)
+ * with the plan's two passes riding along the score pass and the sort (it needs neither's result; both leave most
+ * CUs idle at dataset scale).  Follow it with pcg_choose_aggregate_planned / pcg_choose_select_planned, which take the
+ * arguments of their namesakes - the same values as given here - and skip the plan.  Results are bit-identical to the
+ * separate calls.  Replaces src/layers.py:230-243 (scores) + :683-688 (sort) + the per-batch bookkeeping of :246-262. */
+int pcg_step_front(const pcg_graph_desc *g, const float *W, const float *b, float *s0, uint64_t *pos_keys,
+                   const int32_t *nodes, const int32_t *labels, int32_t B, const double *thresholds,
+                   const double *rho, int32_t train_flag, int32_t add_self, void *workspace, int64_t list_capacity,
+                   uint32_t *status, void *stream);
+int pcg_choose_select_planned(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B,
+                              const float *s0, const float *center_s0, const uint64_t *pos_keys,
+                              const double *thresholds, const double *rho, int32_t train_flag, int32_t add_self,
+                              int32_t *cnt, void *workspace, int64_t list_capacity, uint32_t *status, void *stream);
+int pcg_choose_aggregate_planned(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B,
+                                 const float *s0, const float *center_s0, const uint64_t *pos_keys,
+                                 const double *thresholds, const double *rho, int32_t train_flag,
+                                 int32_t norm, int32_t add_self, float *agg, int32_t agg_stride, int32_t *cnt,
+                                 void *workspace, int64_t list_capacity, uint32_t *status, void *stream);
+
 /* diagnostic only: per-row phase timestamps of the select kernels ([rows][8] uint64, 10-ns ticks); NULL = off */
 void pcg_debug_set_stamps(void *ptr);
 void pcg_debug_set_dense_stamps(void *ptr);   /* [tiles][16] uint64 per dense_step tile */

@@ -50,6 +50,12 @@ PROTOTYPES = {
     "pcg_aggregate_lists": (C.c_int, [_P, _I32, _I32, _I32, _P, _G, _I32, _P, _I64, _I32, _P, _I32, _P]),
     "pcg_choose_aggregate": (C.c_int, [_G, _P, _P, _I32, _P, _P, _P, C.POINTER(_F64), C.POINTER(_F64), _I32, _I32,
                                        _I32, _P, _I32, _P, _P, _I64, _P, _P]),
+    "pcg_step_front": (C.c_int, [_G, _P, _P, _P, _P, _P, _P, _I32, C.POINTER(_F64), C.POINTER(_F64), _I32, _I32, _P, _I64,
+                                 _P, _P]),
+    "pcg_choose_select_planned": (C.c_int, [_G, _P, _P, _I32, _P, _P, _P, C.POINTER(_F64), C.POINTER(_F64), _I32, _I32,
+                                            _P, _P, _I64, _P, _P]),
+    "pcg_choose_aggregate_planned": (C.c_int, [_G, _P, _P, _I32, _P, _P, _P, C.POINTER(_F64), C.POINTER(_F64), _I32, _I32,
+                                               _I32, _P, _I32, _P, _P, _I64, _P, _P]),
     "pcg_debug_set_stamps": (None, [_P]),
     "pcg_debug_set_dense_stamps": (None, [_P]),
     "pcg_sel_capacity_row": (_I64, [_I64, _F64, _F64, _I32, _I32, _I32]),

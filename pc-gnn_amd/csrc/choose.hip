@@ -47,8 +47,8 @@ enum { C_N1 = 0, C_N4 = 1, C_N16 = 2, C_HEAD4 = 3, C_HEAD16 = 4, C_NCHUNK = 5, C
 struct RowRec {            // 32 bytes, written by plan, read by select (one 32-B load instead of a 3-deep chain)
     int64_t start;         // offset of the row in indices[r]
     int32_t node, d, k, m;
-    float c;               // the centre's class-0 logit
     int32_t keep_all;
+    int32_t pad;
 };
 
 struct Workspace {
@@ -87,7 +87,7 @@ static int64_t carve(const pcg_graph_desc *g, int32_t B, int64_t list_capacity, 
     p = take(4 * rows);                            if (w) w->q4 = reinterpret_cast<int32_t *>(p);
     p = take(4 * rows);                            if (w) w->q16 = reinterpret_cast<int32_t *>(p);
     p = take(32 * rows);                           if (w) w->recs = reinterpret_cast<RowRec *>(p);
-    p = take(64 * (rows / PLAN_THREADS + 2));      if (w) w->plan_totals = p;   // PlanTotals, <= 64 B each
+    p = take(64 * (rows / 256 + 2));               if (w) w->plan_totals = p;   // PlanTotals (<= 64 B) per 256 rows
     p = take(4 * chunk_cap);                       if (w) w->chunk_row = reinterpret_cast<int32_t *>(p);
     p = take(4 * chunk_cap * g->feat_stride);      if (w) w->partial = reinterpret_cast<float *>(p);
     p = take(4 * list_capacity);                   if (w) w->list = reinterpret_cast<int32_t *>(p);
@@ -136,7 +136,7 @@ __device__ __forceinline__ RowRec row_plan(const ChooseArgs &a, int row) {
         if (p.m > a.g.n_pos) p.m = a.g.n_pos;
         if (p.m < 0) p.m = 0;
     }
-    p.c = a.center_s0 ? a.center_s0[b] : a.s0[p.node];
+    p.pad = 0;
     return p;
 }
 
@@ -213,8 +213,6 @@ __global__ void __launch_bounds__(PLAN_THREADS) plan_kernel(const ChooseArgs a) 
     // branch-free optional inputs
     const int32_t *lab_ptr = (a.train_flag && a.labels) ? a.labels : a.nodes;
     const int lab_on = (a.train_flag && a.labels) ? 1 : 0;
-    const float *c_ptr = a.center_s0 ? a.center_s0 : a.s0;
-    const bool c_by_batch = a.center_s0 != nullptr;
     const int rows = a.g.n_rel * a.B;
 #define PLAN_STAMP(slot) do { if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)rows * 8 + (slot)] = wall_clock64(); } while (0)
     PLAN_STAMP(0);
@@ -232,7 +230,6 @@ __global__ void __launch_bounds__(PLAN_THREADS) plan_kernel(const ChooseArgs a) 
         // the dependent loads of the 4 rows are issued level by level, not row by row
         int nodev[PLAN_PER], labv[PLAN_PER], rel[PLAN_PER], bidx[PLAN_PER];
         long long s0v[PLAN_PER], s1v[PLAN_PER];
-        float cv[PLAN_PER];
 #pragma unroll
         for (int i = 0; i < PLAN_PER; ++i) {
             const int row = r0 + i < rows ? r0 + i : rows - 1;
@@ -246,7 +243,6 @@ __global__ void __launch_bounds__(PLAN_THREADS) plan_kernel(const ChooseArgs a) 
             const int64_t *ip = t_indptr[rel[i]];
             s0v[i] = ip[nodev[i]];
             s1v[i] = ip[nodev[i] + 1];
-            cv[i] = c_ptr[c_by_batch ? bidx[i] : nodev[i]];
         }
 #pragma unroll
         for (int i = 0; i < PLAN_PER; ++i) {
@@ -265,7 +261,7 @@ __global__ void __launch_bounds__(PLAN_THREADS) plan_kernel(const ChooseArgs a) 
                     if (p.m > a.g.n_pos) p.m = a.g.n_pos;
                     if (p.m < 0) p.m = 0;
                 }
-                p.c = cv[i];
+                p.pad = 0;
                 rec[i] = p;
                 cap[i] = (p.keep_all ? p.d : p.k) + p.m + (a.add_self ? 1 : 0);
                 cap_sum += cap[i];
@@ -327,26 +323,22 @@ __device__ __forceinline__ int row_cap(const RowRec &p, int add_self) {
     return (p.keep_all ? p.d : p.k) + p.m + (add_self ? 1 : 0);
 }
 
-template <int PER>
-__global__ void __launch_bounds__(PLAN_THREADS) plan_count(const ChooseArgs a, PlanTotals *totals) {
-    __shared__ int lds[PLAN_THREADS / PCG_WAVE];
-    __shared__ long long lds64[PLAN_THREADS / PCG_WAVE];
+// pass 1, workgroup `block` of THREADS threads, one row per thread
+template <int THREADS>
+__device__ __forceinline__ void plan_count_body(const ChooseArgs &a, PlanTotals *totals, int block) {
+    __shared__ int lds[THREADS / PCG_WAVE];
+    __shared__ long long lds64[THREADS / PCG_WAVE];
     const int rows = a.g.n_rel * a.B;
-    const int r0 = (blockIdx.x * PLAN_THREADS + threadIdx.x) * PER;
-    long long cap_sum = 0;
+    const int row = block * THREADS + (int)threadIdx.x;
+    long long cap_sum = 0, tiers = 0;
     int chunk_sum = 0;
-    long long tiers = 0;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int row = r0 + i;
-        if (row < rows) {
-            const RowRec p = row_plan(a, row);
-            a.w.recs[row] = p;
-            const int cap = row_cap(p, a.add_self);
-            cap_sum += cap;
-            chunk_sum += (cap + CHUNK - 1) / CHUNK;
-            tiers += tier_word(p.d);
-        }
+    if (row < rows) {
+        const RowRec p = row_plan(a, row);
+        a.w.recs[row] = p;
+        const int cap = row_cap(p, a.add_self);
+        cap_sum = cap;
+        chunk_sum = (cap + CHUNK - 1) / CHUNK;
+        tiers = tier_word(p.d);
     }
     long long t_cap, t_tiers;
     int t_chunk;
@@ -360,21 +352,24 @@ __global__ void __launch_bounds__(PLAN_THREADS) plan_count(const ChooseArgs a, P
         t.chunk = t_chunk;
         t.n0 = tt.n0; t.n1 = tt.n1; t.n4 = tt.n4; t.n16 = tt.n16;
         t.pad[0] = t.pad[1] = t.pad[2] = 0;
-        totals[blockIdx.x] = t;
+        totals[block] = t;
     }
 }
 
-template <int PER>
-__global__ void __launch_bounds__(PLAN_THREADS) plan_write(const ChooseArgs a, const PlanTotals *totals) {
-    __shared__ int lds[PLAN_THREADS / PCG_WAVE];
-    __shared__ long long lds64[PLAN_THREADS / PCG_WAVE];
+// pass 2, workgroup `block` of THREADS threads (one row per thread); pass 1 ran n_count_blocks workgroups of
+// COUNT_THREADS rows each (THREADS is a multiple of COUNT_THREADS)
+template <int THREADS, int COUNT_THREADS>
+__device__ __forceinline__ void plan_write_body(const ChooseArgs &a, const PlanTotals *totals, int block, int n_count_blocks) {
+    __shared__ int lds[THREADS / PCG_WAVE];
+    __shared__ long long lds64[THREADS / PCG_WAVE];
     const int rows = a.g.n_rel * a.B;
     long long run_cap = 0, all_cap = 0;
     int run_chunk = 0, all_chunk = 0;
     TierCounts run = {0, 0, 0, 0}, all = {0, 0, 0, 0};
-    for (int bk = 0; bk < (int)gridDim.x; ++bk) {       // gridDim.x is small (rows / 1024)
+    const int before = block * (THREADS / COUNT_THREADS);
+    for (int bk = 0; bk < n_count_blocks; ++bk) {       // a few dozen uniform loads
         const PlanTotals t = totals[bk];
-        if (bk < (int)blockIdx.x) {
+        if (bk < before) {
             run_cap += t.cap; run_chunk += t.chunk;
             run.n0 += t.n0; run.n1 += t.n1; run.n4 += t.n4; run.n16 += t.n16;
         }
@@ -382,51 +377,69 @@ __global__ void __launch_bounds__(PLAN_THREADS) plan_write(const ChooseArgs a, c
         all.n0 += t.n0; all.n1 += t.n1; all.n4 += t.n4; all.n16 += t.n16;
     }
     const bool overflow = all_cap > a.w.list_capacity || (long long)all_chunk > a.w.chunk_cap;
-    const int r0 = (blockIdx.x * PLAN_THREADS + threadIdx.x) * PER;
-    RowRec rec[PER];
-    int cap[PER];
-    long long cap_sum = 0;
-    int chunk_sum = 0;
-    long long tiers = 0;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int row = r0 + i;
-        cap[i] = 0;
-        if (row < rows) {
-            rec[i] = a.w.recs[row];
-            cap[i] = row_cap(rec[i], a.add_self);
-            cap_sum += cap[i];
-            chunk_sum += (cap[i] + CHUNK - 1) / CHUNK;
-            tiers += tier_word(rec[i].d);
-        }
+    const int row = block * THREADS + (int)threadIdx.x;
+    RowRec rec;
+    rec.d = 0;
+    int cap = 0;
+    if (row < rows) {
+        rec = a.w.recs[row];
+        cap = row_cap(rec, a.add_self);
     }
+    const int nch = (cap + CHUNK - 1) / CHUNK;
     long long t_cap, t_tiers;
     int t_chunk;
-    long long o_cap = run_cap + block_excl_scan<long long>(cap_sum, lds64, t_cap);
-    int o_chunk = run_chunk + block_excl_scan(chunk_sum, lds, t_chunk);
-    TierCounts o = tier_unpack(block_excl_scan<long long>(tiers, lds64, t_tiers));
+    const long long o_cap = run_cap + block_excl_scan<long long>((long long)cap, lds64, t_cap);
+    const int o_chunk = run_chunk + block_excl_scan(nch, lds, t_chunk);
+    TierCounts o = tier_unpack(block_excl_scan<long long>(row < rows ? tier_word(rec.d) : 0ll, lds64, t_tiers));
     o.n0 += run.n0; o.n1 += run.n1; o.n4 += run.n4; o.n16 += run.n16;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int row = r0 + i;
-        if (row >= rows) continue;
-        const int nch = (cap[i] + CHUNK - 1) / CHUNK;
+    if (row < rows) {
         a.w.row_begin[row] = o_cap;
         a.w.chunk_begin[row] = o_chunk;
         if (!overflow) {
             for (int j = 0; j < nch; ++j) a.w.chunk_row[o_chunk + j] = row;
-            tier_push(a.w, rec[i].d, row, o);
+            tier_push(a.w, rec.d, row, o);
         }
-        o_cap += cap[i];
-        o_chunk += nch;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (block == 0 && threadIdx.x == 0) {
         a.w.row_begin[rows] = all_cap;
         a.w.chunk_begin[rows] = all_chunk;
         tier_finish(a.w, all, overflow);
         a.w.counters[C_NCHUNK] = overflow ? 0 : all_chunk;
         if (overflow && a.status) atomicOr(a.status, (uint32_t)PCG_ST_SEL_OVERFLOW);
     }
+}
+
+__global__ void __launch_bounds__(PLAN_THREADS) plan_count(const ChooseArgs a, PlanTotals *totals) {
+    plan_count_body<PLAN_THREADS>(a, totals, (int)blockIdx.x);
+}
+__global__ void __launch_bounds__(PLAN_THREADS) plan_write(const ChooseArgs a, const PlanTotals *totals) {
+    plan_write_body<PLAN_THREADS, PLAN_THREADS>(a, totals, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// The front of a training step in two launches instead of four: the plan's two passes ride along the score pass
+// and the train-pos sort (both have idle CUs at dataset scale, and the plan needs neither's result):
+//   front_a: [plan pass 1 workgroups | score_table workgroups]          (256 threads)
+//   front_b: [plan pass 2 workgroups | rank-sort workgroups]            (1024 threads)
+constexpr int FRONT_COUNT_THREADS = 256;
+
+__global__ void __launch_bounds__(FRONT_COUNT_THREADS) front_a_kernel(const ChooseArgs a, PlanTotals *totals, int n_plan_blocks,
+                                                                      const float *__restrict__ W, const float *__restrict__ bias,
+                                                                      float *__restrict__ s0) {
+    if ((int)blockIdx.x < n_plan_blocks)
+        plan_count_body<FRONT_COUNT_THREADS>(a, totals, (int)blockIdx.x);
+    else
+        score_table_body(a.g.X, a.g.feat_dim, a.g.feat_stride, W, bias, 0, a.g.n_nodes, s0, (int)blockIdx.x - n_plan_blocks,
+                         (int)gridDim.x - n_plan_blocks);
+}
+
+__global__ void __launch_bounds__(PLAN_THREADS) front_b_kernel(const ChooseArgs a, const PlanTotals *totals, int n_write_blocks,
+                                                               int n_count_blocks, uint64_t *__restrict__ keys, int cap) {
+    __shared__ uint64_t sh[RANK_TILE];
+    __shared__ int part[RANK_WAVES * PCG_WAVE];
+    if ((int)blockIdx.x < n_write_blocks)
+        plan_write_body<PLAN_THREADS, FRONT_COUNT_THREADS>(a, totals, (int)blockIdx.x, n_count_blocks);
+    else
+        rank_sort_body(a.s0, a.g.train_pos, a.g.n_pos, cap, keys, (int)blockIdx.x - n_write_blocks, sh, part);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -636,7 +649,8 @@ __device__ __forceinline__ void select_row(const ChooseArgs &a, int row, uint32_
     const bool keep_all = p.keep_all != 0;
     const int r = row / a.B;
     const int32_t *__restrict__ nbr = a.g.indices[r] + p.start;
-    const float c = p.c;
+    // the centre's class-0 logit (not part of the plan record: the plan can then run before / beside the score pass)
+    const float c = a.center_s0 ? a.center_s0[row - r * a.B] : a.s0[node];
     int32_t *__restrict__ out = a.w.list + a.w.row_begin[row];
 
     // ---- 1. neighbour ids and distance keys -> LDS ----------------------------
@@ -1193,18 +1207,20 @@ __global__ void __launch_bounds__(256) combine_rows(const AggArgs a) {
     store_row<NACC>(a.agg + (size_t)row * a.agg_stride, acc, q, a.feat_dim, den);
 }
 
-static int launch_select(const ChooseArgs &a, hipStream_t st) {
+// planned: the plan is already in the workspace (pcg_step_front)
+static int launch_select(const ChooseArgs &a, hipStream_t st, bool planned = false) {
     const pcg_graph_desc &g = a.g;
     const int rows = g.n_rel * a.B;
-    if (rows <= PLAN_THREADS * PLAN_PER) {
+    if (planned) {
+    } else if (rows <= PLAN_THREADS * PLAN_PER) {
         hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(PLAN_THREADS), 0, st, a);
         PCG_LAUNCH_CHECK();
     } else {
         const int nb = (rows + PLAN_THREADS - 1) / PLAN_THREADS;       // one row per thread: spread over many CUs
         PlanTotals *tot = reinterpret_cast<PlanTotals *>(a.w.plan_totals);
-        hipLaunchKernelGGL(plan_count<1>, dim3(nb), dim3(PLAN_THREADS), 0, st, a, tot);
+        hipLaunchKernelGGL(plan_count, dim3(nb), dim3(PLAN_THREADS), 0, st, a, tot);
         PCG_LAUNCH_CHECK();
-        hipLaunchKernelGGL(plan_write<1>, dim3(nb), dim3(PLAN_THREADS), 0, st, a, tot);
+        hipLaunchKernelGGL(plan_write, dim3(nb), dim3(PLAN_THREADS), 0, st, a, tot);
         PCG_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(select_rows, dim3(SEL_BLOCKS), dim3(SEL_NW * PCG_WAVE), select_smem_bytes(), st, a);
@@ -1265,21 +1281,17 @@ int64_t pcg_sel_capacity_row(int64_t deg, double threshold, double rho, int32_t 
     return cap + (add_self ? 1 : 0);
 }
 
-int pcg_choose_select(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B, const float *s0,
-                      const float *center_s0, const uint64_t *pos_keys, const double *thresholds, const double *rho,
-                      int32_t train_flag, int32_t add_self, int32_t *cnt, void *workspace, int64_t list_capacity,
-                      uint32_t *status, void *stream) {
-    if (!g || B < 0) return PCG_E_ARG;
-    if (B == 0) return PCG_OK;  // empty trailing batch (model_handler.py:134 produces one): nothing to do
-    if (!nodes || !s0 || !thresholds || !cnt || !workspace || !status) return PCG_E_ARG;
+static int choose_args(pcg::ChooseArgs &a, const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B,
+                       const float *s0, const float *center_s0, const uint64_t *pos_keys, const double *thresholds,
+                       const double *rho, int32_t train_flag, int32_t add_self, int32_t *cnt, void *workspace,
+                       int64_t list_capacity, uint32_t *status) {
+    if (!nodes || !s0 || !thresholds || !workspace || !status) return PCG_E_ARG;
     if (list_capacity < 1 || list_capacity >= (1ll << 31)) return PCG_E_ARG;
     if (train_flag && !rho) return PCG_E_ARG;
     if (g->n_rel < 1 || g->n_rel > PCG_MAX_REL) return PCG_E_ARG;
     if (train_flag && (!labels || (g->n_pos > 0 && (!pos_keys || !g->train_pos)))) return PCG_E_ARG;
     for (int r = 0; r < g->n_rel; ++r)
         if (!g->indptr[r] || !g->indices[r]) return PCG_E_ARG;
-
-    pcg::ChooseArgs a;
     a.g = *g;
     a.nodes = nodes;
     a.labels = labels;
@@ -1295,7 +1307,74 @@ int pcg_choose_select(const pcg_graph_desc *g, const int32_t *nodes, const int32
     a.status = status;
     a.stamps = pcg::g_stamps;
     pcg::carve(g, B, list_capacity, static_cast<unsigned char *>(workspace), &a.w);
-    return pcg::launch_select(a, static_cast<hipStream_t>(stream));
+    return PCG_OK;
+}
+
+static int choose_select(bool planned, const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B,
+                         const float *s0, const float *center_s0, const uint64_t *pos_keys, const double *thresholds,
+                         const double *rho, int32_t train_flag, int32_t add_self, int32_t *cnt, void *workspace,
+                         int64_t list_capacity, uint32_t *status, void *stream) {
+    if (!g || B < 0) return PCG_E_ARG;
+    if (B == 0) return PCG_OK;  // empty trailing batch (model_handler.py:134 produces one): nothing to do
+    if (!cnt) return PCG_E_ARG;
+    pcg::ChooseArgs a;
+    const int rc = choose_args(a, g, nodes, labels, B, s0, center_s0, pos_keys, thresholds, rho, train_flag, add_self, cnt,
+                               workspace, list_capacity, status);
+    if (rc != PCG_OK) return rc;
+    return pcg::launch_select(a, static_cast<hipStream_t>(stream), planned);
+}
+
+int pcg_choose_select(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B, const float *s0,
+                      const float *center_s0, const uint64_t *pos_keys, const double *thresholds, const double *rho,
+                      int32_t train_flag, int32_t add_self, int32_t *cnt, void *workspace, int64_t list_capacity,
+                      uint32_t *status, void *stream) {
+    return choose_select(false, g, nodes, labels, B, s0, center_s0, pos_keys, thresholds, rho, train_flag, add_self, cnt,
+                         workspace, list_capacity, status, stream);
+}
+
+int pcg_choose_select_planned(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B,
+                              const float *s0, const float *center_s0, const uint64_t *pos_keys, const double *thresholds,
+                              const double *rho, int32_t train_flag, int32_t add_self, int32_t *cnt, void *workspace,
+                              int64_t list_capacity, uint32_t *status, void *stream) {
+    return choose_select(true, g, nodes, labels, B, s0, center_s0, pos_keys, thresholds, rho, train_flag, add_self, cnt,
+                         workspace, list_capacity, status, stream);
+}
+
+int pcg_step_front(const pcg_graph_desc *g, const float *W, const float *b, float *s0, uint64_t *pos_keys,
+                   const int32_t *nodes, const int32_t *labels, int32_t B, const double *thresholds, const double *rho,
+                   int32_t train_flag, int32_t add_self, void *workspace, int64_t list_capacity, uint32_t *status,
+                   void *stream) {
+    if (!g || !g->X || !W || !b || !s0 || B < 0) return PCG_E_ARG;
+    if (g->feat_dim < 1 || g->feat_stride < g->feat_dim || g->feat_stride % 4 != 0) return PCG_E_ARG;
+    if ((reinterpret_cast<uintptr_t>(g->X) & 15u) != 0) return PCG_E_ARG;
+    const bool sort = train_flag && g->n_pos > 0;
+    if (sort && (!pos_keys || !g->train_pos)) return PCG_E_ARG;
+    if (B == 0 || g->n_nodes == 0) {      // nothing to plan: the two stand-alone calls
+        int rc = pcg_score_table(g, W, b, 0, g->n_nodes, s0, stream);
+        if (rc == PCG_OK && sort) rc = pcg_pos_sort(g, s0, pos_keys, stream);
+        return rc;
+    }
+    pcg::ChooseArgs a;
+    const int rc = choose_args(a, g, nodes, labels, B, s0, nullptr, pos_keys, thresholds, rho, train_flag, add_self, nullptr,
+                               workspace, list_capacity, status);
+    if (rc != PCG_OK) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int rows = g->n_rel * B;
+    pcg::PlanTotals *tot = reinterpret_cast<pcg::PlanTotals *>(a.w.plan_totals);
+    const int n_count = (rows + pcg::FRONT_COUNT_THREADS - 1) / pcg::FRONT_COUNT_THREADS;
+    const int n_score = (int)pcg::score_table_blocks(g->n_nodes, g->feat_stride);
+    hipLaunchKernelGGL(pcg::front_a_kernel, dim3(n_count + n_score), dim3(pcg::FRONT_COUNT_THREADS), 0, st, a, tot, n_count, W, b,
+                       s0);
+    PCG_LAUNCH_CHECK();
+    const int n_write = (rows + pcg::PLAN_THREADS - 1) / pcg::PLAN_THREADS;
+    const bool rank = sort && g->n_pos <= pcg::RANK_MAX;
+    const int n_sort = rank ? (g->n_pos + PCG_WAVE - 1) / PCG_WAVE : 0;
+    const int64_t cap = sort ? pcg_pos_sort_capacity(g->n_pos) : 0;
+    hipLaunchKernelGGL(pcg::front_b_kernel, dim3(n_write + n_sort), dim3(pcg::PLAN_THREADS), 0, st, a, tot, n_write, n_count,
+                       pos_keys, (int)cap);
+    PCG_LAUNCH_CHECK();
+    if (sort && !rank) return pcg_pos_sort(g, s0, pos_keys, stream);    // many positives: the chunk sort's own launches
+    return PCG_OK;
 }
 
 int pcg_aggregate_lists(const float *X, int32_t feat_dim, int32_t feat_stride, int32_t n_rows, const int32_t *cnt,
@@ -1338,6 +1417,21 @@ int pcg_choose_aggregate(const pcg_graph_desc *g, const int32_t *nodes, const in
     if (!g->X || !agg) return PCG_E_ARG;
     const int rc = pcg_choose_select(g, nodes, labels, B, s0, center_s0, pos_keys, thresholds, rho, train_flag,
                                      add_self, cnt, workspace, list_capacity, status, stream);
+    if (rc != PCG_OK) return rc;
+    return pcg_aggregate_lists(g->X, g->feat_dim, g->feat_stride, g->n_rel * B, cnt, g, B, workspace, list_capacity,
+                               norm, agg, agg_stride, stream);
+}
+
+int pcg_choose_aggregate_planned(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B,
+                                 const float *s0, const float *center_s0, const uint64_t *pos_keys,
+                                 const double *thresholds, const double *rho, int32_t train_flag, int32_t norm,
+                                 int32_t add_self, float *agg, int32_t agg_stride, int32_t *cnt, void *workspace,
+                                 int64_t list_capacity, uint32_t *status, void *stream) {
+    if (!g || B < 0) return PCG_E_ARG;
+    if (B == 0) return PCG_OK;
+    if (!g->X || !agg) return PCG_E_ARG;
+    const int rc = pcg_choose_select_planned(g, nodes, labels, B, s0, center_s0, pos_keys, thresholds, rho, train_flag,
+                                             add_self, cnt, workspace, list_capacity, status, stream);
     if (rc != PCG_OK) return rc;
     return pcg_aggregate_lists(g->X, g->feat_dim, g->feat_stride, g->n_rel * B, cnt, g, B, workspace, list_capacity,
                                norm, agg, agg_stride, stream);

@@ -88,4 +88,98 @@ __device__ __forceinline__ float score_reduce(float p, int lpr) {
     return p;
 }
 
+// ---- bodies shared by the stand-alone kernels and the fused step-front kernels (same code => same bits) ----------
+
+constexpr int SCORE_UNROLL = 8;
+
+// class-0 logit of rows [row_begin, row_end): workgroup `block` of `n_blocks` (256 threads each), grid-stride
+__device__ __forceinline__ void score_table_body(const float *__restrict__ X, int feat_dim, int stride,
+                                                 const float *__restrict__ W, const float *__restrict__ bias,
+                                                 int64_t row_begin, int64_t row_end, float *__restrict__ s0, int block,
+                                                 int n_blocks) {
+    const int lane = lane_id();
+    const int lpr = lanes_per_row(stride);
+    const int rpw = PCG_WAVE / lpr;
+    const int slot = lane / lpr, sub = lane % lpr;
+    const int64_t wave_global = (int64_t)block * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)n_blocks * (blockDim.x >> 6);
+    const float b0 = bias[0];
+    const int64_t rows_per_iter = (int64_t)rpw * SCORE_UNROLL;
+    for (int64_t base = row_begin + wave_global * rows_per_iter; base < row_end; base += n_waves * rows_per_iter) {
+        float p[SCORE_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SCORE_UNROLL; ++u) {
+            const int64_t row = base + (int64_t)u * rpw + slot;
+            p[u] = row < row_end ? score_partial<true>(X + row * stride, W, feat_dim, stride, sub, lpr) : 0.f;
+        }
+        // after the butterfly every lane of a row-group holds that row's sum: lane `sub` keeps the result of
+        // unrolled row `sub`, so the wave writes its rpw * SCORE_UNROLL consecutive scores in ONE store
+        float mine = 0.f;
+#pragma unroll
+        for (int u = 0; u < SCORE_UNROLL; ++u) {
+            const float s = score_reduce(p[u], lpr);
+            if (sub == u) mine = s;
+        }
+        if (sub < SCORE_UNROLL) {
+            const int64_t row = base + (int64_t)sub * rpw + slot;
+            if (row < row_end) s0[row] = mine + b0;
+        }
+    }
+}
+
+// number of 256-thread workgroups score_table uses for n rows (8 per CU at most, grid-stride beyond)
+__host__ __forceinline__ int64_t score_table_blocks(int64_t n_rows, int stride) {
+    const int rpw = PCG_WAVE / lanes_per_row(stride);
+    const int64_t rows_per_block = (int64_t)4 * rpw * SCORE_UNROLL;
+    int64_t blocks = (n_rows + rows_per_block - 1) / rows_per_block;
+    return blocks > 256 * 8 ? 256 * 8 : blocks;
+}
+
+__device__ __forceinline__ uint64_t make_pos_key(const float *s0, const int32_t *train_pos, int i, int n_pos) {
+    if (i >= n_pos) return ~0ull;
+    return ((uint64_t)orderable(s0[train_pos[i]]) << 32) | (uint32_t)i;
+}
+
+// ---- rank sort of the train-pos keys: one launch, no step barriers (n_pos <= RANK_MAX) -------------------
+// Keys are unique, so rank(i) = #{j : key_j < key_i} is a permutation.  Every workgroup owns 64 keys
+// (one per lane), walks all keys in LDS tiles of RANK_TILE and splits each tile's j-range over its
+// 16 waves; LDS reads are wave-wide broadcasts.  O(P^2) compares, but embarrassingly parallel: it
+// beats the many-launch bitonic network up to a few 10^4 keys.
+constexpr int RANK_MAX = 16384;
+constexpr int RANK_TILE = 8192;
+constexpr int RANK_WAVES = 16;
+
+// sh: RANK_TILE uint64, part: RANK_WAVES * 64 ints (LDS); workgroup `block` of ceil(n_pos / 64), 1024 threads
+__device__ __forceinline__ void rank_sort_body(const float *__restrict__ s0, const int32_t *__restrict__ train_pos, int n_pos,
+                                               int cap, uint64_t *__restrict__ keys, int block, uint64_t *sh, int *part) {
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int i = block * PCG_WAVE + lane;
+    const uint64_t mine = make_pos_key(s0, train_pos, i, n_pos);          // ~0 when i >= n_pos
+    int c = 0;
+    for (int t0 = 0; t0 < n_pos; t0 += RANK_TILE) {
+        const int nt = (n_pos - t0 < RANK_TILE) ? n_pos - t0 : RANK_TILE;
+        __syncthreads();
+        for (int t = threadIdx.x; t < nt; t += blockDim.x) sh[t] = make_pos_key(s0, train_pos, t0 + t, n_pos);
+        __syncthreads();
+        const int chunk = (nt + RANK_WAVES - 1) / RANK_WAVES;
+        const int j0 = wave * chunk, j1 = (j0 + chunk < nt) ? j0 + chunk : nt;
+        int j = j0;
+        for (; j + 4 <= j1; j += 4) {
+            const uint64_t a0 = sh[j], a1 = sh[j + 1], a2 = sh[j + 2], a3 = sh[j + 3];
+            c += (a0 < mine) + (a1 < mine) + (a2 < mine) + (a3 < mine);
+        }
+        for (; j < j1; ++j) c += sh[j] < mine;
+    }
+    part[wave * PCG_WAVE + lane] = c;
+    __syncthreads();
+    if (wave == 0 && i < n_pos) {
+        int rank = 0;
+#pragma unroll
+        for (int w = 0; w < RANK_WAVES; ++w) rank += part[w * PCG_WAVE + lane];
+        keys[rank] = mine;
+    }
+    if (block == 0)
+        for (int t = n_pos + threadIdx.x; t < cap; t += blockDim.x) keys[t] = ~0ull;
+}
+
 }  // namespace pcg

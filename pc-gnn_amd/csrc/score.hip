@@ -6,39 +6,10 @@
 
 namespace pcg {
 
-constexpr int SCORE_UNROLL = 8;
-
 __global__ void __launch_bounds__(256) score_table_kernel(const float *__restrict__ X, int feat_dim, int stride,
                                                           const float *__restrict__ W, const float *__restrict__ bias,
                                                           int64_t row_begin, int64_t row_end, float *__restrict__ s0) {
-    const int lane = lane_id();
-    const int lpr = lanes_per_row(stride);
-    const int rpw = PCG_WAVE / lpr;
-    const int slot = lane / lpr, sub = lane % lpr;
-    const int64_t wave_global = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
-    const float b0 = bias[0];
-    const int64_t rows_per_iter = (int64_t)rpw * SCORE_UNROLL;
-    for (int64_t base = row_begin + wave_global * rows_per_iter; base < row_end; base += n_waves * rows_per_iter) {
-        float p[SCORE_UNROLL];
-#pragma unroll
-        for (int u = 0; u < SCORE_UNROLL; ++u) {
-            const int64_t row = base + (int64_t)u * rpw + slot;
-            p[u] = row < row_end ? score_partial<true>(X + row * stride, W, feat_dim, stride, sub, lpr) : 0.f;
-        }
-        // after the butterfly every lane of a row-group holds that row's sum: lane `sub` keeps the result of
-        // unrolled row `sub`, so the wave writes its rpw * SCORE_UNROLL consecutive scores in ONE store
-        float mine = 0.f;
-#pragma unroll
-        for (int u = 0; u < SCORE_UNROLL; ++u) {
-            const float s = score_reduce(p[u], lpr);
-            if (sub == u) mine = s;
-        }
-        if (sub < SCORE_UNROLL) {
-            const int64_t row = base + (int64_t)sub * rpw + slot;
-            if (row < row_end) s0[row] = mine + b0;
-        }
-    }
+    score_table_body(X, feat_dim, stride, W, bias, row_begin, row_end, s0, (int)blockIdx.x, (int)gridDim.x);
 }
 
 __global__ void __launch_bounds__(256) score_rows_kernel(const float *__restrict__ X, int feat_dim, int stride,
@@ -100,10 +71,7 @@ int pcg_score_table(const pcg_graph_desc *g, const float *W, const float *b, int
     if (pcg::check_graph_features(g) != PCG_OK || !W || !b || !s0) return PCG_E_ARG;
     if (row_begin < 0 || row_end > g->n_nodes || row_begin > row_end) return PCG_E_ARG;
     if (row_begin == row_end) return PCG_OK;
-    const int rpw = PCG_WAVE / pcg::lanes_per_row(g->feat_stride);
-    const int64_t rows_per_block = (int64_t)4 * rpw * pcg::SCORE_UNROLL;
-    int64_t blocks = (row_end - row_begin + rows_per_block - 1) / rows_per_block;
-    if (blocks > 256 * 8) blocks = 256 * 8;  // 8 blocks per CU, grid-stride the rest
+    const int64_t blocks = pcg::score_table_blocks(row_end - row_begin, g->feat_stride);
     hipLaunchKernelGGL(pcg::score_table_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
                        g->X, g->feat_dim, g->feat_stride, W, b, row_begin, row_end, s0);
     PCG_LAUNCH_CHECK();

@@ -11,11 +11,6 @@ namespace pcg {
 constexpr int SORT_CHUNK = 4096;    // keys sorted per workgroup in LDS (32 KiB)
 constexpr int SORT_THREADS = 1024;
 
-__device__ __forceinline__ uint64_t make_pos_key(const float *s0, const int32_t *train_pos, int i, int n_pos) {
-    if (i >= n_pos) return ~0ull;
-    return ((uint64_t)orderable(s0[train_pos[i]]) << 32) | (uint32_t)i;
-}
-
 __device__ __forceinline__ void cmp_swap(uint64_t &a, uint64_t &b, bool ascending) {
     if ((a > b) == ascending) {
         const uint64_t t = a;
@@ -48,48 +43,13 @@ __global__ void __launch_bounds__(SORT_THREADS) pos_sort_local(const float *__re
     for (int t = threadIdx.x; t < SORT_CHUNK; t += SORT_THREADS) keys[base + t] = sh[t];
 }
 
-// ---- rank sort: one launch, no step barriers (n_pos <= RANK_MAX) -------------------
-// Keys are unique, so rank(i) = #{j : key_j < key_i} is a permutation.  Every block owns 64 keys
-// (one per lane), walks all keys in LDS tiles of RANK_TILE and splits each tile's j-range over its
-// 16 waves; LDS reads are wave-wide broadcasts.  O(P^2) compares, but embarrassingly parallel: it
-// beats the many-launch bitonic network up to a few 10^4 keys.
-constexpr int RANK_MAX = 16384;
-constexpr int RANK_TILE = 8192;
-constexpr int RANK_WAVES = 16;
-
+// ---- rank sort (n_pos <= RANK_MAX): rank_sort_body in common.h, shared with the fused step-front kernel ----
 __global__ void __launch_bounds__(RANK_WAVES *PCG_WAVE) pos_rank_sort(const float *__restrict__ s0,
                                                                       const int32_t *__restrict__ train_pos,
                                                                       int n_pos, int cap, uint64_t *__restrict__ keys) {
     __shared__ uint64_t sh[RANK_TILE];
     __shared__ int part[RANK_WAVES * PCG_WAVE];
-    const int lane = lane_id(), wave = threadIdx.x >> 6;
-    const int i = blockIdx.x * PCG_WAVE + lane;
-    const uint64_t mine = make_pos_key(s0, train_pos, i, n_pos);          // ~0 when i >= n_pos
-    int c = 0;
-    for (int t0 = 0; t0 < n_pos; t0 += RANK_TILE) {
-        const int nt = (n_pos - t0 < RANK_TILE) ? n_pos - t0 : RANK_TILE;
-        __syncthreads();
-        for (int t = threadIdx.x; t < nt; t += blockDim.x) sh[t] = make_pos_key(s0, train_pos, t0 + t, n_pos);
-        __syncthreads();
-        const int chunk = (nt + RANK_WAVES - 1) / RANK_WAVES;
-        const int j0 = wave * chunk, j1 = (j0 + chunk < nt) ? j0 + chunk : nt;
-        int j = j0;
-        for (; j + 4 <= j1; j += 4) {
-            const uint64_t a0 = sh[j], a1 = sh[j + 1], a2 = sh[j + 2], a3 = sh[j + 3];
-            c += (a0 < mine) + (a1 < mine) + (a2 < mine) + (a3 < mine);
-        }
-        for (; j < j1; ++j) c += sh[j] < mine;
-    }
-    part[wave * PCG_WAVE + lane] = c;
-    __syncthreads();
-    if (wave == 0 && i < n_pos) {
-        int rank = 0;
-#pragma unroll
-        for (int w = 0; w < RANK_WAVES; ++w) rank += part[w * PCG_WAVE + lane];
-        keys[rank] = mine;
-    }
-    if (blockIdx.x == 0)
-        for (int t = n_pos + threadIdx.x; t < cap; t += blockDim.x) keys[t] = ~0ull;
+    rank_sort_body(s0, train_pos, n_pos, cap, keys, (int)blockIdx.x, sh, part);
 }
 
 // ---- large n_pos: every 4096-chunk sorted in LDS, then one "merge by ranks" pass ----------------------

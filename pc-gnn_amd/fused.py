@@ -95,7 +95,19 @@ class FusedPCGNN:
         ops.score_table(g, self.w_clf, self.b_clf, out=self.s0)
         return ops.pos_sort(g, self.s0, self.keys) if (train_flag and g.n_pos) else None
 
-    def _enqueue_choose(self, ids, labels, B, keys, train_flag):
+    def _ws(self, B):
+        ws = self._ws_by_b.get(B)
+        if ws is None:      # the workspace layout depends on the batch size: one per size
+            ws = self._ws_by_b[B] = ops.ChooseWorkspace(self.g, B)
+        return ws
+
+    def _enqueue_front(self, ids, labels, B, train_flag):
+        """scores + train-pos sort + this batch's plan in two launches (pcg_step_front)."""
+        g = self.g
+        return ops.step_front(g, self.w_clf, self.b_clf, self.s0, self.keys if (train_flag and g.n_pos) else None,
+                              ids, labels if train_flag else None, self.thresholds, self.rho, train_flag, self._ws(B))
+
+    def _enqueue_choose(self, ids, labels, B, keys, train_flag, planned=False):
         g = self.g
         agg = self.agg.view(-1)[:g.R * B * g.feat_dim].view(g.R, B, g.feat_dim)
         cnt = self.cnt.view(-1)[:g.R * B].view(g.R, B)
@@ -103,11 +115,8 @@ class FusedPCGNN:
         if timed:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        ws = self._ws_by_b.get(B)
-        if ws is None:      # the workspace layout depends on the batch size: one per size
-            ws = self._ws_by_b[B] = ops.ChooseWorkspace(g, B)
         ops.choose_aggregate(g, ids, labels if train_flag else None, self.s0, keys, self.thresholds, self.rho,
-                             train_flag, ws=ws, agg=agg, cnt=cnt)
+                             train_flag, ws=self._ws(B), agg=agg, cnt=cnt, planned=planned)
         if timed:
             ev[1].record()
             self._prof.append(ev)
@@ -115,9 +124,9 @@ class FusedPCGNN:
         return agg, cnt
 
     def _enqueue_sample(self, ids, labels, B, train_flag):
-        """score table, train-pos sort, choose + aggregate for one batch (views sized to B)."""
-        keys = self._enqueue_scores(train_flag)
-        return self._enqueue_choose(ids, labels, B, keys, train_flag)
+        """score table + train-pos sort + plan (two launches), then select + aggregate, for one batch (views sized to B)."""
+        keys = self._enqueue_front(ids, labels, B, train_flag)
+        return self._enqueue_choose(ids, labels, B, keys, train_flag, planned=True)
 
     def _enqueue_dense(self, ids, labels, B, agg, train: bool, combined=None):
         g = self.g
@@ -193,14 +202,14 @@ class FusedPCGNN:
         agg = self.agg.view(-1)[:g.R * B * g.feat_dim].view(g.R, B, g.feat_dim)
 
         def pre():
-            self._enqueue_scores(True)
+            self._enqueue_front(ids, lab, B, True)
 
         def post():
             self._enqueue_dense(ids, lab, B, agg, True)
             self._enqueue_adam(B, apply=True)
 
         def choose():
-            self._enqueue_choose(ids, lab, B, keys, True)
+            self._enqueue_choose(ids, lab, B, keys, True, planned=True)
 
         def full():
             pre()

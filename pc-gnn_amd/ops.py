@@ -152,8 +152,9 @@ def choose_aggregate(g: DeviceGraph, nodes: torch.Tensor, labels: Optional[torch
                      pos_keys: Optional[torch.Tensor], thresholds: Sequence[float], rho, train_flag: bool,
                      norm: int = _lib.PCG_NORM_COUNT, add_self: bool = False,
                      center_s0: Optional[torch.Tensor] = None, ws: Optional[ChooseWorkspace] = None,
-                     agg: Optional[torch.Tensor] = None, cnt: Optional[torch.Tensor] = None):
-    """choose + mean for all relations of a batch -> agg [R, B, F] (and |set| [R, B])."""
+                     agg: Optional[torch.Tensor] = None, cnt: Optional[torch.Tensor] = None, planned: bool = False):
+    """choose + mean for all relations of a batch -> agg [R, B, F] (and |set| [R, B]).
+    planned: ws already holds this batch's plan (step_front)."""
     lib = _lib.load()
     B = nodes.numel()
     if ws is None or ws.B != B:
@@ -163,11 +164,29 @@ def choose_aggregate(g: DeviceGraph, nodes: torch.Tensor, labels: Optional[torch
     if cnt is None:
         cnt = torch.empty(g.R, B, dtype=torch.int32, device=g.device)
     thr, rhos = _host_arrays(g, thresholds, rho)
-    _lib.check(lib.pcg_choose_aggregate(
+    fn = lib.pcg_choose_aggregate_planned if planned else lib.pcg_choose_aggregate
+    _lib.check(fn(
         g.desc_ref(), _p(nodes), _p(labels), B, _p(s0), _p(center_s0), _p(pos_keys), thr, rhos,
         1 if train_flag else 0, norm, 1 if add_self else 0, _p(agg), agg.stride(-2), _p(cnt),
         _p(ws.buf), ws.list_capacity, _p(ws.status), _stream(g.device)), "pcg_choose_aggregate")
     return agg, cnt
+
+
+def step_front(g: DeviceGraph, W: torch.Tensor, b: torch.Tensor, s0: torch.Tensor, pos_keys: Optional[torch.Tensor],
+               nodes: torch.Tensor, labels: Optional[torch.Tensor], thresholds: Sequence[float], rho, train_flag: bool,
+               ws: ChooseWorkspace, add_self: bool = False):
+    """score table + train-pos sort + the batch's plan in two launches (pcg_step_front); follow with
+    choose_aggregate(..., planned=True) on the same arguments.  Returns the sorted keys (or None)."""
+    lib = _lib.load()
+    B = nodes.numel()
+    assert ws.B == B
+    thr, rhos = _host_arrays(g, thresholds, rho)
+    sort = bool(train_flag) and g.n_pos > 0
+    _lib.check(lib.pcg_step_front(
+        g.desc_ref(), _p(W), _p(b), _p(s0), _p(pos_keys) if sort else None, _p(nodes), _p(labels), B, thr, rhos,
+        1 if train_flag else 0, 1 if add_self else 0, _p(ws.buf), ws.list_capacity, _p(ws.status),
+        _stream(g.device)), "pcg_step_front")
+    return pos_keys if sort else None
 
 
 def read_sets(g: DeviceGraph, B: int, ws: ChooseWorkspace):

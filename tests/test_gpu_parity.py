@@ -596,6 +596,57 @@ def test_large_batch_two_pass_plan(P):
     assert [sets[1][b] for b in probe] == want
 
 
+@pytest.mark.parametrize("B,train", [(23, True), (700, True), (5000, True), (300, False)])
+def test_step_front_equals_separate_calls(P, B, train):
+    """pcg_step_front (score pass + plan pass 1 | sort + plan pass 2) followed by the *_planned entry points gives
+    bit for bit what pcg_score_table + pcg_pos_sort + pcg_choose_aggregate give: scores, sorted keys, row offsets,
+    list entries, counts and aggregated rows."""
+    ops = P.ops
+    n = 30000
+    hub_degs = [13000, 7000, 5000, 600, 300, 100, 3, 1]
+    X, labels, csr = hub_graph(5, n, hub_degs)
+    _, _, csrs2 = synth_graph(43, n, 32, (4,), 0.1)
+    csrs = [csr, csrs2[0]]
+    train_pos = np.flatnonzero(labels == 1)[:1500].tolist()
+    g = P.DeviceGraph(X, csrs, train_pos, dev())
+    gen = torch.Generator().manual_seed(8)
+    W, b = torch.randn(2, 32, generator=gen).cuda(), torch.randn(2, generator=gen).cuda()
+    rs = np.random.RandomState(B)
+    nodes = np.concatenate([np.arange(len(hub_degs)), rs.randint(0, n, size=B - len(hub_degs))]).astype(np.int32)
+    ids = torch.from_numpy(nodes).cuda()
+    lab = torch.from_numpy(labels[nodes].astype(np.int32)).cuda() if train else None
+    thr, rho = [0.5, 0.7], [0.5, 1.5]
+    # separate calls
+    s0_a = ops.score_table(g, W, b)
+    keys_a = ops.pos_sort(g, s0_a) if train else None
+    ws_a = ops.ChooseWorkspace(g, B)
+    agg_a, cnt_a = ops.choose_aggregate(g, ids, lab, s0_a, keys_a, thr, rho, train, ws=ws_a)
+    # front + planned
+    s0_b = torch.full_like(s0_a, float("nan"))
+    keys_b = torch.zeros_like(keys_a) if train else None
+    ws_b = ops.ChooseWorkspace(g, B)
+    kb = ops.step_front(g, W, b, s0_b, keys_b, ids, lab, thr, rho, train, ws_b)
+    agg_b, cnt_b = ops.choose_aggregate(g, ids, lab, s0_b, kb, thr, rho, train, ws=ws_b, planned=True)
+    torch.cuda.synchronize()
+    ws_a.check(); ws_b.check()
+    assert torch.equal(s0_a, s0_b)
+    if train:
+        assert torch.equal(keys_a, keys_b)
+    assert torch.equal(cnt_a, cnt_b)
+    assert torch.equal(agg_a.view(torch.int32), agg_b.view(torch.int32))          # bitwise, NaN-safe
+    rows = g.R * B
+    begin_a, begin_b = ws_a.view(0, torch.int64, rows + 1), ws_b.view(0, torch.int64, rows + 1)
+    assert torch.equal(begin_a, begin_b)
+    total = int(begin_a[-1])
+    assert torch.equal(ws_a.view(1, torch.int32, rows), ws_b.view(1, torch.int32, rows))
+    assert torch.equal(ws_a.view(2, torch.int32, total), ws_b.view(2, torch.int32, total))
+    # an empty batch still refreshes scores and keys
+    s0_c = torch.zeros_like(s0_a)
+    empty = torch.zeros(0, dtype=torch.int32, device=dev())
+    ops.step_front(g, W, b, s0_c, keys_b, empty, empty if train else None, thr, rho, train, ops.ChooseWorkspace(g, 0))
+    assert torch.equal(s0_a, s0_c)
+
+
 def test_fused_trajectory_tracks_oracle(P, case):
     """Four consecutive Adam steps: the HIP path's loss trajectory and parameters follow the CPU oracle's
     (independent implementation: Python sets + torch.sort + dense-mask mean + torch autograd + torch Adam)."""
