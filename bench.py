@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--force-partitioned", action="store_true",
                     help="run the node-partitioned RCCL path even at world size 1 (rehearsal of the N>1 code)")
     ap.add_argument("--event-every", type=int, default=10,
-                    help="graph engine: bracket the choose+aggregate launch with HIP events on every Nth timed step")
+                    help="graph engine: bracket the select+aggregate launch with HIP events on every step of every Nth epoch")
     ap.add_argument("--engine", default=None, choices=["graph", "fused", "torch", "dp"],
                     help="graph: fused HIP step replayed from a hipGraph (default at 1 GPU); fused: same kernels "
                          "launched eagerly (default at N>1, gradient all-reduce in between); torch: torch dense tail")
@@ -93,7 +93,9 @@ def cpu_baseline(w, trainer, cfg, batches, n_batches):
     om = O.OraclePCGNN(torch.from_numpy(w.X), adj, w.train_pos, params, cfg["rho"], cfg["alpha"], dense_mask=True)
     opt = O.make_adam(om, cfg["lr"], cfg["weight_decay"])
     nodes, spent = 0, 0.0
-    for ids in batches[:n_batches]:
+    batches = batches[:n_batches]
+    n_batches = len(batches)
+    for ids in batches:
         t0 = time.perf_counter()
         O.train_step(om, opt, ids.tolist(), w.labels[ids])
         spent += time.perf_counter() - t0
@@ -223,9 +225,10 @@ def main():
 
     def next_batch():
         if state["ids"] is None or state["b"] == nb:
-            state["ids"] = tr.start_epoch(state["epoch"])      # pick + shuffle on the device
-            if epoch_graphs:
-                tr.fused.begin_epoch(state["ids"], tr.labels_i32[state["ids"].long()], B)
+            if epoch_graphs:     # pick + shuffle + labels in one launch, straight into the epoch's static buffers
+                state["ids"] = tr.start_epoch_staged()
+            else:
+                state["ids"] = tr.start_epoch(state["epoch"])      # pick + shuffle on the device
             state["epoch"] += 1
             state["b"] = 0
         b = state["b"]
@@ -238,29 +241,52 @@ def main():
         torch.cuda.synchronize(dev)
 
     warmup = args.warmup
-    if epoch_graphs:                       # every batch slot of an epoch has its own graph: capture them all untimed
-        warmup = max(warmup, nb + 2)
-    for _ in range(warmup):
-        one_step(next_batch())
+    if epoch_graphs:                       # capture every graph (per-slot and whole-epoch) untimed
+        warmup = max(warmup, 2 * nb + 2)
 
     inter = tr.model.inter1
     prof = tr.fused if tr.fused is not None else inter
-    prof._prof = []                                    # (start, end) HIP events around the choose+aggregate launch
-    used, used_ev = [], []
+    used_ev, counted = [], {"nodes": 0}
+
+    def run_steps(n_steps, measure):
+        """n_steps training steps.  Graph engine: the steps of every `event_every`-th epoch are replayed as
+        [front graph] -> event -> [select + aggregate graph] -> event -> [dense + Adam graph] (the same kernels in the
+        same order); every other epoch that fits into the remaining steps is ONE graph launch."""
+        k = 0
+        while k < n_steps:
+            at_epoch_start = state["ids"] is None or state["b"] == nb
+            timed_epoch = engine != "graph" or (state["epoch"] - (0 if at_epoch_start else 1)) % args.event_every == 0
+            if epoch_graphs and at_epoch_start and not timed_epoch and k + nb <= n_steps:
+                tr.run_epoch_one_graph()             # pick + shuffle + labels + every batch's step: one graph launch
+                state["ids"], state["b"] = tr.fused._ep_ids[:tr.pick_size], nb
+                state["epoch"] += 1
+                if measure:
+                    counted["nodes"] += tr.pick_size
+                k += nb
+                continue
+            ids = next_batch()
+            timed = timed_epoch             # (also during the warm-up, so that every graph is captured before the clock starts)
+            one_step(ids, timed)
+            if measure:
+                if timed:
+                    used_ev.append((ids.clone(), prof.last_counts.clone()))
+                counted["nodes"] += int(ids.numel())
+            k += 1
+
+    prof._prof = []
+    run_steps(warmup, False)
+    while epoch_graphs and state["b"] != nb:   # the warm-up may end mid-epoch; whole-epoch graphs start at an epoch boundary
+        one_step(next_batch())
+        warmup += 1
+    prof._prof = []                                    # (start, end) HIP events around the select + aggregate launch
     barrier()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        ids = next_batch()
-        timed = engine != "graph" or k % args.event_every == 0    # graph engine: events on every Nth step
-        one_step(ids, timed)
-        if timed:
-            used_ev.append((ids, prof.last_counts.clone()))
-        used.append(ids)
+    run_steps(args.steps, True)
     barrier()
     elapsed = time.perf_counter() - t0
     events, prof._prof = prof._prof, None
 
-    nodes_local = sum(int(i.numel()) for i in used)
+    nodes_local = counted["nodes"]
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     n = torch.tensor([nodes_local], dtype=torch.float64, device=dev)
     if dist is not None:
@@ -270,7 +296,7 @@ def main():
 
     if rank == 0:
         kern_ms = [a.elapsed_time(b) for a, b in events]
-        batches_host = [i.cpu().numpy().astype(np.int64) for i in used]
+        batches_host = [i.cpu().numpy().astype(np.int64) for i, _ in used_ev]   # the event-bracketed batches: the CPU sample
         abytes = [algorithmic_bytes(tr.graph, i.cpu().numpy().astype(np.int64), c.cpu().numpy()) for i, c in used_ev]
         avg_ms = float(np.mean(kern_ms))
         achieved = float(np.mean(abytes)) / (avg_ms * 1e-3) / 1e9

@@ -192,6 +192,16 @@ int pcg_segment_mean(const pcg_graph_desc *g, const int64_t *begin, const int32_
 int pcg_pick(const double *cum, const int32_t *idx_train, int32_t n_train,
              const double *uniforms, uint64_t seed, uint64_t epoch, int32_t k, int32_t *out, void *stream);
 
+/* One epoch's picks, shuffled, with their labels, in one launch: pick (src/utils.py:274-278) + random.shuffle
+ * (src/model_handler.py:131-133) + the label lookup of the batch loop (:147).  Draw i is pcg_pick's draw i of
+ * (seed, epoch); its output position is the rank of a second Philox word of the same counter among all k draws (a
+ * uniformly random permutation; equal words ordered by i).  epoch = epoch_base + (*epoch_counter if given); with bump != 0 a
+ * second, one-thread launch increments *epoch_counter afterwards, so a captured graph replays a new epoch each time.
+ * labels_all: int32 label of every node (or NULL with out_labels NULL).  k <= 131072. */
+int pcg_pick_shuffled(const double *cum, const int32_t *idx_train, int32_t n_train, uint64_t seed, uint64_t epoch_base,
+                      uint64_t *epoch_counter, int32_t bump, int32_t k, const int32_t *labels_all, int32_t *out_ids,
+                      int32_t *out_labels, void *stream);
+
 /* ---- dense tail: relation / inter GEMMs, classifier, loss, backward, Adam ---------------
  * Parameters live in ONE flat f32 buffer `theta` in this order (offsets from
  * pcg_dense_param_offset; shapes are the reference's state-dict shapes, row-major):

@@ -61,6 +61,7 @@ PROTOTYPES = {
     "pcg_sel_capacity_row": (_I64, [_I64, _F64, _F64, _I32, _I32, _I32]),
     "pcg_segment_mean": (C.c_int, [_G, _P, _P, _P, _I32, _I32, _P, _I32, _P]),
     "pcg_pick": (C.c_int, [_P, _P, _I32, _P, _U64, _U64, _I32, _P, _P]),
+    "pcg_pick_shuffled": (C.c_int, [_P, _P, _I32, _U64, _U64, _P, _I32, _I32, _P, _P, _P, _P]),
     "pcg_gather_rows": (C.c_int, [_G, _P, _I32, _P, _I32, _P]),
     "pcg_halo_classify": (C.c_int, [_P, _P, _I64, _I32, _I32, _I32, _P, _P, _P]),
     "pcg_halo_compact": (C.c_int, [_P, _P, _I32, _P, _P]),

@@ -95,13 +95,18 @@ __device__ __forceinline__ double philox_uniform(uint64_t seed, uint64_t epoch, 
     return ((double)(c[0] >> 5) * 67108864.0 + (double)(c[1] >> 6)) * (1.0 / 9007199254740992.0);
 }
 
-// out[i] = idx_train[bisect_right(cum, u * cum[n-1], 0, n-1)]   (random.choices, utils.py:278)
-__global__ void __launch_bounds__(256) pick_kernel(const double *__restrict__ cum, const int32_t *__restrict__ idx_train,
-                                                   int n, const double *__restrict__ uniforms, uint64_t seed,
-                                                   uint64_t epoch, int k, int32_t *__restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= k) return;
-    const double u = uniforms ? uniforms[i] : philox_uniform(seed, epoch, (uint32_t)i);
+// all four words of the Philox block of (seed, epoch, draw)
+__device__ __forceinline__ void philox_block(uint64_t seed, uint64_t epoch, uint32_t draw, uint32_t (&c)[4]) {
+    c[0] = draw; c[1] = 0u; c[2] = (uint32_t)epoch; c[3] = (uint32_t)(epoch >> 32);
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+
+__device__ __forceinline__ int32_t pick_draw(const double *__restrict__ cum, const int32_t *__restrict__ idx_train, int n, double u) {
     const double x = u * (cum[n - 1] + 0.0);
     int lo = 0, hi = n - 1;
     while (lo < hi) {
@@ -109,8 +114,69 @@ __global__ void __launch_bounds__(256) pick_kernel(const double *__restrict__ cu
         if (x < cum[mid]) hi = mid;
         else lo = mid + 1;
     }
-    out[i] = idx_train[lo];
+    return idx_train[lo];
 }
+
+// out[i] = idx_train[bisect_right(cum, u * cum[n-1], 0, n-1)]   (random.choices, utils.py:278)
+__global__ void __launch_bounds__(256) pick_kernel(const double *__restrict__ cum, const int32_t *__restrict__ idx_train,
+                                                   int n, const double *__restrict__ uniforms, uint64_t seed,
+                                                   uint64_t epoch, int k, int32_t *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    const double u = uniforms ? uniforms[i] : philox_uniform(seed, epoch, (uint32_t)i);
+    out[i] = pick_draw(cum, idx_train, n, u);
+}
+
+// An epoch's picks, shuffled, with their labels, in one launch (utils.py:274-278 + random.shuffle, model_handler.py:131-133).
+// Draw i is exactly pcg_pick's draw i of the same (seed, epoch).  Its place in the output is the rank of a shuffle key
+// (third Philox word of the same block, ties by i) among all k keys: a uniformly random permutation.  Every workgroup owns
+// 64 draws and ranks them against all k keys, recomputed into LDS tiles (rank sort as for the train positives).
+constexpr int SHUF_TILE = 8192;
+constexpr int SHUF_WAVES = 16;
+
+__device__ __forceinline__ uint64_t shuffle_key(uint64_t seed, uint64_t epoch, int i, int k) {
+    if (i >= k) return ~0ull;
+    uint32_t c[4];
+    philox_block(seed, epoch, (uint32_t)i, c);
+    return ((uint64_t)c[2] << 32) | (uint32_t)i;
+}
+
+__global__ void __launch_bounds__(SHUF_WAVES *PCG_WAVE) pick_shuffled_kernel(const double *__restrict__ cum, const int32_t *__restrict__ idx_train,
+                                                                             int n, uint64_t seed, uint64_t epoch_base,
+                                                                             const unsigned long long *__restrict__ epoch_counter, int k,
+                                                                             const int32_t *__restrict__ labels_all,
+                                                                             int32_t *__restrict__ out_ids, int32_t *__restrict__ out_labels) {
+    __shared__ uint64_t sh[SHUF_TILE];
+    __shared__ int part[SHUF_WAVES * PCG_WAVE];
+    const uint64_t epoch = epoch_base + (epoch_counter ? *epoch_counter : 0ull);
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * PCG_WAVE + lane;
+    const uint64_t mine = shuffle_key(seed, epoch, i, k);
+    // the owners' draws: a chain of ~log2(n) dependent loads - issued before the ranking so that it overlaps with it
+    int32_t id = 0;
+    if (wave == 0 && i < k) id = pick_draw(cum, idx_train, n, philox_uniform(seed, epoch, (uint32_t)i));
+    int c = 0;
+    for (int t0 = 0; t0 < k; t0 += SHUF_TILE) {
+        const int nt = (k - t0 < SHUF_TILE) ? k - t0 : SHUF_TILE;
+        __syncthreads();
+        for (int t = threadIdx.x; t < nt; t += blockDim.x) sh[t] = shuffle_key(seed, epoch, t0 + t, k);
+        __syncthreads();
+        const int chunk = (nt + SHUF_WAVES - 1) / SHUF_WAVES;
+        const int j0 = wave * chunk, j1 = (j0 + chunk < nt) ? j0 + chunk : nt;
+        for (int j = j0; j < j1; ++j) c += sh[j] < mine;
+    }
+    part[wave * PCG_WAVE + lane] = c;
+    __syncthreads();
+    if (wave == 0 && i < k) {
+        int rank = 0;
+#pragma unroll
+        for (int w = 0; w < SHUF_WAVES; ++w) rank += part[w * PCG_WAVE + lane];
+        out_ids[rank] = id;
+        if (out_labels) out_labels[rank] = labels_all[id];
+    }
+}
+
+__global__ void bump_counter_kernel(unsigned long long *counter) { *counter += 1ull; }
 
 }  // namespace pcg
 
@@ -135,6 +201,27 @@ int pcg_pick(const double *cum, const int32_t *idx_train, int32_t n_train, const
     hipLaunchKernelGGL(pcg::pick_kernel, dim3((k + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), cum,
                        idx_train, n_train, uniforms, seed, epoch, k, out);
     PCG_LAUNCH_CHECK();
+    return PCG_OK;
+}
+
+int pcg_pick_shuffled(const double *cum, const int32_t *idx_train, int32_t n_train, uint64_t seed, uint64_t epoch_base,
+                      uint64_t *epoch_counter, int32_t bump, int32_t k, const int32_t *labels_all, int32_t *out_ids,
+                      int32_t *out_labels, void *stream) {
+    if (!cum || !idx_train || !out_ids || n_train < 1 || k < 0) return PCG_E_ARG;
+    if (out_labels && !labels_all) return PCG_E_ARG;
+    if (bump && !epoch_counter) return PCG_E_ARG;
+    if (k > 131072) return PCG_E_UNSUPPORTED;     // k^2 key compares: beyond this use pcg_pick + a sort-based shuffle
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (k > 0) {
+        hipLaunchKernelGGL(pcg::pick_shuffled_kernel, dim3((k + PCG_WAVE - 1) / PCG_WAVE), dim3(pcg::SHUF_WAVES * PCG_WAVE), 0, st,
+                           cum, idx_train, n_train, seed, epoch_base, reinterpret_cast<const unsigned long long *>(epoch_counter),
+                           k, labels_all, out_ids, out_labels);
+        PCG_LAUNCH_CHECK();
+    }
+    if (bump) {
+        hipLaunchKernelGGL(pcg::bump_counter_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<unsigned long long *>(epoch_counter));
+        PCG_LAUNCH_CHECK();
+    }
     return PCG_OK;
 }
 

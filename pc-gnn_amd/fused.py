@@ -241,13 +241,9 @@ class FusedPCGNN:
         """Stage an epoch's (already shuffled) ids and labels; afterwards ``epoch_step(b)`` is exactly one
         graph launch - no copies, no indexing kernels (model_handler.py:142-148 slices a Python list here)."""
         n = ids.numel()
-        if getattr(self, "_ep_ids", None) is None or self._ep_ids.numel() < n:
-            self._ep_ids = torch.zeros(n, dtype=torch.int32, device=self.dev)
-            self._ep_lab = torch.zeros(n, dtype=torch.int32, device=self.dev)
-            self._ep_graphs = {}
-        self._ep_ids[:n].copy_(ids)
-        self._ep_lab[:n].copy_(labels)
-        self._ep_n, self._ep_bs = n, batch_size
+        ep_ids, ep_lab = self.stage_epoch(n, batch_size)
+        ep_ids.copy_(ids)
+        ep_lab.copy_(labels)
 
     def epoch_step(self, b: int):
         lo = b * self._ep_bs
@@ -274,6 +270,49 @@ class FusedPCGNN:
             self._prof = prof
             self._ep_graphs[key] = gr
         gr.replay()
+
+    def stage_epoch(self, n: int, batch_size: int):
+        """Static id / label buffers of an epoch of n picks (filled by begin_epoch or by a sampler)."""
+        if getattr(self, "_ep_ids", None) is None or self._ep_ids.numel() < n:
+            self._ep_ids = torch.zeros(n, dtype=torch.int32, device=self.dev)
+            self._ep_lab = torch.zeros(n, dtype=torch.int32, device=self.dev)
+            self._ep_graphs = {}
+        self._ep_n, self._ep_bs = n, batch_size
+        return self._ep_ids[:n], self._ep_lab[:n]
+
+    def epoch_run(self, n_steps: Optional[int] = None, sample=None):
+        """All batches of the staged epoch as ONE graph launch: the host latency between two graph launches (~8 us)
+        is paid once per epoch instead of once per batch.  ``sample()``, if given, is enqueued (and captured) first: it
+        fills the staged id / label buffers on the device (pick + shuffle + labels), so a replay is a whole new epoch."""
+        nb = -(-self._ep_n // self._ep_bs)
+        n_steps = nb if n_steps is None else min(n_steps, nb)
+        key = ("epoch", self._ep_n, self._ep_bs, n_steps, sample is not None)
+        gr = self._ep_graphs.get(key)
+        if gr is None:
+            def run():
+                for b in range(n_steps):
+                    lo = b * self._ep_bs
+                    B = min(self._ep_bs, self._ep_n - lo)
+                    self.train_step(self._ep_ids[lo:lo + B], self._ep_lab[lo:lo + B])
+            state = (self.theta.clone(), self.m.clone(), self.v.clone(), self.step_counter.clone())
+            prof, self._prof = self._prof, None
+            s = torch.cuda.Stream(self.dev)
+            s.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(s):
+                run()                      # (sets kernel attributes, allocates the per-batch-size workspaces)
+            torch.cuda.current_stream(self.dev).wait_stream(s)
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                if sample is not None:
+                    sample()
+                run()
+            for dst, src in zip((self.theta, self.m, self.v, self.step_counter), state):
+                dst.copy_(src)
+            self._prof = prof
+            self._ep_graphs[key] = gr
+        self._lastB = min(self._ep_bs, self._ep_n - (n_steps - 1) * self._ep_bs)
+        gr.replay()
+        return n_steps
 
     def last_loss(self) -> torch.Tensor:
         B = self._lastB

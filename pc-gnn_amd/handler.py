@@ -56,6 +56,7 @@ class PCGNNTrainer:
                                    seed=cfg["seed"])
         self.pick_size = 2 * len(w.train_pos)                                          # :130
         self.batch_size = cfg["batch_size"]
+        self._epoch_dev = torch.zeros(1, dtype=torch.int64, device=self.device)      # epoch number of the staged sampler
         self._gen = torch.Generator(device=self.device)
         self._gen.manual_seed(cfg["seed"])
 
@@ -68,6 +69,19 @@ class PCGNNTrainer:
         picked = self.sampler.pick(self.pick_size, epoch)
         perm = torch.randperm(self.pick_size, device=self.device, generator=self._gen)
         return picked[perm]
+
+    def start_epoch_staged(self) -> torch.Tensor:
+        """pick + shuffle + label lookup in ONE launch (pcg_pick_shuffled), straight into the fused engine's epoch
+        buffers; the epoch number lives on the device and is incremented by the call.  Returns the staged ids."""
+        ids, lab = self.fused.stage_epoch(self.pick_size, self.batch_size)
+        self.sampler.pick_shuffled(self.pick_size, ids, self.labels_i32, lab, epoch_counter=self._epoch_dev, bump=True)
+        return ids
+
+    def run_epoch_one_graph(self) -> int:
+        """A whole epoch - pick, shuffle, labels and every batch's training step - as one graph launch."""
+        self.fused.stage_epoch(self.pick_size, self.batch_size)
+        self.fused.epoch_run(sample=self.start_epoch_staged)
+        return self.pick_size
 
     def step(self, batch_ids: torch.Tensor, timed: bool = False) -> torch.Tensor:
         """One iteration of the batch loop (model_handler.py:147-153)."""

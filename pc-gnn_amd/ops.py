@@ -245,3 +245,18 @@ def pick(cum: torch.Tensor, idx_train: torch.Tensor, k: int, uniforms: Optional[
     _lib.check(lib.pcg_pick(_p(cum), _p(idx_train), idx_train.numel(), _p(uniforms), seed & (2 ** 64 - 1),
                             epoch & (2 ** 64 - 1), k, _p(out), _stream(cum.device)), "pcg_pick")
     return out
+
+
+def pick_shuffled(cum: torch.Tensor, idx_train: torch.Tensor, k: int, seed: int, epoch_base: int,
+                  out_ids: torch.Tensor, labels_all: Optional[torch.Tensor] = None,
+                  out_labels: Optional[torch.Tensor] = None, epoch_counter: Optional[torch.Tensor] = None,
+                  bump: bool = False):
+    """An epoch's picks, shuffled, with their labels, in one launch (pcg_pick_shuffled): the same draws as
+    ``pick(seed, epoch)``, in a uniformly random order.  epoch = epoch_base + epoch_counter[0] (a device int64 the
+    call increments afterwards when ``bump``: a captured graph then replays a new epoch every time)."""
+    lib = _lib.load()
+    _lib.check(lib.pcg_pick_shuffled(_p(cum), _p(idx_train), idx_train.numel(), seed & (2 ** 64 - 1),
+                                     epoch_base & (2 ** 64 - 1), _p(epoch_counter), 1 if bump else 0, k,
+                                     _p(labels_all), _p(out_ids), _p(out_labels), _stream(cum.device)),
+               "pcg_pick_shuffled")
+    return out_ids

@@ -31,6 +31,13 @@ class PickSampler:
         """int32 device tensor of `size` training-node ids, drawn with replacement."""
         return ops.pick(self.cum, self.idx_train, size, uniforms, self.seed, epoch, out)
 
+    def pick_shuffled(self, size: int, out_ids: torch.Tensor, labels_all: Optional[torch.Tensor] = None,
+                      out_labels: Optional[torch.Tensor] = None, epoch: int = 0,
+                      epoch_counter: Optional[torch.Tensor] = None, bump: bool = False) -> torch.Tensor:
+        """pick + random.shuffle + label lookup of one epoch in one launch (utils.py:274-278, model_handler.py:131-133)."""
+        return ops.pick_shuffled(self.cum, self.idx_train, size, self.seed, epoch, out_ids, labels_all, out_labels,
+                                 epoch_counter, bump)
+
 
 def pick_step(idx_train, y_train, adj_list, size, device="cuda", uniforms=None, seed=0, epoch=0):
     """Reference signature (utils.py:274): returns a Python list like the reference does.

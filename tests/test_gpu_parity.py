@@ -166,6 +166,37 @@ def test_pick_golden(P, case):
     assert out.cpu().tolist() == c.z["pick_out"].tolist()
 
 
+def test_pick_shuffled_is_a_shuffle_of_pick(P):
+    """pcg_pick_shuffled = pcg_pick's draws of the same (seed, epoch) in a random order, with their labels; the
+    device epoch counter advances by one per call."""
+    ops = P.ops
+    rs = np.random.RandomState(3)
+    n_nodes, n_train = 50000, 18000
+    idx_train = np.sort(rs.choice(n_nodes, size=n_train, replace=False)).astype(np.int32)
+    labels = (rs.rand(n_nodes) < 0.15).astype(np.int32)
+    cum = torch.from_numpy(np.cumsum(rs.randint(1, 50, size=n_train) / 7.0)).cuda()
+    idx_d, lab_d = torch.from_numpy(idx_train).cuda(), torch.from_numpy(labels).cuda()
+    counter = torch.zeros(1, dtype=torch.int64, device=dev())
+    orders = []
+    for k in (1, 63, 5346, 20000):
+        out_ids = torch.full((k,), -1, dtype=torch.int32, device=dev())
+        out_lab = torch.full((k,), -1, dtype=torch.int32, device=dev())
+        e0 = int(counter.item())
+        ops.pick_shuffled(cum, idx_d, k, 11, 100, out_ids, lab_d, out_lab, counter, bump=True)
+        ref = ops.pick(cum, idx_d, k, None, 11, 100 + e0)
+        assert int(counter.item()) == e0 + 1
+        a, b = out_ids.cpu().numpy(), ref.cpu().numpy()
+        assert np.array_equal(np.sort(a), np.sort(b))                      # same draws ...
+        assert np.array_equal(out_lab.cpu().numpy(), labels[a])            # ... with their labels
+        if k > 1000:
+            assert not np.array_equal(a, b)                                # ... in another order
+            orders.append(a)
+    # a different epoch gives different draws
+    out2 = torch.empty(5346, dtype=torch.int32, device=dev())
+    ops.pick_shuffled(cum, idx_d, 5346, 11, 100, out2, None, None, counter, bump=False)
+    assert not np.array_equal(np.sort(out2.cpu().numpy()), np.sort(orders[0]))
+
+
 def test_kat(P):
     z = np.load(os.path.join(GOLDEN, "kat.npz"))
     ops = P.ops
