@@ -1188,21 +1188,34 @@ __global__ void __launch_bounds__(256) combine_rows(const AggArgs a) {
     }
     const RowGeom q = row_geom(a.feat_stride, lane);
     if (lane >= q.lpr) return;
+    const int cnt = a.cnt[row];
     float4 acc[NACC];
 #pragma unroll
     for (int x = 0; x < NACC; ++x) acc[x] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int j = 0; j < nch_row; ++j) {
-        const float *pp = a.partial + (size_t)(cb + j) * a.feat_stride;
+    // the partial sums are added in chunk order; their loads are issued a batch at a time (the row with the most chunks
+    // sets this kernel's duration: one load latency per batch instead of one per chunk)
+    constexpr int CB = NACC == 1 ? 16 : 8;
+    for (int j0 = 0; j0 < nch_row; j0 += CB) {
+        float4 t[CB][NACC];
 #pragma unroll
-        for (int x = 0; x < NACC; ++x) {
-            const int c4 = x * q.lpr + q.sub;
-            if (c4 < q.nch) {
-                const float4 t = *reinterpret_cast<const float4 *>(pp + 4 * c4);
-                acc[x].x += t.x; acc[x].y += t.y; acc[x].z += t.z; acc[x].w += t.w;
+        for (int u = 0; u < CB; ++u) {
+            const float *pp = a.partial + (size_t)(cb + j0 + u) * a.feat_stride;
+#pragma unroll
+            for (int x = 0; x < NACC; ++x) {
+                const int c4 = x * q.lpr + q.sub;
+                t[u][x] = (j0 + u < nch_row && c4 < q.nch) ? *reinterpret_cast<const float4 *>(pp + 4 * c4)
+                                                          : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
+#pragma unroll
+        for (int u = 0; u < CB; ++u)
+#pragma unroll
+            for (int x = 0; x < NACC; ++x) {
+                if (j0 + u < nch_row) {
+                    acc[x].x += t[u][x].x; acc[x].y += t[u][x].y; acc[x].z += t[u][x].z; acc[x].w += t[u][x].w;
+                }
+            }
     }
-    const int cnt = a.cnt[row];
     const float den = a.norm == PCG_NORM_SQRT_COUNT ? sqrtf((float)cnt) : (float)cnt;
     store_row<NACC>(a.agg + (size_t)row * a.agg_stride, acc, q, a.feat_dim, den);
 }

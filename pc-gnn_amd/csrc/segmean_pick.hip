@@ -141,20 +141,58 @@ __device__ __forceinline__ uint64_t shuffle_key(uint64_t seed, uint64_t epoch, i
     return ((uint64_t)c[2] << 32) | (uint32_t)i;
 }
 
+// bisect_right(cum, x, 0, n-1) by a group of 16 lanes: 16 probes per step => ceil(log16 n) dependent loads instead of log2 n.
+// All 16 lanes of the group must call it with the same x; every lane returns the index.
+__device__ __forceinline__ int bisect16(const double *__restrict__ cum, int n, double x, int sub) {
+    int lo = 0, hi = n - 1;                      // the answer is the first index in [lo, hi) with x < cum[index], or hi
+    while (hi - lo > 0) {
+        const int span = hi - lo;
+        const int step = (span + 15) >> 4;       // probes at lo + (sub+1)*step - 1, clipped to hi - 1
+        int q = lo + (sub + 1) * step - 1;
+        if (q > hi - 1) q = hi - 1;
+        const bool below = !(x < cum[q]);        // true on a prefix of the probes: the answer lies beyond q
+        const uint64_t m = __ballot(below);
+        const int shift = lane_id() & ~15;
+        const int c = __popc(((unsigned)(m >> shift)) & 0xFFFFu);     // leading `below` probes of this group
+        if (c == 16) {
+            int ql = lo + 16 * step - 1;
+            if (ql > hi - 1) ql = hi - 1;
+            lo = ql + 1;                         // beyond the last probe
+        } else {
+            int qc = lo + (c + 1) * step - 1;    // first probe with x < cum[probe]
+            if (qc > hi - 1) qc = hi - 1;
+            if (c > 0) {
+                int ql = lo + c * step - 1;
+                if (ql > hi - 1) ql = hi - 1;
+                lo = ql + 1;
+            }
+            hi = qc;
+        }
+    }
+    return lo;
+}
+
 __global__ void __launch_bounds__(SHUF_WAVES *PCG_WAVE) pick_shuffled_kernel(const double *__restrict__ cum, const int32_t *__restrict__ idx_train,
                                                                              int n, uint64_t seed, uint64_t epoch_base,
-                                                                             const unsigned long long *__restrict__ epoch_counter, int k,
+                                                                             unsigned long long *__restrict__ epoch_counter, int bump,
+                                                                             unsigned int *__restrict__ done, int k,
                                                                              const int32_t *__restrict__ labels_all,
                                                                              int32_t *__restrict__ out_ids, int32_t *__restrict__ out_labels) {
     __shared__ uint64_t sh[SHUF_TILE];
     __shared__ int part[SHUF_WAVES * PCG_WAVE];
+    __shared__ int32_t drawn[PCG_WAVE];
     const uint64_t epoch = epoch_base + (epoch_counter ? *epoch_counter : 0ull);
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int i = blockIdx.x * PCG_WAVE + lane;
     const uint64_t mine = shuffle_key(seed, epoch, i, k);
-    // the owners' draws: a chain of ~log2(n) dependent loads - issued before the ranking so that it overlaps with it
-    int32_t id = 0;
-    if (wave == 0 && i < k) id = pick_draw(cum, idx_train, n, philox_uniform(seed, epoch, (uint32_t)i));
+    // this workgroup's 64 draws: 16 lanes per draw (1024 threads), a 16-ary search each
+    {
+        const int dl = threadIdx.x >> 4, sub = threadIdx.x & 15;          // draw slot 0..63, lane in the group
+        const int di = blockIdx.x * PCG_WAVE + dl;
+        const double u = philox_uniform(seed, epoch, (uint32_t)(di < k ? di : 0));
+        const int pos = bisect16(cum, n, u * (cum[n - 1] + 0.0), sub);
+        if (sub == 0) drawn[dl] = idx_train[pos];
+    }
     int c = 0;
     for (int t0 = 0; t0 < k; t0 += SHUF_TILE) {
         const int nt = (k - t0 < SHUF_TILE) ? k - t0 : SHUF_TILE;
@@ -171,8 +209,18 @@ __global__ void __launch_bounds__(SHUF_WAVES *PCG_WAVE) pick_shuffled_kernel(con
         int rank = 0;
 #pragma unroll
         for (int w = 0; w < SHUF_WAVES; ++w) rank += part[w * PCG_WAVE + lane];
+        const int32_t id = drawn[lane];
         out_ids[rank] = id;
         if (out_labels) out_labels[rank] = labels_all[id];
+    }
+    // the last workgroup to finish moves the epoch on (every workgroup has read the counter by then)
+    if (bump && threadIdx.x == 0) {
+        __threadfence();
+        const unsigned int ticket = atomicAdd(done, 1u);
+        if (ticket == gridDim.x - 1) {
+            *done = 0u;
+            *epoch_counter += 1ull;
+        }
     }
 }
 
@@ -213,12 +261,13 @@ int pcg_pick_shuffled(const double *cum, const int32_t *idx_train, int32_t n_tra
     if (k > 131072) return PCG_E_UNSUPPORTED;     // k^2 key compares: beyond this use pcg_pick + a sort-based shuffle
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (k > 0) {
+        // epoch_counter[1] is the kernel's "workgroups done" ticket (zero between launches)
         hipLaunchKernelGGL(pcg::pick_shuffled_kernel, dim3((k + PCG_WAVE - 1) / PCG_WAVE), dim3(pcg::SHUF_WAVES * PCG_WAVE), 0, st,
-                           cum, idx_train, n_train, seed, epoch_base, reinterpret_cast<const unsigned long long *>(epoch_counter),
-                           k, labels_all, out_ids, out_labels);
+                           cum, idx_train, n_train, seed, epoch_base, reinterpret_cast<unsigned long long *>(epoch_counter), bump,
+                           reinterpret_cast<unsigned int *>(epoch_counter ? epoch_counter + 1 : nullptr), k, labels_all, out_ids,
+                           out_labels);
         PCG_LAUNCH_CHECK();
-    }
-    if (bump) {
+    } else if (bump) {
         hipLaunchKernelGGL(pcg::bump_counter_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<unsigned long long *>(epoch_counter));
         PCG_LAUNCH_CHECK();
     }

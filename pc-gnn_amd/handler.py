@@ -56,7 +56,7 @@ class PCGNNTrainer:
                                    seed=cfg["seed"])
         self.pick_size = 2 * len(w.train_pos)                                          # :130
         self.batch_size = cfg["batch_size"]
-        self._epoch_dev = torch.zeros(1, dtype=torch.int64, device=self.device)      # epoch number of the staged sampler
+        self._epoch_dev = torch.zeros(2, dtype=torch.int64, device=self.device)      # [epoch of the staged sampler, kernel scratch]
         self._gen = torch.Generator(device=self.device)
         self._gen.manual_seed(cfg["seed"])
 

@@ -176,15 +176,15 @@ def test_pick_shuffled_is_a_shuffle_of_pick(P):
     labels = (rs.rand(n_nodes) < 0.15).astype(np.int32)
     cum = torch.from_numpy(np.cumsum(rs.randint(1, 50, size=n_train) / 7.0)).cuda()
     idx_d, lab_d = torch.from_numpy(idx_train).cuda(), torch.from_numpy(labels).cuda()
-    counter = torch.zeros(1, dtype=torch.int64, device=dev())
+    counter = torch.zeros(2, dtype=torch.int64, device=dev())
     orders = []
     for k in (1, 63, 5346, 20000):
         out_ids = torch.full((k,), -1, dtype=torch.int32, device=dev())
         out_lab = torch.full((k,), -1, dtype=torch.int32, device=dev())
-        e0 = int(counter.item())
+        e0 = int(counter[0].item())
         ops.pick_shuffled(cum, idx_d, k, 11, 100, out_ids, lab_d, out_lab, counter, bump=True)
         ref = ops.pick(cum, idx_d, k, None, 11, 100 + e0)
-        assert int(counter.item()) == e0 + 1
+        assert int(counter[0].item()) == e0 + 1 and int(counter[1].item()) == 0
         a, b = out_ids.cpu().numpy(), ref.cpu().numpy()
         assert np.array_equal(np.sort(a), np.sort(b))                      # same draws ...
         assert np.array_equal(out_lab.cpu().numpy(), labels[a])            # ... with their labels
