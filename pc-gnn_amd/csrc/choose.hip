@@ -36,7 +36,7 @@ constexpr int SEL_BLOCKS = 768;  // persistent select workgroups: 3 per CU
 constexpr int SEL_LDS_WORDS = 3 * T4_CAP;
 constexpr int CHUNK = 128;       // list entries per gather work item
 constexpr int UNROLL = 8;        // row-gather instructions in flight per wave
-constexpr int KEY_UNROLL = 4;    // neighbour-score gathers in flight per lane
+constexpr int KEY_UNROLL = 8;    // neighbour-score gathers in flight per lane
 constexpr int PLAN_THREADS = 1024;
 constexpr int PLAN_PER = 4;      // rows per plan thread per tile
 constexpr int GATHER_BLOCKS = 2048;
@@ -845,13 +845,22 @@ __device__ __forceinline__ void select_row(const ChooseArgs &a, int row, uint32_
         }
         int run;
         grp_scan<NW>(mine, wave, lane, red, run, ns);
-        for (int i0 = b0; i0 < e0; i0 += PCG_WAVE) {
-            const int i = i0 + lane;
-            const bool sel = i < e0 && keys[i] <= kstar;
-            const uint32_t id = i < e0 ? nbr_id(i) : 0u;
-            const uint64_t sm = __ballot(sel);
-            if (sel) selbuf[run + __popcll(sm & lanemask_lt())] = id;
-            run += __popcll(sm);
+        constexpr int CU = 4;     // ids of 4 iterations in flight (CSR_IDS: global loads, one latency per batch)
+        for (int i0 = b0; i0 < e0; i0 += CU * PCG_WAVE) {
+            uint32_t idv[CU];
+#pragma unroll
+            for (int u = 0; u < CU; ++u) {
+                const int i = i0 + u * PCG_WAVE + lane;
+                idv[u] = i < e0 ? nbr_id(i) : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < CU; ++u) {
+                const int i = i0 + u * PCG_WAVE + lane;
+                const bool sel = i < e0 && keys[i] <= kstar;
+                const uint64_t sm = __ballot(sel);
+                if (sel) selbuf[run + __popcll(sm & lanemask_lt())] = idv[u];
+                run += __popcll(sm);
+            }
         }
     }
     grp_sync<NW>();

@@ -1,0 +1,59 @@
+"""Turn two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, as MI355X_MICROARCH.md prescribes) into
+profiles/pmc_traffic.json: HBM-side bytes per select + aggregate call, corrected for gfx950 (FETCH_SIZE counts half
+of a 16-B/lane coalesced read: the float4 row gather of gather_chunks is doubled; 4-B/lane kernels are left as read).
+
+    python scripts/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <workload> [out.json] [per_kernel.csv]
+"""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+CALL_KERNELS = ("select_rows", "gather_chunks", "combine_rows")      # the launches of pcg_choose_aggregate_planned
+WIDE_READERS = ("gather_chunks",)                                     # 16 B per lane: FETCH_SIZE x 2
+
+
+def per_kernel(path, counter):
+    tot, n = defaultdict(float), defaultdict(int)
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if row.get("Counter_Name") != counter:
+                continue
+            k = row["Kernel_Name"]
+            tot[k] += float(row["Counter_Value"])
+            n[k] += 1
+    return {k: (tot[k] / n[k], n[k]) for k in tot}
+
+
+def main():
+    fetch_csv, write_csv, workload = sys.argv[1:4]
+    out = sys.argv[4] if len(sys.argv) > 4 else "profiles/pmc_traffic.json"
+    per_csv = sys.argv[5] if len(sys.argv) > 5 else None
+    fetch, write = per_kernel(fetch_csv, "FETCH_SIZE"), per_kernel(write_csv, "WRITE_SIZE")
+    if per_csv:
+        with open(per_csv, "w") as f:
+            f.write("kernel,dispatches,FETCH_SIZE_KB_mean,WRITE_SIZE_KB_mean\n")
+            for k in sorted(set(fetch) | set(write)):
+                f.write('"%s",%d,%.1f,%.1f\n' % (k, fetch.get(k, (0, 0))[1] or write.get(k, (0, 0))[1],
+                                                  fetch.get(k, (0, 0))[0], write.get(k, (0, 0))[0]))
+    detail, total = {}, 0.0
+    for name in CALL_KERNELS:
+        fk = sum(v[0] for k, v in fetch.items() if name in k)
+        wk = sum(v[0] for k, v in write.items() if name in k)
+        mult = 2.0 if name in WIDE_READERS else 1.0
+        detail[name] = {"FETCH_SIZE_KB": fk, "fetch_correction": mult, "WRITE_SIZE_KB": wk}
+        total += (fk * mult + wk) * 1024.0
+    try:
+        data = json.load(open(out))
+    except Exception:
+        data = {}
+    data[workload] = {"choose_agg_bytes_per_launch": total, "detail": detail,
+                      "correction": "gfx950: FETCH_SIZE reads 1/2 of 16-B/lane coalesced reads (MI355X_MICROARCH.md, HBM) -> "
+                                    "gather_chunks (float4 per lane) doubled; 4-B/lane kernels uncorrected",
+                      "note": "mean over the run's dispatches of every kernel of the call; counters in KB"}
+    json.dump(data, open(out, "w"), indent=1)
+    print(json.dumps(data[workload], indent=1))
+
+
+if __name__ == "__main__":
+    main()
