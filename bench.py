@@ -122,6 +122,7 @@ def run_partitioned(args, w, B, lr, wd, dev, dist, world, rank):
 
     for k in range(args.warmup):
         one_step(k)
+    prof = d.profile_select(args.event_every) if rank == 0 else None
     barrier()
     t0 = time.perf_counter()
     halo_rows = remote = entries = 0
@@ -139,6 +140,21 @@ def run_partitioned(args, w, B, lr, wd, dev, dist, world, rank):
     nodes_total = args.steps * B * world
     if rank == 0:
         hr, rm, en = (float(x) / (args.steps * world) for x in stats.tolist())
+        # roofline of the dominant launch of this path: the select segment (train-pos sort + plan + select_rows), rank 0
+        ms, ab = [], []
+        g = d.g
+        for e0, e1, ids_l, cnt in prof:
+            ms.append(e0.elapsed_time(e1))
+            ids_h = ids_l.cpu().numpy().astype(np.int64)
+            deg = [g.deg_host[r][ids_h].astype(np.int64).sum() for r in range(g.R)]
+            ab.append(sum(4 * (2 * len(ids_h) + int(x)) + 4 * int(x) for x in deg) + 4 * int(cnt.sum().item()) + 8 * g.n_pos)
+        avg_ms = float(np.mean(ms)) if ms else float("nan")
+        achieved = float(np.mean(ab)) / (avg_ms * 1e-3) / 1e9 if ms else float("nan")
+        roofline = {"bound": "hbm", "kernel": "select segment of the partitioned step on rank 0 (pos_sort + plan + select_rows: CSR rows, "
+                                              "neighbour scores, lists); the feature-row gather follows the halo exchange",
+                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": float(np.mean(ab)) if ab else None,
+                    "launches_timed": len(ms)}
         out = {
             "metric": "sampled-nodes/sec", "value": nodes_total / elapsed, "unit": "nodes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -151,6 +167,7 @@ def run_partitioned(args, w, B, lr, wd, dev, dist, world, rank):
                        "id + feature-row all-to-all, grad all-reduce (RCCL)", "engine": "fused-eager",
                        "nodes_processed": int(nodes_total),
                        "per_rank_per_step": {"halo_rows_fetched": hr, "rows_served_to_others": rm, "halo_bytes_in": en}},
+            "roofline": roofline,
         }
         print(json.dumps(out))
     dist.destroy_process_group()

@@ -369,10 +369,20 @@ class DistributedPCGNN:
             ids_local, labels = self.ids_buf[:B], self.lab_buf[:B]
         ops.score_table(g, self.w_clf, self.b_clf, out=self.s0_send, row_begin=0, row_end=part.n_local)
         self._all_gather(self.s0_full, self.s0_send)
+        prof = getattr(self, "_prof", None)
+        timed = prof is not None and self._prof_step % self._prof_every == 0
+        if prof is not None:
+            self._prof_step += 1
+        if timed:      # HIP events around the select segment (bench.py's roofline at N > 1), on the launching stream
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         if use_graphs:
             gr["select"].replay()
         else:
             self._seg_select(ids_local, labels, B, True)
+        if timed:
+            ev[1].record()
+            prof.append((ev[0], ev[1], ids_local.clone(), self.cnt[:self.g.R * B].clone()))
         self._exchange(B)
         if use_graphs:
             gr["dense"].replay()
@@ -383,6 +393,11 @@ class DistributedPCGNN:
         self._libmod.check(lib.pcg_adam_step(_p(self.theta), _p(self.m), _p(self.v), _p(self.grad), 1, self.n_params,
                                              _p(self.step_counter), c["lr"], 0.9, 0.999, 1e-8, c["weight_decay"], None, 1,
                                              ops._stream(self.dev)), "pcg_adam_step")
+
+    def profile_select(self, every: int = 10):
+        """Start collecting (start event, end event, ids, |set| counts) of every `every`-th step's select segment."""
+        self._prof, self._prof_every, self._prof_step = [], every, 0
+        return self._prof
 
     def pick_epoch(self, size: int, epoch: int) -> torch.Tensor:
         """this rank's share of the epoch's picks: local row numbers of owned training nodes."""
