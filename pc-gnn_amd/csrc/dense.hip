@@ -20,7 +20,7 @@ namespace pcg {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TB = 16;          // batch rows per workgroup (one MFMA M-tile)
-constexpr int DENSE_WAVES = 8;
+constexpr int DENSE_WAVES = 16;
 
 struct DenseArgs {
     const float *X;
@@ -277,18 +277,21 @@ __global__ void __launch_bounds__(DENSE_WAVES *PCG_WAVE) dense_step_kernel(const
         const float g = s_dlog[2 * t] * s_wc[e] + s_dlog[2 * t + 1] * s_wc[E + e];
         s_dcomb[t * ldE + e] = s_comb[t * ldE + e] > 0.f ? g : 0.f;
     }
+    DENSE_STAMP(8);
     for (int i = tid; i < 2 * E; i += blockDim.x) {
         const int cidx = i / E, e = i - cidx * E;
         float sacc = 0.f;
         for (int t = 0; t < TB; ++t) sacc = fmaf(s_dlog[2 * t + cidx], s_comb[t * ldE + e], sacc);
         slab[off_cls(F, E, R) + i] = sacc;
     }
+    DENSE_STAMP(9);
     for (int i = tid; i < 2 * F; i += blockDim.x) {
         const int cidx = i / F, f = i - cidx * F;
         float sacc = 0.f;
         for (int t = 0; t < TB; ++t) sacc = fmaf(s_dcl[2 * t + cidx], s_cat[t * ld2 + f], sacc);
         slab[off_clf(F, E, R) + i] = sacc;
     }
+    DENSE_STAMP(10);
     if (tid < 2) {
         float sacc = 0.f;
         for (int t = 0; t < TB; ++t) sacc += s_dcl[2 * t + tid];

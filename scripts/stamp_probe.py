@@ -56,11 +56,13 @@ for it in range(3):
     torch.cuda.synchronize()
 lib.pcg_debug_set_dense_stamps(None)
 d = dst.cpu().numpy().astype(np.float64) * 0.01
-names = ["stage weights+self(1)", "h_r fwd(2)", "combined(3)", "logits(4)", "loss grads(5)", "dcomb+small dW(6)", "dW_inter(7)", "per-rel bwd(8)"]
+names = ["stage weights+self+agg", "h_r fwd", "combined", "logits + loss grads", "dcomb + small dW", "dh_r + dW_inter", "dW_r", ""]
 print("dense_step per tile (us):", "start skew %.1f" % (d[:,0].max()-d[:,0].min()), " total mean %.1f max %.1f" % ((d[:,7]-d[:,0]).mean(), (d[:,7]-d[:,0]).max()))
 for i in range(1, 8):
     dt = d[:, i] - d[:, i-1]
     print(f"   {names[i-1]:24s} mean {dt.mean():6.2f}  max {dt.max():6.2f}")
+print("   inside phase 5 (thread 0): dcomb loop %.2f, dW_cls loop %.2f, dW_clf loop %.2f, rest+barrier %.2f" % (
+    (d[:, 8] - d[:, 4]).mean(), (d[:, 9] - d[:, 8]).mean(), (d[:, 10] - d[:, 9]).mean(), (d[:, 5] - d[:, 10]).mean()))
 
 # ---- the slowest T1 rows
 tot = st[:, 6] - st[:, 0]
