@@ -156,6 +156,17 @@ int pcg_step_front(const pcg_graph_desc *g, const float *W, const float *b, floa
                    const int32_t *nodes, const int32_t *labels, int32_t B, const double *thresholds,
                    const double *rho, int32_t train_flag, int32_t add_self, void *workspace, int64_t list_capacity,
                    uint32_t *status, void *stream);
+/* The two halves of pcg_step_front on their own, for callers that need something between them (the partitioned
+ * path all-gathers the scores): _a = scores of rows [row_begin, row_end) into s0_out[row] (as pcg_score_table) || plan
+ * pass 1;  _b = train-pos sort by s0 || plan pass 2.  Same plan arguments in both. */
+int pcg_step_front_a(const pcg_graph_desc *g, const float *W, const float *b, int64_t row_begin, int64_t row_end,
+                     float *s0_out, const int32_t *nodes, const int32_t *labels, int32_t B, const double *thresholds,
+                     const double *rho, int32_t train_flag, int32_t add_self, void *workspace, int64_t list_capacity,
+                     uint32_t *status, void *stream);
+int pcg_step_front_b(const pcg_graph_desc *g, const float *s0, uint64_t *pos_keys, const int32_t *nodes,
+                     const int32_t *labels, int32_t B, const double *thresholds, const double *rho,
+                     int32_t train_flag, int32_t add_self, void *workspace, int64_t list_capacity, uint32_t *status,
+                     void *stream);
 int pcg_choose_select_planned(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B,
                               const float *s0, const float *center_s0, const uint64_t *pos_keys,
                               const double *thresholds, const double *rho, int32_t train_flag, int32_t add_self,

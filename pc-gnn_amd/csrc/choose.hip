@@ -424,11 +424,11 @@ constexpr int FRONT_COUNT_THREADS = 256;
 
 __global__ void __launch_bounds__(FRONT_COUNT_THREADS) front_a_kernel(const ChooseArgs a, PlanTotals *totals, int n_plan_blocks,
                                                                       const float *__restrict__ W, const float *__restrict__ bias,
-                                                                      float *__restrict__ s0) {
+                                                                      int64_t row_begin, int64_t row_end, float *__restrict__ s0) {
     if ((int)blockIdx.x < n_plan_blocks)
         plan_count_body<FRONT_COUNT_THREADS>(a, totals, (int)blockIdx.x);
     else
-        score_table_body(a.g.X, a.g.feat_dim, a.g.feat_stride, W, bias, 0, a.g.n_nodes, s0, (int)blockIdx.x - n_plan_blocks,
+        score_table_body(a.g.X, a.g.feat_dim, a.g.feat_stride, W, bias, row_begin, row_end, s0, (int)blockIdx.x - n_plan_blocks,
                          (int)gridDim.x - n_plan_blocks);
 }
 
@@ -1306,12 +1306,13 @@ int64_t pcg_sel_capacity_row(int64_t deg, double threshold, double rho, int32_t 
 static int choose_args(pcg::ChooseArgs &a, const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B,
                        const float *s0, const float *center_s0, const uint64_t *pos_keys, const double *thresholds,
                        const double *rho, int32_t train_flag, int32_t add_self, int32_t *cnt, void *workspace,
-                       int64_t list_capacity, uint32_t *status) {
-    if (!nodes || !s0 || !thresholds || !workspace || !status) return PCG_E_ARG;
+                       int64_t list_capacity, uint32_t *status, bool plan_only = false) {
+    if (!nodes || !thresholds || !workspace || !status) return PCG_E_ARG;
+    if (!plan_only && !s0) return PCG_E_ARG;      // (the plan reads neither the scores nor the sorted keys)
     if (list_capacity < 1 || list_capacity >= (1ll << 31)) return PCG_E_ARG;
     if (train_flag && !rho) return PCG_E_ARG;
     if (g->n_rel < 1 || g->n_rel > PCG_MAX_REL) return PCG_E_ARG;
-    if (train_flag && (!labels || (g->n_pos > 0 && (!pos_keys || !g->train_pos)))) return PCG_E_ARG;
+    if (train_flag && (!labels || (!plan_only && g->n_pos > 0 && (!pos_keys || !g->train_pos)))) return PCG_E_ARG;
     for (int r = 0; r < g->n_rel; ++r)
         if (!g->indptr[r] || !g->indices[r]) return PCG_E_ARG;
     a.g = *g;
@@ -1362,41 +1363,66 @@ int pcg_choose_select_planned(const pcg_graph_desc *g, const int32_t *nodes, con
                          workspace, list_capacity, status, stream);
 }
 
-int pcg_step_front(const pcg_graph_desc *g, const float *W, const float *b, float *s0, uint64_t *pos_keys,
-                   const int32_t *nodes, const int32_t *labels, int32_t B, const double *thresholds, const double *rho,
-                   int32_t train_flag, int32_t add_self, void *workspace, int64_t list_capacity, uint32_t *status,
-                   void *stream) {
-    if (!g || !g->X || !W || !b || !s0 || B < 0) return PCG_E_ARG;
+/* first half: class-0 logits of rows [row_begin, row_end) -> s0_out[row]  ||  plan pass 1 */
+int pcg_step_front_a(const pcg_graph_desc *g, const float *W, const float *b, int64_t row_begin, int64_t row_end,
+                     float *s0_out, const int32_t *nodes, const int32_t *labels, int32_t B, const double *thresholds,
+                     const double *rho, int32_t train_flag, int32_t add_self, void *workspace, int64_t list_capacity,
+                     uint32_t *status, void *stream) {
+    if (!g || !g->X || !W || !b || !s0_out || B < 0) return PCG_E_ARG;
     if (g->feat_dim < 1 || g->feat_stride < g->feat_dim || g->feat_stride % 4 != 0) return PCG_E_ARG;
     if ((reinterpret_cast<uintptr_t>(g->X) & 15u) != 0) return PCG_E_ARG;
+    if (row_begin < 0 || row_end > g->n_nodes || row_begin > row_end) return PCG_E_ARG;
+    if (B == 0) return pcg_score_table(g, W, b, row_begin, row_end, s0_out, stream);
+    pcg::ChooseArgs a;
+    const int rc = choose_args(a, g, nodes, labels, B, nullptr, nullptr, nullptr, thresholds, rho, train_flag, add_self, nullptr,
+                               workspace, list_capacity, status, true);
+    if (rc != PCG_OK) return rc;
+    const int rows = g->n_rel * B;
+    pcg::PlanTotals *tot = reinterpret_cast<pcg::PlanTotals *>(a.w.plan_totals);
+    const int n_count = (rows + pcg::FRONT_COUNT_THREADS - 1) / pcg::FRONT_COUNT_THREADS;
+    const int n_score = (int)pcg::score_table_blocks(row_end - row_begin, g->feat_stride);
+    hipLaunchKernelGGL(pcg::front_a_kernel, dim3(n_count + n_score), dim3(pcg::FRONT_COUNT_THREADS), 0,
+                       static_cast<hipStream_t>(stream), a, tot, n_count, W, b, row_begin, row_end, s0_out);
+    PCG_LAUNCH_CHECK();
+    return PCG_OK;
+}
+
+/* second half: train-pos sort by s0 (if train_flag and n_pos > 0)  ||  plan pass 2 */
+int pcg_step_front_b(const pcg_graph_desc *g, const float *s0, uint64_t *pos_keys, const int32_t *nodes,
+                     const int32_t *labels, int32_t B, const double *thresholds, const double *rho, int32_t train_flag,
+                     int32_t add_self, void *workspace, int64_t list_capacity, uint32_t *status, void *stream) {
+    if (!g || !s0 || B < 0) return PCG_E_ARG;
     const bool sort = train_flag && g->n_pos > 0;
     if (sort && (!pos_keys || !g->train_pos)) return PCG_E_ARG;
-    if (B == 0 || g->n_nodes == 0) {      // nothing to plan: the two stand-alone calls
-        int rc = pcg_score_table(g, W, b, 0, g->n_nodes, s0, stream);
-        if (rc == PCG_OK && sort) rc = pcg_pos_sort(g, s0, pos_keys, stream);
-        return rc;
-    }
+    if (B == 0) return sort ? pcg_pos_sort(g, s0, pos_keys, stream) : PCG_OK;
     pcg::ChooseArgs a;
     const int rc = choose_args(a, g, nodes, labels, B, s0, nullptr, pos_keys, thresholds, rho, train_flag, add_self, nullptr,
                                workspace, list_capacity, status);
     if (rc != PCG_OK) return rc;
-    hipStream_t st = static_cast<hipStream_t>(stream);
     const int rows = g->n_rel * B;
     pcg::PlanTotals *tot = reinterpret_cast<pcg::PlanTotals *>(a.w.plan_totals);
     const int n_count = (rows + pcg::FRONT_COUNT_THREADS - 1) / pcg::FRONT_COUNT_THREADS;
-    const int n_score = (int)pcg::score_table_blocks(g->n_nodes, g->feat_stride);
-    hipLaunchKernelGGL(pcg::front_a_kernel, dim3(n_count + n_score), dim3(pcg::FRONT_COUNT_THREADS), 0, st, a, tot, n_count, W, b,
-                       s0);
-    PCG_LAUNCH_CHECK();
     const int n_write = (rows + pcg::PLAN_THREADS - 1) / pcg::PLAN_THREADS;
     const bool rank = sort && g->n_pos <= pcg::RANK_MAX;
     const int n_sort = rank ? (g->n_pos + PCG_WAVE - 1) / PCG_WAVE : 0;
     const int64_t cap = sort ? pcg_pos_sort_capacity(g->n_pos) : 0;
-    hipLaunchKernelGGL(pcg::front_b_kernel, dim3(n_write + n_sort), dim3(pcg::PLAN_THREADS), 0, st, a, tot, n_write, n_count,
-                       pos_keys, (int)cap);
+    hipLaunchKernelGGL(pcg::front_b_kernel, dim3(n_write + n_sort), dim3(pcg::PLAN_THREADS), 0, static_cast<hipStream_t>(stream), a,
+                       tot, n_write, n_count, pos_keys, (int)cap);
     PCG_LAUNCH_CHECK();
     if (sort && !rank) return pcg_pos_sort(g, s0, pos_keys, stream);    // many positives: the chunk sort's own launches
     return PCG_OK;
+}
+
+int pcg_step_front(const pcg_graph_desc *g, const float *W, const float *b, float *s0, uint64_t *pos_keys,
+                   const int32_t *nodes, const int32_t *labels, int32_t B, const double *thresholds, const double *rho,
+                   int32_t train_flag, int32_t add_self, void *workspace, int64_t list_capacity, uint32_t *status,
+                   void *stream) {
+    if (!g) return PCG_E_ARG;
+    const int rc = pcg_step_front_a(g, W, b, 0, g->n_nodes, s0, nodes, labels, B, thresholds, rho, train_flag, add_self, workspace,
+                                    list_capacity, status, stream);
+    if (rc != PCG_OK) return rc;
+    return pcg_step_front_b(g, s0, pos_keys, nodes, labels, B, thresholds, rho, train_flag, add_self, workspace, list_capacity,
+                            status, stream);
 }
 
 int pcg_aggregate_lists(const float *X, int32_t feat_dim, int32_t feat_stride, int32_t n_rows, const int32_t *cnt,

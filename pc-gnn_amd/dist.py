@@ -284,13 +284,21 @@ class DistributedPCGNN:
             dist.all_reduce(t, group=self.group)
 
     # -- one step ---------------------------------------------------------------------------------
+    def _seg_scores(self, ids_local, labels, B, train_flag):
+        """collective-free segment 0: this rank's rows of the score table || plan pass 1 (pcg_step_front_a)."""
+        self.ops.step_front_a(self.g, self.w_clf, self.b_clf, self.s0_send, 0, self.part.n_local, ids_local,
+                              labels if train_flag else None, self.thresholds, self.rho, train_flag, self._ws_of(B))
+
     def _seg_select(self, ids_local, labels, B, train_flag):
-        """collective-free segment 1: train-pos sort, centre scores, plan + select (lists of global ids)."""
+        """collective-free segment 1 (after the score all-gather): train-pos sort || plan pass 2, centre scores,
+        select (lists of global ids)."""
         ops, g, part = self.ops, self.g, self.part
-        keys = ops.pos_sort(g, self.s0_full, self.keys) if (train_flag and g.n_pos) else None
+        ws = self._ws_of(B)
+        keys = ops.step_front_b(g, self.s0_full, self.keys, ids_local, labels if train_flag else None, self.thresholds,
+                                self.rho, train_flag, ws)
         self.center_buf[:B].copy_(self.s0_full[(ids_local.long() + part.lo)])
         ops.choose_select(g, ids_local, labels if train_flag else None, self.s0_full, keys, self.thresholds, self.rho,
-                          train_flag, self._ws_of(B), self.cnt[:g.R * B], center_s0=self.center_buf[:B])
+                          train_flag, ws, self.cnt[:g.R * B], center_s0=self.center_buf[:B], planned=True)
 
     def _seg_dense(self, ids_local, labels, B):
         """collective-free segment 2: gather + mean over the extended table, dense step, gradient reduction."""
@@ -322,7 +330,7 @@ class DistributedPCGNN:
         """steps 1-3 + aggregate: returns agg [R, B, F] for this rank's centres (local row numbers)."""
         ops, g, part = self.ops, self.g, self.part
         B = ids_local.numel()
-        ops.score_table(g, self.w_clf, self.b_clf, out=self.s0_send, row_begin=0, row_end=part.n_local)
+        self._seg_scores(ids_local, labels, B, train_flag)
         self._all_gather(self.s0_full, self.s0_send)
         self._seg_select(ids_local, labels, B, train_flag)
         self._exchange(B)
@@ -341,6 +349,7 @@ class DistributedPCGNN:
         s = torch.cuda.Stream(self.dev)            # warm-up: kernel attributes, auxiliary streams, workspaces
         s.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(s):
+            self._seg_scores(ids, lab, B, True)
             self._seg_select(ids, lab, B, True)
             self._seg_dense(ids, lab, B)
         torch.cuda.current_stream(self.dev).wait_stream(s)
@@ -367,7 +376,7 @@ class DistributedPCGNN:
             self.ids_buf[:B].copy_(ids_local)
             self.lab_buf[:B].copy_(labels)
             ids_local, labels = self.ids_buf[:B], self.lab_buf[:B]
-        ops.score_table(g, self.w_clf, self.b_clf, out=self.s0_send, row_begin=0, row_end=part.n_local)
+        self._seg_scores(ids_local, labels, B, True)
         self._all_gather(self.s0_full, self.s0_send)
         prof = getattr(self, "_prof", None)
         timed = prof is not None and self._prof_step % self._prof_every == 0

@@ -129,11 +129,13 @@ def _host_arrays(g, thresholds, rho):
 
 
 def choose_select(g: DeviceGraph, nodes, labels, s0, pos_keys, thresholds, rho, train_flag: bool, ws: ChooseWorkspace,
-                  cnt: torch.Tensor, add_self: bool = False, center_s0=None):
-    """plan + select only: every row's chosen ids into ws's selection list, |set| into cnt [R*B]."""
+                  cnt: torch.Tensor, add_self: bool = False, center_s0=None, planned: bool = False):
+    """plan + select only: every row's chosen ids into ws's selection list, |set| into cnt [R*B].
+    planned: ws already holds this batch's plan (step_front / step_front_a + _b)."""
     lib = _lib.load()
     thr, rhos = _host_arrays(g, thresholds, rho)
-    _lib.check(lib.pcg_choose_select(
+    fn = lib.pcg_choose_select_planned if planned else lib.pcg_choose_select
+    _lib.check(fn(
         g.desc_ref(), _p(nodes), _p(labels), nodes.numel(), _p(s0), _p(center_s0), _p(pos_keys), thr, rhos,
         1 if train_flag else 0, 1 if add_self else 0, _p(cnt), _p(ws.buf), ws.list_capacity, _p(ws.status),
         _stream(g.device)), "pcg_choose_select")
@@ -260,3 +262,27 @@ def pick_shuffled(cum: torch.Tensor, idx_train: torch.Tensor, k: int, seed: int,
                                      _p(labels_all), _p(out_ids), _p(out_labels), _stream(cum.device)),
                "pcg_pick_shuffled")
     return out_ids
+
+
+def step_front_a(g: DeviceGraph, W: torch.Tensor, b: torch.Tensor, s0_out: torch.Tensor, row_begin: int, row_end: int,
+                 nodes: torch.Tensor, labels: Optional[torch.Tensor], thresholds: Sequence[float], rho, train_flag: bool,
+                 ws: ChooseWorkspace, add_self: bool = False):
+    """first half of step_front: scores of rows [row_begin, row_end) (as score_table) || plan pass 1."""
+    lib = _lib.load()
+    thr, rhos = _host_arrays(g, thresholds, rho)
+    _lib.check(lib.pcg_step_front_a(g.desc_ref(), _p(W), _p(b), row_begin, row_end, _p(s0_out), _p(nodes), _p(labels),
+                                    nodes.numel(), thr, rhos, 1 if train_flag else 0, 1 if add_self else 0, _p(ws.buf),
+                                    ws.list_capacity, _p(ws.status), _stream(g.device)), "pcg_step_front_a")
+
+
+def step_front_b(g: DeviceGraph, s0: torch.Tensor, pos_keys: Optional[torch.Tensor], nodes: torch.Tensor,
+                 labels: Optional[torch.Tensor], thresholds: Sequence[float], rho, train_flag: bool, ws: ChooseWorkspace,
+                 add_self: bool = False):
+    """second half of step_front: train-pos sort by s0 || plan pass 2.  Returns the sorted keys (or None)."""
+    lib = _lib.load()
+    thr, rhos = _host_arrays(g, thresholds, rho)
+    sort = bool(train_flag) and g.n_pos > 0
+    _lib.check(lib.pcg_step_front_b(g.desc_ref(), _p(s0), _p(pos_keys) if sort else None, _p(nodes), _p(labels),
+                                    nodes.numel(), thr, rhos, 1 if train_flag else 0, 1 if add_self else 0, _p(ws.buf),
+                                    ws.list_capacity, _p(ws.status), _stream(g.device)), "pcg_step_front_b")
+    return pos_keys if sort else None
