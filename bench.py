@@ -15,9 +15,15 @@ N=1 workload: BASELINE.json configs[1] - YelpChi-shaped synthetic graph
 (N=45,954, F=32, 3 relations with 49,315 / 573,616 / 3,402,743 undirected edges,
 14.53 % positives, 40 % train), emb 64, batch 1024, rho 0.5.
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = choose_agg,
-HIP events inside the timed region) and `cpu_baseline` (the oracle port timed on
-the host cores on a bounded sample of the same batches; rank 0, N=1 only).
+Graph engine (default at N=1): an epoch - sampler + every batch's seven launches - is
+ONE hipGraph launch; the first epoch of the timed region and every `--event-every`-th
+after it are replayed batch by batch as [front graph] -> HIP event -> [select + gather
++ combine graph] -> HIP event -> [dense + Adam graph] (same kernels, same order): those
+events give the `roofline` object (dominant launch = select + aggregate).  N>1: the
+destination-node partitioned path (pc-gnn_amd/dist.py), weak scaling.
+
+Prints ONE JSON line (rank 0) with `roofline` and `cpu_baseline` (the oracle port timed
+on the host cores on the event-bracketed batches of the same run; rank 0, N=1 only).
 """
 import argparse
 import json
@@ -229,9 +235,7 @@ def main():
                     p.grad.copy_(flat[o:o + p.numel()].view_as(p))
                     o += p.numel()
             tr.opt.step()
-        elif epoch_graphs and not timed:
-            tr.fused.epoch_step(state["b"] - 1)
-        elif dist is None:
+        elif dist is None:        # (graph engine: the per-batch graphs; whole epochs go through run_epoch_one_graph below)
             tr.step(ids, timed)
         else:
             tr.fused.train_step(ids, tr.labels_i32[ids.long()], allreduce=allreduce)
@@ -270,9 +274,13 @@ def main():
         [front graph] -> event -> [select + aggregate graph] -> event -> [dense + Adam graph] (the same kernels in the
         same order); every other epoch that fits into the remaining steps is ONE graph launch."""
         k = 0
+        phase = {"epochs": 0 if (state["ids"] is None or state["b"] == nb) else 1}
         while k < n_steps:
             at_epoch_start = state["ids"] is None or state["b"] == nb
-            timed_epoch = engine != "graph" or (state["epoch"] - (0 if at_epoch_start else 1)) % args.event_every == 0
+            if at_epoch_start:
+                phase["epochs"] += 1
+            # the first epoch of a phase (warm-up, measurement) and every event_every-th after it are event-bracketed
+            timed_epoch = engine != "graph" or (phase["epochs"] - 1) % args.event_every == 0
             if epoch_graphs and at_epoch_start and not timed_epoch and k + nb <= n_steps:
                 tr.run_epoch_one_graph()             # pick + shuffle + labels + every batch's step: one graph launch
                 state["ids"], state["b"] = tr.fused._ep_ids[:tr.pick_size], nb
