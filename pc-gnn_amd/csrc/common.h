@@ -154,12 +154,30 @@ __device__ __forceinline__ void rank_sort_body(const float *__restrict__ s0, con
                                                int cap, uint64_t *__restrict__ keys, int block, uint64_t *sh, int *part) {
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int i = block * PCG_WAVE + lane;
-    const uint64_t mine = make_pos_key(s0, train_pos, i, n_pos);          // ~0 when i >= n_pos
+    // a key costs two dependent loads (train_pos[i], then s0 of it): this thread's own key and its share of a tile's keys
+    // are requested level by level, so the staging of a tile costs two load latencies in all
+    constexpr int PER = RANK_TILE / (RANK_WAVES * PCG_WAVE);
+    const int id_mine = i < n_pos ? train_pos[i] : 0;
+    uint64_t mine = ~0ull;                                                 // ~0 when i >= n_pos
     int c = 0;
     for (int t0 = 0; t0 < n_pos; t0 += RANK_TILE) {
         const int nt = (n_pos - t0 < RANK_TILE) ? n_pos - t0 : RANK_TILE;
+        int idt[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int t = (int)threadIdx.x + u * (int)blockDim.x;
+            idt[u] = t < nt ? train_pos[t0 + t] : 0;
+        }
+        float st[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) st[u] = s0[idt[u]];
+        if (t0 == 0 && i < n_pos) mine = ((uint64_t)orderable(s0[id_mine]) << 32) | (uint32_t)i;
         __syncthreads();
-        for (int t = threadIdx.x; t < nt; t += blockDim.x) sh[t] = make_pos_key(s0, train_pos, t0 + t, n_pos);
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int t = (int)threadIdx.x + u * (int)blockDim.x;
+            if (t < nt) sh[t] = ((uint64_t)orderable(st[u]) << 32) | (uint32_t)(t0 + t);
+        }
         __syncthreads();
         const int chunk = (nt + RANK_WAVES - 1) / RANK_WAVES;
         const int j0 = wave * chunk, j1 = (j0 + chunk < nt) ? j0 + chunk : nt;

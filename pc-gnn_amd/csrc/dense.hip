@@ -361,27 +361,44 @@ __global__ void __launch_bounds__(256) adam_reduce_kernel(float *__restrict__ th
                                                           const int32_t *__restrict__ step_counter, float lr,
                                                           float beta1, float beta2, float eps, float wd,
                                                           float *__restrict__ grad_out, int apply) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_params) return;
+    // 64 parameters per workgroup; the slabs are split over its 4 waves (each: 8 interleaved accumulators = 8 loads in
+    // flight), the four partial sums are added in wave order: a fixed order, and a quarter of the dependent load batches
+    __shared__ float part[4][PCG_WAVE];
+    const int lane = threadIdx.x & (PCG_WAVE - 1), w = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * PCG_WAVE + lane;
+    const bool ok = i < n_params;
+    const int per = (n_slabs + 3) / 4;
+    const int s_begin = w * per, s_end = (s_begin + per < n_slabs) ? s_begin + per : n_slabs;
+    // the optimizer state of wave 0's parameters is requested up front, behind nothing
+    float p = 0.f, m_old = 0.f, v_old = 0.f, t = 1.f;
+    if (w == 0 && ok && apply) {
+        p = theta[i];
+        m_old = m[i];
+        v_old = v[i];
+        t = (float)step_counter[0];
+    }
     float acc[ADAM_ACC];
 #pragma unroll
     for (int u = 0; u < ADAM_ACC; ++u) acc[u] = 0.f;
-    int s = 0;
-    for (; s + ADAM_ACC <= n_slabs; s += ADAM_ACC) {
+    int s = s_begin;
+    if (ok) {
+        for (; s + ADAM_ACC <= s_end; s += ADAM_ACC) {
 #pragma unroll
-        for (int u = 0; u < ADAM_ACC; ++u) acc[u] += slabs[(size_t)(s + u) * n_params + i];
+            for (int u = 0; u < ADAM_ACC; ++u) acc[u] += slabs[(size_t)(s + u) * n_params + i];
+        }
+        for (int u = 0; s < s_end; ++s, ++u) acc[u] += slabs[(size_t)s * n_params + i];
     }
-    for (int u = 0; s < n_slabs; ++s, ++u) acc[u] += slabs[(size_t)s * n_params + i];
-    float g = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    part[w][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    __syncthreads();
+    if (w != 0 || !ok) return;
+    float g = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
     if (grad_out) grad_out[i] = g;
     if (!apply) return;
-    const float p = theta[i];
     g = fmaf(wd, p, g);
-    const float mi = beta1 * m[i] + (1.f - beta1) * g;
-    const float vi = beta2 * v[i] + (1.f - beta2) * g * g;
+    const float mi = beta1 * m_old + (1.f - beta1) * g;
+    const float vi = beta2 * v_old + (1.f - beta2) * g * g;
     m[i] = mi;
     v[i] = vi;
-    const float t = (float)step_counter[0];
     const float bc1 = 1.f - powf(beta1, t), bc2 = 1.f - powf(beta2, t);
     const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
     theta[i] = p - (lr / bc1) * (mi / denom);
@@ -480,7 +497,7 @@ int pcg_adam_step(float *theta, float *m, float *v, const float *slabs, int32_t 
     if (!slabs || n_slabs < 0 || n_params < 1) return PCG_E_ARG;
     if (apply && (!theta || !m || !v || !step_counter)) return PCG_E_ARG;
     if (!apply && !grad_out) return PCG_E_ARG;
-    hipLaunchKernelGGL(pcg::adam_reduce_kernel, dim3((unsigned)((n_params + 255) / 256)), dim3(256), 0,
+    hipLaunchKernelGGL(pcg::adam_reduce_kernel, dim3((unsigned)((n_params + PCG_WAVE - 1) / PCG_WAVE)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), theta, m, v, slabs, n_slabs, n_params, step_counter, (float)lr,
                        (float)beta1, (float)beta2, (float)eps, (float)weight_decay, grad_out, apply);
     PCG_LAUNCH_CHECK();

@@ -201,7 +201,12 @@ __global__ void __launch_bounds__(SHUF_WAVES *PCG_WAVE) pick_shuffled_kernel(con
         __syncthreads();
         const int chunk = (nt + SHUF_WAVES - 1) / SHUF_WAVES;
         const int j0 = wave * chunk, j1 = (j0 + chunk < nt) ? j0 + chunk : nt;
-        for (int j = j0; j < j1; ++j) c += sh[j] < mine;
+        int j = j0;
+        for (; j + 4 <= j1; j += 4) {
+            const uint64_t a0 = sh[j], a1 = sh[j + 1], a2 = sh[j + 2], a3 = sh[j + 3];
+            c += (a0 < mine) + (a1 < mine) + (a2 < mine) + (a3 < mine);
+        }
+        for (; j < j1; ++j) c += sh[j] < mine;
     }
     part[wave * PCG_WAVE + lane] = c;
     __syncthreads();
