@@ -1,23 +1,24 @@
 // choose + aggregate for gfx950: the PC-GNN hot path in four kinds of launches.
 //
-//   plan     one workgroup: per (relation r, centre b) row the kept-count bound
-//            cap = (deg > k+1 ? k : deg) + m (+1), exclusive offsets into the selection
-//            list, the degree-tier queues and the 256-entry chunk table of the gather.
-//   select   one group per row, group size by row length (<=512: one wave, <=4096: a
-//            512-thread workgroup, longer: 1024 threads; > 8192 via global scratch):
-//              1. neighbour ids + distance keys |s0[c] - s0[j]| -> LDS (4 gathers in flight)
-//              2. exact k-th smallest key by a bracketed counting search (interpolation in
-//                 value space alternating with bit-space bisection; <= 64 survivors are
-//                 ranked on registers); ties by row position via ballot prefix counts
+//   plan     per (relation r, centre b) row the kept-count bound cap = (deg > k+1 ? k : deg) + m (+1), exclusive
+//            offsets into the selection list, four degree-tier queues and the 128-entry chunk table of the gather.
+//            One workgroup (plan_kernel), two passes of many (plan_count / plan_write), or the same two passes riding
+//            along the score pass and the train-pos sort (front_a / front_b: pcg_step_front).
+//   select   ONE persistent launch (select_rows): every workgroup takes hub rows (deg > 4096) and mid rows
+//            (513..4096) whole, then rows of <= 512 one per wave - longest first, statically assigned.  Per row:
+//              1. neighbour ids + distance keys |s0[c] - s0[j]| -> LDS (8 gathers in flight per lane)
+//              2. exact k-th smallest key by a bracketed counting search (two pivots by interpolation in value space,
+//                 every 4th round a bit-space midpoint; the first bracket's survivors compacted; <= 64 survivors
+//                 finished on registers); ties by row position via ballot prefix counts
 //              3. kept ids compacted (ascending) in LDS and written to the row's list
-//              4. minority over-sampling for positive centres: 64-ary window search in the
-//                 per-step sorted train-pos keys; de-duplicated against (3) by LDS binary
-//                 search; a duplicate leaves a hole (-1) so slots - and sums - keep a fixed order
-//   gather   chip-wide balanced: one wave per 256-entry chunk of a row's list, feature rows
-//            gathered 64/lpr per wave-instruction (128-B rows: 8 rows = 1 KiB), 8 in flight,
-//            f32 segmented sum; single-chunk rows are finished here
-//   combine  rows longer than one chunk: partial sums added in chunk order (bitwise
-//            reproducible), divided by |set| (or its sqrt)
+//              4. minority over-sampling for positive centres: 64-ary window search in the per-step sorted train-pos
+//                 keys; de-duplicated against (3) by LDS binary search; a duplicate leaves a hole (-1) so slots -
+//                 and sums - keep a fixed order
+//   gather   chip-wide balanced: one wave per 128-entry chunk of a row's list, feature rows gathered 64/lpr per
+//            wave-instruction (128-B rows: 8 rows = 1 KiB), 8 in flight, f32 segmented sum; single-chunk rows are
+//            finished here
+//   combine  rows longer than one chunk: partial sums added in chunk order (bitwise reproducible), divided by |set|
+//            (or its sqrt)
 //
 // Reference lines replaced: src/layers.py:217-219, 246-262, 587-624, 633-738;
 // src/graphsage.py:62-96, 200-232 (keep-all + add_self + sqrt normalisation).
@@ -42,7 +43,7 @@ constexpr int PLAN_PER = 4;      // rows per plan thread per tile
 constexpr int GATHER_BLOCKS = 2048;
 
 // counters (uint32) at the head of the workspace
-enum { C_N1 = 0, C_N4 = 1, C_N16 = 2, C_HEAD4 = 3, C_HEAD16 = 4, C_NCHUNK = 5, C_TOTAL_LO = 6, C_TOTAL_HI = 7, C_N0 = 8, C_HEAD1 = 9, C_HEAD0 = 10 };
+enum { C_N1 = 0, C_N4 = 1, C_N16 = 2, C_NCHUNK = 5, C_N0 = 8 };
 
 struct RowRec {            // 32 bytes, written by plan, read by select (one 32-B load instead of a 3-deep chain)
     int64_t start;         // offset of the row in indices[r]
@@ -169,10 +170,6 @@ __device__ __forceinline__ void tier_finish(const Workspace &w, const TierCounts
     w.counters[C_N1] = overflow ? 0 : t.n1;
     w.counters[C_N4] = overflow ? 0 : t.n4;
     w.counters[C_N16] = overflow ? 0 : t.n16;
-    w.counters[C_HEAD0] = 0;
-    w.counters[C_HEAD1] = 0;
-    w.counters[C_HEAD4] = 0;
-    w.counters[C_HEAD16] = 0;
 }
 // exclusive scan of one value per thread over the block; returns the block total through `total`
 template <typename T>
