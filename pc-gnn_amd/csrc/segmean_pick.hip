@@ -95,17 +95,6 @@ __device__ __forceinline__ double philox_uniform(uint64_t seed, uint64_t epoch, 
     return ((double)(c[0] >> 5) * 67108864.0 + (double)(c[1] >> 6)) * (1.0 / 9007199254740992.0);
 }
 
-// all four words of the Philox block of (seed, epoch, draw)
-__device__ __forceinline__ void philox_block(uint64_t seed, uint64_t epoch, uint32_t draw, uint32_t (&c)[4]) {
-    c[0] = draw; c[1] = 0u; c[2] = (uint32_t)epoch; c[3] = (uint32_t)(epoch >> 32);
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-    for (int r = 0; r < 10; ++r) {
-        philox_round(c, k0, k1);
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-}
-
 __device__ __forceinline__ int32_t pick_draw(const double *__restrict__ cum, const int32_t *__restrict__ idx_train, int n, double u) {
     const double x = u * (cum[n - 1] + 0.0);
     int lo = 0, hi = n - 1;
@@ -129,16 +118,21 @@ __global__ void __launch_bounds__(256) pick_kernel(const double *__restrict__ cu
 
 // An epoch's picks, shuffled, with their labels, in one launch (utils.py:274-278 + random.shuffle, model_handler.py:131-133).
 // Draw i is exactly pcg_pick's draw i of the same (seed, epoch).  Its place in the output is the rank of a shuffle key
-// (third Philox word of the same block, ties by i) among all k keys: a uniformly random permutation.  Every workgroup owns
+// (a 64-bit mix of seed, epoch and i; ties by i) among all k keys: a pseudo-random permutation.  Every workgroup owns
 // 64 draws and ranks them against all k keys, recomputed into LDS tiles (rank sort as for the train positives).
 constexpr int SHUF_TILE = 8192;
 constexpr int SHUF_WAVES = 16;
 
+// shuffle key of draw i: a 64-bit finalizer-style mix of (seed, epoch, i) (splitmix64 constants) - every workgroup
+// recomputes all k keys, so this must be cheap; ten Philox rounds per key made the kernel 3x longer - with i in the low
+// half so that keys are unique
 __device__ __forceinline__ uint64_t shuffle_key(uint64_t seed, uint64_t epoch, int i, int k) {
     if (i >= k) return ~0ull;
-    uint32_t c[4];
-    philox_block(seed, epoch, (uint32_t)i, c);
-    return ((uint64_t)c[2] << 32) | (uint32_t)i;
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (epoch + 1) + 0xD1B54A32D192ED03ull * (uint64_t)(uint32_t)i;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (z & 0xFFFFFFFF00000000ull) | (uint32_t)i;
 }
 
 // bisect_right(cum, x, 0, n-1) by a group of 16 lanes: 16 probes per step => ceil(log16 n) dependent loads instead of log2 n.
