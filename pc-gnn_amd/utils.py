@@ -91,6 +91,57 @@ def test(test_nodes, labels, model, batch_size: int, result=None, epoch: Optiona
     return m["auc"], m["recall"], m["f1_macro"], m["precision"]
 
 
+def get_best_f1(labels, probs, thresholds=None) -> Tuple[float, float]:
+    """Best positive-class F1 over the reference's 100 thresholds linspace(0.01, 0.99) and the threshold reaching it
+    (the "(f1)" variant, src/utils(f1).py:334-350: one sklearn f1_score call per threshold; the first threshold wins
+    ties).  Here: one sort of the confidences, then every threshold's TP / FP by binary search."""
+    y = np.asarray(labels).astype(np.int64)
+    p = np.asarray(probs, dtype=np.float64)
+    th = np.linspace(0.01, 0.99, 100) if thresholds is None else np.asarray(thresholds, dtype=np.float64)
+    order = np.argsort(p, kind="stable")
+    ps, ys = p[order], y[order]
+    pos_from = np.concatenate([np.cumsum(ys[::-1])[::-1], [0]])       # positives among ps[i:]
+    first = np.searchsorted(ps, th, side="right")                     # predictions 1: probs > thresh  (:345)
+    tp = pos_from[first].astype(np.float64)
+    n_pred = (len(ps) - first).astype(np.float64)
+    n_pos = float(ys.sum())
+    denom = n_pred + n_pos                                             # 2TP + FP + FN
+    f1 = np.where(denom > 0, 2.0 * tp / np.maximum(denom, 1.0), 0.0)
+    best_f1, best_t = 0.0, 0.0                                         # :342 (a threshold must beat 0 to be taken)
+    for f, t in zip(f1, th):
+        if f > best_f1:
+            best_f1, best_t = float(f), float(t)
+    return best_f1, best_t
+
+
+def test_f1(test_nodes, labels, model, batch_size: int, flag: str = "valid", valid_thresh: Optional[float] = None):
+    """The "(f1)" evaluation (src/utils(f1).py:280-332): F1-macro at the best validation threshold (flag "valid":
+    searched here and returned; otherwise ``valid_thresh`` is applied), the other metrics from the argmax prediction.
+    Returns (auc, recall, f1_macro, precision, threshold) like the reference."""
+    nodes = np.asarray(test_nodes)
+    y = np.asarray(labels)
+    outs = []
+    with torch.no_grad():
+        for start in range(0, len(nodes), batch_size):
+            batch = nodes[start:start + batch_size]
+            if hasattr(model, "predict"):
+                ids = torch.as_tensor(batch, dtype=torch.int32, device=model.dev)
+                outs.append(torch.sigmoid(model.predict(ids, None, False)[0]))
+            else:
+                outs.append(model.to_prob(batch.tolist(), y[start:start + batch_size], train_flag=False)[0])
+    prob = torch.cat(outs).float().cpu().numpy() if outs else np.zeros((0, 2), np.float32)
+    threshold = None
+    if flag == "valid":
+        _, threshold = get_best_f1(y, prob[:, 1])                     # :316-317
+        cut = threshold
+    else:
+        cut = valid_thresh                                            # :320
+    preds = (prob[:, 1] > cut).astype(np.int64)
+    f1_macro = 0.5 * (_prf(y, preds, 1)[2] + _prf(y, preds, 0)[2])    # :318 / :322
+    m = binary_metrics(y, prob.argmax(axis=1), prob[:, 1])            # :324-330
+    return m["auc"], m["recall"], f1_macro, m["precision"], threshold
+
+
 # ---- data helpers ------------------------------------------------------------------------------------
 def pos_neg_split(nodes, labels):
     """positive / negative node ids in input order (utils.py:256-271, which is O(n^2) there)."""

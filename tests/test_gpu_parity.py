@@ -534,6 +534,13 @@ def test_eval_loop_matches_reference_probabilities(P, case):
     fz = FusedPCGNN(m, c.lr, c.wd, max_batch=64)
     auc2, recall2, f1m2, prec2 = U.test(np.array(c.nodes), c.batch_labels, fz, batch_size=64, print_line=False)
     assert abs(auc2 - want["auc"]) < 1e-6 and abs(f1m2 - want["f1_macro"]) < 1e-6
+    # the "(f1)" evaluation (utils(f1).py:280-350): validation picks the threshold, the test split applies it
+    _, thr_want = U.get_best_f1(c.batch_labels, prob[:, 1])
+    auc3, _, f1m3, _, thr = U.test_f1(np.array(c.nodes), c.batch_labels, fz, batch_size=64, flag="valid")
+    preds = (prob[:, 1] > thr_want).astype(np.int64)
+    f1m_want = 0.5 * (U._prf(c.batch_labels, preds, 1)[2] + U._prf(c.batch_labels, preds, 0)[2])
+    assert abs(thr - thr_want) < 1e-12 and abs(auc3 - want["auc"]) < 1e-6 and abs(f1m3 - f1m_want) < 1e-6
+    assert U.test_f1(np.array(c.nodes), c.batch_labels, m, batch_size=50, flag="test", valid_thresh=thr)[4] is None
 
 
 # ---------------------------------------------------------------------------
