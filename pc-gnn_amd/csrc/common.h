@@ -90,7 +90,16 @@ __device__ __forceinline__ float score_reduce(float p, int lpr) {
 
 // ---- bodies shared by the stand-alone kernels and the fused step-front kernels (same code => same bits) ----------
 
-constexpr int SCORE_UNROLL = 8;
+#ifndef PCG_SCORE_UNROLL        // (tuning knobs of the score stream, overridable for scripts/score_bw.py)
+#define PCG_SCORE_UNROLL 8
+#endif
+#ifndef PCG_SCORE_BLOCKS_PER_CU
+#define PCG_SCORE_BLOCKS_PER_CU 4
+#endif
+#ifndef PCG_SCORE_NT
+#define PCG_SCORE_NT 1
+#endif
+constexpr int SCORE_UNROLL = PCG_SCORE_UNROLL;
 
 // class-0 logit of rows [row_begin, row_end): workgroup `block` of `n_blocks` (256 threads each), grid-stride
 __device__ __forceinline__ void score_table_body(const float *__restrict__ X, int feat_dim, int stride,
@@ -110,7 +119,7 @@ __device__ __forceinline__ void score_table_body(const float *__restrict__ X, in
 #pragma unroll
         for (int u = 0; u < SCORE_UNROLL; ++u) {
             const int64_t row = base + (int64_t)u * rpw + slot;
-            p[u] = row < row_end ? score_partial<true>(X + row * stride, W, feat_dim, stride, sub, lpr) : 0.f;
+            p[u] = row < row_end ? score_partial<PCG_SCORE_NT != 0>(X + row * stride, W, feat_dim, stride, sub, lpr) : 0.f;
         }
         // after the butterfly every lane of a row-group holds that row's sum: lane `sub` keeps the result of
         // unrolled row `sub`, so the wave writes its rpw * SCORE_UNROLL consecutive scores in ONE store
@@ -132,7 +141,7 @@ __host__ __forceinline__ int64_t score_table_blocks(int64_t n_rows, int stride) 
     const int rpw = PCG_WAVE / lanes_per_row(stride);
     const int64_t rows_per_block = (int64_t)4 * rpw * SCORE_UNROLL;
     int64_t blocks = (n_rows + rows_per_block - 1) / rows_per_block;
-    return blocks > 256 * 8 ? 256 * 8 : blocks;
+    return blocks > 256 * PCG_SCORE_BLOCKS_PER_CU ? 256 * PCG_SCORE_BLOCKS_PER_CU : blocks;
 }
 
 __device__ __forceinline__ uint64_t make_pos_key(const float *s0, const int32_t *train_pos, int i, int n_pos) {
