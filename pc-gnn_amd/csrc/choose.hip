@@ -640,7 +640,7 @@ __device__ __forceinline__ void select_row(const ChooseArgs &a, int row, uint32_
     const int tid = wave * PCG_WAVE + lane;
     constexpr int NT = NW * PCG_WAVE;
 
-    PCG_STAMP(0);
+    if (a.stamps && tid == 0) a.stamps[(size_t)row * 8] = wall_clock64() | ((unsigned long long)blockIdx.x << 54);   // + who ran it
     const RowRec p = a.w.recs[row];
     const int d = p.d, k = p.k, m = p.m, node = p.node;
     const bool keep_all = p.keep_all != 0;

@@ -4,11 +4,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pcgnn_amd
 from pcgnn_amd import synth, ops, _lib
 from pcgnn_amd.handler import PCGNNTrainer
-w = synth.yelp_like(0)
-tr = PCGNNTrainer(w, dict(engine="fused", batch_size=1024), torch.device("cuda", 0))
+B = int(os.environ.get("PROBE_B", "1024"))
+if os.environ.get("PROBE_WORKLOAD", "yelp") == "powerlaw":
+    w = synth.power_law(int(os.environ.get("PROBE_NODES", "2000000")), int(os.environ.get("PROBE_EDGES", "40000000")), 0)
+else:
+    w = synth.yelp_like(0)
+tr = PCGNNTrainer(w, dict(engine="fused", batch_size=B), torch.device("cuda", 0))
 fz = tr.fused; g = fz.g; lib = _lib.load()
 ids_all = tr.start_epoch(0)
-B = 1024; ids = ids_all[:B].contiguous(); lab = tr.labels_i32[ids.long()]
+ids = ids_all[:B].contiguous(); lab = tr.labels_i32[ids.long()]
 rows = g.R * B
 stamps = torch.zeros(rows + 1, 8, dtype=torch.int64, device="cuda")
 for it in range(3):
@@ -18,8 +22,11 @@ for it in range(3):
     torch.cuda.synchronize()
 lib.pcg_debug_set_stamps(None)
 plan = stamps[rows].cpu().numpy().astype(np.float64) * 0.01
-print('plan phases (us): load+rowplan %.2f, scans %.2f, writes %.2f; plan start -> first select start %.2f' % (plan[1]-plan[0], plan[2]-plan[1], plan[3]-plan[2], stamps[:rows,0].cpu().numpy().min()*0.01 - plan[0]))
-st = stamps[:rows].cpu().numpy().astype(np.float64) * 0.01   # us
+print('plan phases (us): load+rowplan %.2f, scans %.2f, writes %.2f; plan start -> first select start %.2f' % (plan[1]-plan[0], plan[2]-plan[1], plan[3]-plan[2], (stamps[:rows,0].cpu().numpy() & ((1 << 54) - 1)).min()*0.01 - plan[0]))
+raw = stamps[:rows].cpu().numpy()
+blk = (raw[:, 0] >> 54) & 0x3FF                                   # workgroup that ran the row
+raw[:, 0] &= (1 << 54) - 1
+st = raw.astype(np.float64) * 0.01   # us
 deg = np.stack([g.deg_host[r][ids.cpu().numpy()] for r in range(g.R)]).reshape(-1)
 t0 = st[:, 0].min()
 names = ["rec+keys(1)", "kth(2)", "compact+list(3)", "min-search(4)", "min-resolve(5)", "tail(6)"]
@@ -37,6 +44,21 @@ for lo, hi, tier in ((0, 512, "T1"), (512, 4096, "T4"), (4096, 1 << 30, "T16")):
     tot = s[:, 6] - s[:, 0]
     print(f"   total per row      mean {tot.mean():7.2f} us  max {tot.max():7.2f}")
 
+end = st[:, 6] - t0
+print("row end times (us): p50 %.1f p90 %.1f p99 %.1f max %.1f; rows still running after 50%% of the kernel: %d" % (
+    np.percentile(end, 50), np.percentile(end, 90), np.percentile(end, 99), end.max(), int((end > 0.5 * end.max()).sum())))
+bend = np.zeros(1024); bstart = np.full(1024, 1e18); brows = np.zeros(1024, dtype=int); bwide = np.zeros(1024, dtype=int)
+for r_ in range(rows):
+    b_ = int(blk[r_]); bend[b_] = max(bend[b_], end[r_]); bstart[b_] = min(bstart[b_], st[r_, 0] - t0); brows[b_] += 1; bwide[b_] += int(deg[r_] > 512)
+used_b = np.flatnonzero(brows)
+print("workgroups used %d; end time p50 %.1f p90 %.1f max %.1f; first-row start max %.1f" % (len(used_b), np.percentile(bend[used_b], 50), np.percentile(bend[used_b], 90), bend[used_b].max(), bstart[used_b].max()))
+late = used_b[np.argsort(-bend[used_b])][:8]
+for b_ in late:
+    sel_ = blk == b_
+    print(f"   wg {b_}: rows {brows[b_]} (wide {bwide[b_]}), first start {bstart[b_]:.1f}, end {bend[b_]:.1f}, sum of row times {(st[sel_,6]-st[sel_,0]).sum():.1f}, wide row time {(st[sel_ & (deg>512),6]-st[sel_ & (deg>512),0]).sum():.1f}")
+busy = (st[:, 6] - st[:, 0])
+print("sum of row times %.0f us -> %.1f us if spread evenly over 768 x 8 wave slots (wide rows use 8 slots each)" % (
+    busy.sum(), (busy * np.where(deg > 512, 8, 1)).sum() / (768 * 8)))
 rounds = (stamps[:rows].cpu().numpy()[:, 7] & 0xFFFFFFFF).astype(np.int64)
 ncand = (stamps[:rows].cpu().numpy()[:, 7] >> 32).astype(np.int64)
 kth = st[:, 2] - st[:, 1]
