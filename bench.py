@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--rho", type=float, default=0.5)
     ap.add_argument("--nodes", type=int, default=2_000_000, help="powerlaw only")
     ap.add_argument("--edges", type=int, default=40_000_000, help="powerlaw only")
-    ap.add_argument("--cpu-batches", type=int, default=12, help="oracle batches timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-batches", type=int, default=24, help="oracle batches timed for cpu_baseline (0 = skip)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-epoch-graphs", action="store_true", help="graph engine: copy each batch into a static buffer "
                     "instead of staging the whole epoch (A/B switch)")
