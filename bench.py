@@ -329,7 +329,8 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(args.workload, {}).get("choose_agg_bytes_per_launch")
+                tkey = args.workload if args.workload != "powerlaw" else f"powerlaw_{args.nodes}_{args.edges}_b{B}"
+                traffic = json.load(open(tpath)).get(tkey, {}).get("choose_agg_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
