@@ -87,8 +87,8 @@ int pcg_score_rows(const pcg_graph_desc *g, const float *W, const float *b,
 /* Sort the training positives by class-0 logit once per step; replaces the
  * per-centre torch.sort over all of pos_scores (layers.py:683-688).
  * keys [pcg_pos_sort_capacity(n_pos)] uint64; on return its first ceil_pow2(max(n_pos, 4096)) entries hold
- * (orderable(s0[train_pos[p]]) << 32) | p ascending, padded with UINT64_MAX (for n_pos > 16384 the capacity is twice
- * that: the second half is scratch of the chunk-sort path). */
+ * (orderable(s0[train_pos[p]]) << 32) | p ascending, padded with UINT64_MAX; the capacity is twice that: the second
+ * half is scratch (the chunk-sort path for n_pos > 16384; the unsorted keys pcg_step_front forms beside the score pass). */
 int64_t pcg_pos_sort_capacity(int32_t n_pos);
 int pcg_pos_sort(const pcg_graph_desc *g, const float *s0, uint64_t *keys, void *stream);
 
@@ -158,15 +158,18 @@ int pcg_step_front(const pcg_graph_desc *g, const float *W, const float *b, floa
                    uint32_t *status, void *stream);
 /* The two halves of pcg_step_front on their own, for callers that need something between them (the partitioned
  * path all-gathers the scores): _a = scores of rows [row_begin, row_end) into s0_out[row] (as pcg_score_table) || plan
- * pass 1;  _b = train-pos sort by s0 || plan pass 2.  Same plan arguments in both. */
+ * pass 1;  _b = train-pos sort by s0 || plan pass 2.  Same plan arguments in both.
+ * _a with pos_keys != NULL (training, 0 < n_pos <= 16384, every train-pos row present in g->X) also forms the unsorted keys
+ * from the feature rows in the scratch half of pos_keys (a third group of workgroups); pass raw_keys_ready = 1 to _b then,
+ * and its sort stages them with coalesced loads instead of gathering n_pos scores in every sort workgroup. */
 int pcg_step_front_a(const pcg_graph_desc *g, const float *W, const float *b, int64_t row_begin, int64_t row_end,
-                     float *s0_out, const int32_t *nodes, const int32_t *labels, int32_t B, const double *thresholds,
+                     float *s0_out, uint64_t *pos_keys, const int32_t *nodes, const int32_t *labels, int32_t B,
+                     const double *thresholds, const double *rho, int32_t train_flag, int32_t add_self,
+                     void *workspace, int64_t list_capacity, uint32_t *status, void *stream);
+int pcg_step_front_b(const pcg_graph_desc *g, const float *s0, uint64_t *pos_keys, int32_t raw_keys_ready,
+                     const int32_t *nodes, const int32_t *labels, int32_t B, const double *thresholds,
                      const double *rho, int32_t train_flag, int32_t add_self, void *workspace, int64_t list_capacity,
                      uint32_t *status, void *stream);
-int pcg_step_front_b(const pcg_graph_desc *g, const float *s0, uint64_t *pos_keys, const int32_t *nodes,
-                     const int32_t *labels, int32_t B, const double *thresholds, const double *rho,
-                     int32_t train_flag, int32_t add_self, void *workspace, int64_t list_capacity, uint32_t *status,
-                     void *stream);
 int pcg_choose_select_planned(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B,
                               const float *s0, const float *center_s0, const uint64_t *pos_keys,
                               const double *thresholds, const double *rho, int32_t train_flag, int32_t add_self,

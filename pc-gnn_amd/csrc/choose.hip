@@ -420,23 +420,29 @@ __global__ void __launch_bounds__(PLAN_THREADS) plan_write(const ChooseArgs a, c
 constexpr int FRONT_COUNT_THREADS = 256;
 
 __global__ void __launch_bounds__(FRONT_COUNT_THREADS) front_a_kernel(const ChooseArgs a, PlanTotals *totals, int n_plan_blocks,
+                                                                      int n_key_blocks, uint64_t *__restrict__ raw_keys,
                                                                       const float *__restrict__ W, const float *__restrict__ bias,
                                                                       int64_t row_begin, int64_t row_end, float *__restrict__ s0) {
-    if ((int)blockIdx.x < n_plan_blocks)
-        plan_count_body<FRONT_COUNT_THREADS>(a, totals, (int)blockIdx.x);
+    const int b = (int)blockIdx.x;
+    if (b < n_plan_blocks)
+        plan_count_body<FRONT_COUNT_THREADS>(a, totals, b);
+    else if (b < n_plan_blocks + n_key_blocks)      // the train positives' sort keys, from their feature rows
+        pos_key_body(a.g.X, a.g.feat_dim, a.g.feat_stride, W, bias, a.g.train_pos, a.g.n_pos, raw_keys, b - n_plan_blocks,
+                     n_key_blocks);
     else
-        score_table_body(a.g.X, a.g.feat_dim, a.g.feat_stride, W, bias, row_begin, row_end, s0, (int)blockIdx.x - n_plan_blocks,
-                         (int)gridDim.x - n_plan_blocks);
+        score_table_body(a.g.X, a.g.feat_dim, a.g.feat_stride, W, bias, row_begin, row_end, s0,
+                         b - n_plan_blocks - n_key_blocks, (int)gridDim.x - n_plan_blocks - n_key_blocks);
 }
 
 __global__ void __launch_bounds__(PLAN_THREADS) front_b_kernel(const ChooseArgs a, const PlanTotals *totals, int n_write_blocks,
-                                                               int n_count_blocks, uint64_t *__restrict__ keys, int cap) {
+                                                               int n_count_blocks, uint64_t *__restrict__ keys, int cap,
+                                                               const uint64_t *__restrict__ raw_keys) {
     __shared__ uint64_t sh[RANK_TILE];
     __shared__ int part[RANK_WAVES * PCG_WAVE];
     if ((int)blockIdx.x < n_write_blocks)
         plan_write_body<PLAN_THREADS, FRONT_COUNT_THREADS>(a, totals, (int)blockIdx.x, n_count_blocks);
     else
-        rank_sort_body(a.s0, a.g.train_pos, a.g.n_pos, cap, keys, (int)blockIdx.x - n_write_blocks, sh, part);
+        rank_sort_body(a.s0, a.g.train_pos, a.g.n_pos, cap, keys, (int)blockIdx.x - n_write_blocks, sh, part, raw_keys);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1362,14 +1368,14 @@ int pcg_choose_select_planned(const pcg_graph_desc *g, const int32_t *nodes, con
 
 /* first half: class-0 logits of rows [row_begin, row_end) -> s0_out[row]  ||  plan pass 1 */
 int pcg_step_front_a(const pcg_graph_desc *g, const float *W, const float *b, int64_t row_begin, int64_t row_end,
-                     float *s0_out, const int32_t *nodes, const int32_t *labels, int32_t B, const double *thresholds,
-                     const double *rho, int32_t train_flag, int32_t add_self, void *workspace, int64_t list_capacity,
-                     uint32_t *status, void *stream) {
+                     float *s0_out, uint64_t *pos_keys, const int32_t *nodes, const int32_t *labels, int32_t B,
+                     const double *thresholds, const double *rho, int32_t train_flag, int32_t add_self, void *workspace,
+                     int64_t list_capacity, uint32_t *status, void *stream) {
     if (!g || !g->X || !W || !b || !s0_out || B < 0) return PCG_E_ARG;
     if (g->feat_dim < 1 || g->feat_stride < g->feat_dim || g->feat_stride % 4 != 0) return PCG_E_ARG;
     if ((reinterpret_cast<uintptr_t>(g->X) & 15u) != 0) return PCG_E_ARG;
     if (row_begin < 0 || row_end > g->n_nodes || row_begin > row_end) return PCG_E_ARG;
-    if (B == 0) return pcg_score_table(g, W, b, row_begin, row_end, s0_out, stream);
+    if (B == 0) return pcg_score_table(g, W, b, row_begin, row_end, s0_out, stream);   // (then _b gathers its keys itself)
     pcg::ChooseArgs a;
     const int rc = choose_args(a, g, nodes, labels, B, nullptr, nullptr, nullptr, thresholds, rho, train_flag, add_self, nullptr,
                                workspace, list_capacity, status, true);
@@ -1378,16 +1384,23 @@ int pcg_step_front_a(const pcg_graph_desc *g, const float *W, const float *b, in
     pcg::PlanTotals *tot = reinterpret_cast<pcg::PlanTotals *>(a.w.plan_totals);
     const int n_count = (rows + pcg::FRONT_COUNT_THREADS - 1) / pcg::FRONT_COUNT_THREADS;
     const int n_score = (int)pcg::score_table_blocks(row_end - row_begin, g->feat_stride);
-    hipLaunchKernelGGL(pcg::front_a_kernel, dim3(n_count + n_score), dim3(pcg::FRONT_COUNT_THREADS), 0,
-                       static_cast<hipStream_t>(stream), a, tot, n_count, W, b, row_begin, row_end, s0_out);
+    // the train positives' unsorted keys go to the scratch half of pos_keys (rank-sort sizes only)
+    const bool raw = pos_keys && train_flag && g->n_pos > 0 && g->n_pos <= pcg::RANK_MAX && g->train_pos;
+    const int rows_per_block = 4 * (PCG_WAVE / pcg::lanes_per_row(g->feat_stride));
+    int n_key = raw ? (g->n_pos + rows_per_block - 1) / rows_per_block : 0;
+    if (n_key > 256) n_key = 256;
+    uint64_t *raw_keys = raw ? pos_keys + pcg_pos_sort_capacity(g->n_pos) / 2 : nullptr;
+    hipLaunchKernelGGL(pcg::front_a_kernel, dim3(n_count + n_key + n_score), dim3(pcg::FRONT_COUNT_THREADS), 0,
+                       static_cast<hipStream_t>(stream), a, tot, n_count, n_key, raw_keys, W, b, row_begin, row_end, s0_out);
     PCG_LAUNCH_CHECK();
     return PCG_OK;
 }
 
 /* second half: train-pos sort by s0 (if train_flag and n_pos > 0)  ||  plan pass 2 */
-int pcg_step_front_b(const pcg_graph_desc *g, const float *s0, uint64_t *pos_keys, const int32_t *nodes,
-                     const int32_t *labels, int32_t B, const double *thresholds, const double *rho, int32_t train_flag,
-                     int32_t add_self, void *workspace, int64_t list_capacity, uint32_t *status, void *stream) {
+int pcg_step_front_b(const pcg_graph_desc *g, const float *s0, uint64_t *pos_keys, int32_t raw_keys_ready,
+                     const int32_t *nodes, const int32_t *labels, int32_t B, const double *thresholds, const double *rho,
+                     int32_t train_flag, int32_t add_self, void *workspace, int64_t list_capacity, uint32_t *status,
+                     void *stream) {
     if (!g || !s0 || B < 0) return PCG_E_ARG;
     const bool sort = train_flag && g->n_pos > 0;
     if (sort && (!pos_keys || !g->train_pos)) return PCG_E_ARG;
@@ -1402,9 +1415,10 @@ int pcg_step_front_b(const pcg_graph_desc *g, const float *s0, uint64_t *pos_key
     const int n_write = (rows + pcg::PLAN_THREADS - 1) / pcg::PLAN_THREADS;
     const bool rank = sort && g->n_pos <= pcg::RANK_MAX;
     const int n_sort = rank ? (g->n_pos + PCG_WAVE - 1) / PCG_WAVE : 0;
-    const int64_t cap = sort ? pcg_pos_sort_capacity(g->n_pos) : 0;
+    const int64_t cap = sort ? pcg_pos_sort_capacity(g->n_pos) / 2 : 0;
+    const uint64_t *raw_keys = (rank && raw_keys_ready) ? pos_keys + cap : nullptr;
     hipLaunchKernelGGL(pcg::front_b_kernel, dim3(n_write + n_sort), dim3(pcg::PLAN_THREADS), 0, static_cast<hipStream_t>(stream), a,
-                       tot, n_write, n_count, pos_keys, (int)cap);
+                       tot, n_write, n_count, pos_keys, (int)cap, raw_keys);
     PCG_LAUNCH_CHECK();
     if (sort && !rank) return pcg_pos_sort(g, s0, pos_keys, stream);    // many positives: the chunk sort's own launches
     return PCG_OK;
@@ -1415,11 +1429,11 @@ int pcg_step_front(const pcg_graph_desc *g, const float *W, const float *b, floa
                    int32_t train_flag, int32_t add_self, void *workspace, int64_t list_capacity, uint32_t *status,
                    void *stream) {
     if (!g) return PCG_E_ARG;
-    const int rc = pcg_step_front_a(g, W, b, 0, g->n_nodes, s0, nodes, labels, B, thresholds, rho, train_flag, add_self, workspace,
-                                    list_capacity, status, stream);
+    const int rc = pcg_step_front_a(g, W, b, 0, g->n_nodes, s0, pos_keys, nodes, labels, B, thresholds, rho, train_flag, add_self,
+                                    workspace, list_capacity, status, stream);
     if (rc != PCG_OK) return rc;
-    return pcg_step_front_b(g, s0, pos_keys, nodes, labels, B, thresholds, rho, train_flag, add_self, workspace, list_capacity,
-                            status, stream);
+    return pcg_step_front_b(g, s0, pos_keys, B > 0 ? 1 : 0, nodes, labels, B, thresholds, rho, train_flag, add_self, workspace,
+                            list_capacity, status, stream);
 }
 
 int pcg_aggregate_lists(const float *X, int32_t feat_dim, int32_t feat_stride, int32_t n_rows, const int32_t *cnt,

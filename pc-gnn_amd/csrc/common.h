@@ -149,6 +149,28 @@ __device__ __forceinline__ uint64_t make_pos_key(const float *s0, const int32_t 
     return ((uint64_t)orderable(s0[train_pos[i]]) << 32) | (uint32_t)i;
 }
 
+// raw[i] = make_pos_key(i) computed from the feature rows themselves (the same partial dot + butterfly as the score table,
+// so the same bits as s0[train_pos[i]]): lets the keys be formed beside the score pass instead of after it.
+// workgroup `block` of `n_blocks`, 256 threads.
+__device__ __forceinline__ void pos_key_body(const float *__restrict__ X, int feat_dim, int stride, const float *__restrict__ W,
+                                             const float *__restrict__ bias, const int32_t *__restrict__ train_pos, int n_pos,
+                                             uint64_t *__restrict__ raw, int block, int n_blocks) {
+    const int lane = lane_id();
+    const int lpr = lanes_per_row(stride);
+    const int rpw = PCG_WAVE / lpr;
+    const int slot = lane / lpr, sub = lane % lpr;
+    const float b0 = bias[0];
+    const int waves = n_blocks * (int)(blockDim.x >> 6);
+    for (int base = (block * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6)) * rpw; base < n_pos; base += waves * rpw) {
+        const int i = base + slot;
+        const bool ok = i < n_pos;
+        const float *row = X + (size_t)(ok ? train_pos[i] : 0) * stride;
+        float p = ok ? score_partial(row, W, feat_dim, stride, sub, lpr) : 0.f;
+        p = score_reduce(p, lpr);
+        if (ok && sub == 0) raw[i] = ((uint64_t)orderable(p + b0) << 32) | (uint32_t)i;
+    }
+}
+
 // ---- rank sort of the train-pos keys: one launch, no step barriers (n_pos <= RANK_MAX) -------------------
 // Keys are unique, so rank(i) = #{j : key_j < key_i} is a permutation.  Every workgroup owns 64 keys
 // (one per lane), walks all keys in LDS tiles of RANK_TILE and splits each tile's j-range over its
@@ -159,18 +181,36 @@ constexpr int RANK_TILE = 8192;
 constexpr int RANK_WAVES = 16;
 
 // sh: RANK_TILE uint64, part: RANK_WAVES * 64 ints (LDS); workgroup `block` of ceil(n_pos / 64), 1024 threads
+// raw: the unsorted keys (make_pos_key of every i < n_pos), if somebody has formed them already (pos_key_body) - then a
+// tile is staged with coalesced 8-byte loads instead of two dependent loads and a random 4-byte gather per key
 __device__ __forceinline__ void rank_sort_body(const float *__restrict__ s0, const int32_t *__restrict__ train_pos, int n_pos,
-                                               int cap, uint64_t *__restrict__ keys, int block, uint64_t *sh, int *part) {
+                                               int cap, uint64_t *__restrict__ keys, int block, uint64_t *sh, int *part,
+                                               const uint64_t *__restrict__ raw = nullptr) {
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int i = block * PCG_WAVE + lane;
     // a key costs two dependent loads (train_pos[i], then s0 of it): this thread's own key and its share of a tile's keys
     // are requested level by level, so the staging of a tile costs two load latencies in all
     constexpr int PER = RANK_TILE / (RANK_WAVES * PCG_WAVE);
-    const int id_mine = i < n_pos ? train_pos[i] : 0;
-    uint64_t mine = ~0ull;                                                 // ~0 when i >= n_pos
+    const int id_mine = (!raw && i < n_pos) ? train_pos[i] : 0;
+    uint64_t mine = (raw && i < n_pos) ? raw[i] : ~0ull;                   // ~0 when i >= n_pos
     int c = 0;
     for (int t0 = 0; t0 < n_pos; t0 += RANK_TILE) {
         const int nt = (n_pos - t0 < RANK_TILE) ? n_pos - t0 : RANK_TILE;
+        if (raw) {
+            uint64_t kt[PER];
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const int t = (int)threadIdx.x + u * (int)blockDim.x;
+                kt[u] = t < nt ? raw[t0 + t] : ~0ull;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const int t = (int)threadIdx.x + u * (int)blockDim.x;
+                if (t < nt) sh[t] = kt[u];
+            }
+            __syncthreads();
+        } else {
         int idt[PER];
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
@@ -188,6 +228,7 @@ __device__ __forceinline__ void rank_sort_body(const float *__restrict__ s0, con
             if (t < nt) sh[t] = ((uint64_t)orderable(st[u]) << 32) | (uint32_t)(t0 + t);
         }
         __syncthreads();
+        }
         const int chunk = (nt + RANK_WAVES - 1) / RANK_WAVES;
         const int j0 = wave * chunk, j1 = (j0 + chunk < nt) ? j0 + chunk : nt;
         int j = j0;

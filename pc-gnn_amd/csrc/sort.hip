@@ -95,7 +95,7 @@ extern "C" {
 int64_t pcg_pos_sort_capacity(int32_t n_pos) {
     if (n_pos < 0) return PCG_E_ARG;
     const int64_t cap = pcg::sort_capacity(n_pos);
-    return n_pos <= pcg::RANK_MAX ? cap : 2 * cap;     // the chunk-sort path needs a second buffer of the same size
+    return 2 * cap;     // second half: the chunk-sort path's buffer / the unsorted keys pcg_step_front forms beside the score pass
 }
 
 int pcg_pos_sort(const pcg_graph_desc *g, const float *s0, uint64_t *keys, void *stream) {

@@ -270,7 +270,7 @@ def step_front_a(g: DeviceGraph, W: torch.Tensor, b: torch.Tensor, s0_out: torch
     """first half of step_front: scores of rows [row_begin, row_end) (as score_table) || plan pass 1."""
     lib = _lib.load()
     thr, rhos = _host_arrays(g, thresholds, rho)
-    _lib.check(lib.pcg_step_front_a(g.desc_ref(), _p(W), _p(b), row_begin, row_end, _p(s0_out), _p(nodes), _p(labels),
+    _lib.check(lib.pcg_step_front_a(g.desc_ref(), _p(W), _p(b), row_begin, row_end, _p(s0_out), None, _p(nodes), _p(labels),
                                     nodes.numel(), thr, rhos, 1 if train_flag else 0, 1 if add_self else 0, _p(ws.buf),
                                     ws.list_capacity, _p(ws.status), _stream(g.device)), "pcg_step_front_a")
 
@@ -282,7 +282,7 @@ def step_front_b(g: DeviceGraph, s0: torch.Tensor, pos_keys: Optional[torch.Tens
     lib = _lib.load()
     thr, rhos = _host_arrays(g, thresholds, rho)
     sort = bool(train_flag) and g.n_pos > 0
-    _lib.check(lib.pcg_step_front_b(g.desc_ref(), _p(s0), _p(pos_keys) if sort else None, _p(nodes), _p(labels),
+    _lib.check(lib.pcg_step_front_b(g.desc_ref(), _p(s0), _p(pos_keys) if sort else None, 0, _p(nodes), _p(labels),
                                     nodes.numel(), thr, rhos, 1 if train_flag else 0, 1 if add_self else 0, _p(ws.buf),
                                     ws.list_capacity, _p(ws.status), _stream(g.device)), "pcg_step_front_b")
     return pos_keys if sort else None

@@ -42,7 +42,7 @@ def test_host_helpers_and_argument_checks():
                 want = (k if deg > k + 1 else deg) + min(int(k * rho), 7)
                 assert lib.pcg_sel_capacity_row(deg, thr, rho, 1, 7, 0) == want
                 assert lib.pcg_sel_capacity_row(deg, thr, rho, 0, 7, 1) == (k if deg > k + 1 else deg) + 1
-    assert lib.pcg_pos_sort_capacity(0) == 4096 and lib.pcg_pos_sort_capacity(4097) == 8192 and lib.pcg_pos_sort_capacity(20000) == 65536
+    assert lib.pcg_pos_sort_capacity(0) == 8192 and lib.pcg_pos_sort_capacity(4097) == 16384 and lib.pcg_pos_sort_capacity(20000) == 65536
     # null / inconsistent arguments are rejected before any launch
     assert lib.pcg_score_table(None, None, None, 0, 0, None, None) == _lib.PCG_E_ARG
     assert lib.pcg_pick(None, None, 0, None, 0, 0, 1, None, None) == _lib.PCG_E_ARG
