@@ -208,11 +208,11 @@ int pcg_pick(const double *cum, const int32_t *idx_train, int32_t n_train,
 
 /* One epoch's picks, shuffled, with their labels, in one launch: pick (src/utils.py:274-278) + random.shuffle
  * (src/model_handler.py:131-133) + the label lookup of the batch loop (:147).  Draw i is pcg_pick's draw i of
- * (seed, epoch); its output position is the rank of a 64-bit mix of (seed, epoch, i) among all k draws (a pseudo-random
- * permutation; equal keys ordered by i).  epoch = epoch_base + (epoch_counter[0] if given); with
- * bump != 0 the last workgroup to finish increments epoch_counter[0], so a captured graph replays a new epoch each
- * time.  epoch_counter is TWO uint64 words, zero-initialised by the caller: [0] the epoch, [1] scratch of the kernel.
- * labels_all: int32 label of every node (or NULL with out_labels NULL).  k <= 131072. */
+ * (seed, epoch); it is stored at position sigma(i), sigma a keyed pseudo-random permutation of [0, k) (an invertible
+ * integer mix on the next power of two, cycle-walked into [0, k)).  epoch = epoch_base + (epoch_counter[0] if given); with
+ * bump != 0 a second, one-thread launch increments epoch_counter[0] afterwards, so a captured graph replays a new epoch
+ * each time.  epoch_counter points to TWO zero-initialised uint64 words ([1] is reserved).
+ * labels_all: int32 label of every node (or NULL with out_labels NULL). */
 int pcg_pick_shuffled(const double *cum, const int32_t *idx_train, int32_t n_train, uint64_t seed, uint64_t epoch_base,
                       uint64_t *epoch_counter, int32_t bump, int32_t k, const int32_t *labels_all, int32_t *out_ids,
                       int32_t *out_labels, void *stream);

@@ -117,22 +117,41 @@ __global__ void __launch_bounds__(256) pick_kernel(const double *__restrict__ cu
 }
 
 // An epoch's picks, shuffled, with their labels, in one launch (utils.py:274-278 + random.shuffle, model_handler.py:131-133).
-// Draw i is exactly pcg_pick's draw i of the same (seed, epoch).  Its place in the output is the rank of a shuffle key
-// (a 64-bit mix of seed, epoch and i; ties by i) among all k keys: a pseudo-random permutation.  Every workgroup owns
-// 64 draws and ranks them against all k keys, recomputed into LDS tiles (rank sort as for the train positives).
-constexpr int SHUF_TILE = 8192;
-constexpr int SHUF_WAVES = 16;
-
-// shuffle key of draw i: a 64-bit finalizer-style mix of (seed, epoch, i) (splitmix64 constants) - every workgroup
-// recomputes all k keys, so this must be cheap; ten Philox rounds per key made the kernel 3x longer - with i in the low
-// half so that keys are unique
-__device__ __forceinline__ uint64_t shuffle_key(uint64_t seed, uint64_t epoch, int i, int k) {
-    if (i >= k) return ~0ull;
-    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (epoch + 1) + 0xD1B54A32D192ED03ull * (uint64_t)(uint32_t)i;
+// Draw i is exactly pcg_pick's draw i of the same (seed, epoch); it is stored at position sigma(i), sigma a keyed
+// pseudo-random permutation of [0, k).
+// A keyed bijection on [0, 2^bits): additions, odd multiplications and xor-shifts modulo 2^bits are each invertible.
+__device__ __forceinline__ uint32_t permute_bits(uint32_t x, int bits, uint64_t key) {
+    if (bits == 0) return 0u;
+    const uint32_t mask = bits >= 32 ? 0xFFFFFFFFu : ((1u << bits) - 1u);
+    const uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+    const int h = (bits + 1) >> 1, t = (bits + 2) / 3;
+    x = (x + k0) & mask;
+    x = (x * 0x9E3779B1u) & mask;
+    x ^= x >> h;
+    x = (x * ((k1 << 1) | 1u)) & mask;
+    x ^= x >> t;
+    x = (x + (k1 ^ 0x85EBCA6Bu)) & mask;
+    x = (x * 0xC2B2AE35u) & mask;
+    x ^= x >> h;
+    x = (x * (((k0 >> 3) << 1) | 1u)) & mask;
+    x ^= x >> t;
+    return x;
+}
+// The shuffle: draw i goes to position sigma(i), sigma = the bijection above restricted to [0, k) by cycle walking
+// (follow the permutation of [0, 2^bits) from i until it lands below k again: a bijection of [0, k), on average
+// < 2 steps).  O(1) per draw, nothing shared between draws - the rank-of-random-keys shuffle it replaces was O(k^2).
+__device__ __forceinline__ int shuffle_position(int i, int k, int bits, uint64_t key) {
+    uint32_t p = (uint32_t)i;
+    do {
+        p = permute_bits(p, bits, key);
+    } while (p >= (uint32_t)k);
+    return (int)p;
+}
+__device__ __forceinline__ uint64_t shuffle_key_of(uint64_t seed, uint64_t epoch) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (epoch + 1);
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return (z & 0xFFFFFFFF00000000ull) | (uint32_t)i;
+    return z ^ (z >> 31);
 }
 
 // bisect_right(cum, x, 0, n-1) by a group of 16 lanes: 16 probes per step => ceil(log16 n) dependent loads instead of log2 n.
@@ -166,60 +185,23 @@ __device__ __forceinline__ int bisect16(const double *__restrict__ cum, int n, d
     return lo;
 }
 
-__global__ void __launch_bounds__(SHUF_WAVES *PCG_WAVE) pick_shuffled_kernel(const double *__restrict__ cum, const int32_t *__restrict__ idx_train,
-                                                                             int n, uint64_t seed, uint64_t epoch_base,
-                                                                             unsigned long long *__restrict__ epoch_counter, int bump,
-                                                                             unsigned int *__restrict__ done, int k,
-                                                                             const int32_t *__restrict__ labels_all,
-                                                                             int32_t *__restrict__ out_ids, int32_t *__restrict__ out_labels) {
-    __shared__ uint64_t sh[SHUF_TILE];
-    __shared__ int part[SHUF_WAVES * PCG_WAVE];
-    __shared__ int32_t drawn[PCG_WAVE];
+// 16 draws per 256-thread workgroup: 16 lanes per draw run the 16-ary search, lane 0 of the group stores the draw at
+// its shuffled position.
+__global__ void __launch_bounds__(256) pick_shuffled_kernel(const double *__restrict__ cum, const int32_t *__restrict__ idx_train, int n,
+                                                            uint64_t seed, uint64_t epoch_base,
+                                                            const unsigned long long *__restrict__ epoch_counter, int k, int bits,
+                                                            const int32_t *__restrict__ labels_all, int32_t *__restrict__ out_ids,
+                                                            int32_t *__restrict__ out_labels) {
     const uint64_t epoch = epoch_base + (epoch_counter ? *epoch_counter : 0ull);
-    const int lane = lane_id(), wave = threadIdx.x >> 6;
-    const int i = blockIdx.x * PCG_WAVE + lane;
-    const uint64_t mine = shuffle_key(seed, epoch, i, k);
-    // this workgroup's 64 draws: 16 lanes per draw (1024 threads), a 16-ary search each
-    {
-        const int dl = threadIdx.x >> 4, sub = threadIdx.x & 15;          // draw slot 0..63, lane in the group
-        const int di = blockIdx.x * PCG_WAVE + dl;
-        const double u = philox_uniform(seed, epoch, (uint32_t)(di < k ? di : 0));
-        const int pos = bisect16(cum, n, u * (cum[n - 1] + 0.0), sub);
-        if (sub == 0) drawn[dl] = idx_train[pos];
-    }
-    int c = 0;
-    for (int t0 = 0; t0 < k; t0 += SHUF_TILE) {
-        const int nt = (k - t0 < SHUF_TILE) ? k - t0 : SHUF_TILE;
-        __syncthreads();
-        for (int t = threadIdx.x; t < nt; t += blockDim.x) sh[t] = shuffle_key(seed, epoch, t0 + t, k);
-        __syncthreads();
-        const int chunk = (nt + SHUF_WAVES - 1) / SHUF_WAVES;
-        const int j0 = wave * chunk, j1 = (j0 + chunk < nt) ? j0 + chunk : nt;
-        int j = j0;
-        for (; j + 4 <= j1; j += 4) {
-            const uint64_t a0 = sh[j], a1 = sh[j + 1], a2 = sh[j + 2], a3 = sh[j + 3];
-            c += (a0 < mine) + (a1 < mine) + (a2 < mine) + (a3 < mine);
-        }
-        for (; j < j1; ++j) c += sh[j] < mine;
-    }
-    part[wave * PCG_WAVE + lane] = c;
-    __syncthreads();
-    if (wave == 0 && i < k) {
-        int rank = 0;
-#pragma unroll
-        for (int w = 0; w < SHUF_WAVES; ++w) rank += part[w * PCG_WAVE + lane];
-        const int32_t id = drawn[lane];
-        out_ids[rank] = id;
-        if (out_labels) out_labels[rank] = labels_all[id];
-    }
-    // the last workgroup to finish moves the epoch on (every workgroup has read the counter by then)
-    if (bump && threadIdx.x == 0) {
-        __threadfence();
-        const unsigned int ticket = atomicAdd(done, 1u);
-        if (ticket == gridDim.x - 1) {
-            *done = 0u;
-            *epoch_counter += 1ull;
-        }
+    const int dl = threadIdx.x >> 4, sub = threadIdx.x & 15;          // draw slot 0..15, lane in the group
+    const int di = blockIdx.x * 16 + dl;
+    const double u = philox_uniform(seed, epoch, (uint32_t)(di < k ? di : 0));
+    const int pos = bisect16(cum, n, u * (cum[n - 1] + 0.0), sub);
+    if (sub == 0 && di < k) {
+        const int32_t id = idx_train[pos];
+        const int at = shuffle_position(di, k, bits, shuffle_key_of(seed, epoch));
+        out_ids[at] = id;
+        if (out_labels) out_labels[at] = labels_all[id];
     }
 }
 
@@ -257,16 +239,15 @@ int pcg_pick_shuffled(const double *cum, const int32_t *idx_train, int32_t n_tra
     if (!cum || !idx_train || !out_ids || n_train < 1 || k < 0) return PCG_E_ARG;
     if (out_labels && !labels_all) return PCG_E_ARG;
     if (bump && !epoch_counter) return PCG_E_ARG;
-    if (k > 131072) return PCG_E_UNSUPPORTED;     // k^2 key compares: beyond this use pcg_pick + a sort-based shuffle
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (k > 0) {
-        // epoch_counter[1] is the kernel's "workgroups done" ticket (zero between launches)
-        hipLaunchKernelGGL(pcg::pick_shuffled_kernel, dim3((k + PCG_WAVE - 1) / PCG_WAVE), dim3(pcg::SHUF_WAVES * PCG_WAVE), 0, st,
-                           cum, idx_train, n_train, seed, epoch_base, reinterpret_cast<unsigned long long *>(epoch_counter), bump,
-                           reinterpret_cast<unsigned int *>(epoch_counter ? epoch_counter + 1 : nullptr), k, labels_all, out_ids,
-                           out_labels);
+        int bits = 0;
+        while ((1ll << bits) < (long long)k) ++bits;
+        hipLaunchKernelGGL(pcg::pick_shuffled_kernel, dim3((k + 15) / 16), dim3(256), 0, st, cum, idx_train, n_train, seed, epoch_base,
+                           reinterpret_cast<const unsigned long long *>(epoch_counter), k, bits, labels_all, out_ids, out_labels);
         PCG_LAUNCH_CHECK();
-    } else if (bump) {
+    }
+    if (bump) {       // a second, one-thread launch: a ticket per workgroup would be thousands of same-address atomics
         hipLaunchKernelGGL(pcg::bump_counter_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<unsigned long long *>(epoch_counter));
         PCG_LAUNCH_CHECK();
     }
