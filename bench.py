@@ -329,7 +329,9 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                tkey = args.workload if args.workload != "powerlaw" else f"powerlaw_{args.nodes}_{args.edges}_b{B}"
+                # the PMC passes were run on one batch size per workload: yelp 1024, amazon 256 (their defaults)
+                tkey = (f"powerlaw_{args.nodes}_{args.edges}_b{B}" if args.workload == "powerlaw"
+                        else args.workload if B == default_b else f"{args.workload}_b{B}")
                 traffic = json.load(open(tpath)).get(tkey, {}).get("choose_agg_bytes_per_launch")
             except Exception:
                 traffic = None
