@@ -235,6 +235,8 @@ def main():
                     p.grad.copy_(flat[o:o + p.numel()].view_as(p))
                     o += p.numel()
             tr.opt.step()
+        elif epoch_graphs and timed:   # the staged batch as front | select + aggregate | dense + Adam graphs with events
+            tr.fused.epoch_step_timed(state["b"] - 1)
         elif dist is None:        # (graph engine: the per-batch graphs; whole epochs go through run_epoch_one_graph below)
             tr.step(ids, timed)
         else:
@@ -290,7 +292,9 @@ def main():
                 k += nb
                 continue
             ids = next_batch()
-            timed = timed_epoch             # (also during the warm-up, so that every graph is captured before the clock starts)
+            # (also during the warm-up, so that every graph is captured before the clock starts; with epoch graphs every
+            #  batch that is not part of a whole-epoch replay goes through the event-bracketed per-slot graphs)
+            timed = timed_epoch or epoch_graphs
             one_step(ids, timed)
             if measure:
                 if timed:

@@ -271,6 +271,53 @@ class FusedPCGNN:
             self._ep_graphs[key] = gr
         gr.replay()
 
+    def epoch_step_timed(self, b: int):
+        """Batch b of the staged epoch as three graphs - front | select + aggregate | dense + Adam - with HIP events
+        around the middle one (appended to ``_prof``): the same kernels in the same order as one step of ``epoch_run``,
+        reading the staged ids in place (no copies, no label gather)."""
+        lo = b * self._ep_bs
+        B = min(self._ep_bs, self._ep_n - lo)
+        if B <= 0:
+            return
+        self._lastB = B
+        key = (lo, B, "timed")
+        grs = self._ep_graphs.get(key)
+        ids, lab = self._ep_ids[lo:lo + B], self._ep_lab[lo:lo + B]
+        g = self.g
+        if grs is None:
+            agg = self.agg.view(-1)[:g.R * B * g.feat_dim].view(g.R, B, g.feat_dim)
+            keys = self.keys if g.n_pos else None
+            parts = (lambda: self._enqueue_front(ids, lab, B, True),
+                     lambda: self._enqueue_choose(ids, lab, B, keys, True, planned=True),
+                     lambda: (self._enqueue_dense(ids, lab, B, agg, True), self._enqueue_adam(B, apply=True)))
+            state = (self.theta.clone(), self.m.clone(), self.v.clone(), self.step_counter.clone())
+            prof, self._prof = self._prof, None
+            s = torch.cuda.Stream(self.dev)
+            s.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(s):
+                for fn in parts:
+                    fn()
+            torch.cuda.current_stream(self.dev).wait_stream(s)
+            grs = []
+            for fn in parts:
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr):
+                    fn()
+                grs.append(gr)
+            for dst, src in zip((self.theta, self.m, self.v, self.step_counter), state):
+                dst.copy_(src)
+            self._prof = prof
+            self._ep_graphs[key] = grs
+        grs[0].replay()
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+        grs[1].replay()
+        ev[1].record()
+        if self._prof is not None:
+            self._prof.append(ev)
+        self.last_counts = self.cnt.view(-1)[:g.R * B].view(g.R, B)
+        grs[2].replay()
+
     def stage_epoch(self, n: int, batch_size: int):
         """Static id / label buffers of an epoch of n picks (filled by begin_epoch or by a sampler)."""
         if getattr(self, "_ep_ids", None) is None or self._ep_ids.numel() < n:
