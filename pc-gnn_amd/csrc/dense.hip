@@ -43,9 +43,10 @@ struct DenseArgs {
     float *slabs;               // [n_tiles, n_params] or null
     int64_t n_params;
     int32_t *step_counter;      // incremented once per training launch (Adam's t), or null
+    int32_t n_split;            // training: workgroups per 16-row tile; they all run the forward pass, the weight-gradient tiles are dealt out
     unsigned long long *stamps; // diagnostic only (pcg_debug_set_dense_stamps): [tiles][16] wall-clock ticks, else null
 };
-#define DENSE_STAMP(slot) do { if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 16 + (slot)] = wall_clock64(); } while (0)
+#define DENSE_STAMP(slot) do { if (a.stamps && threadIdx.x == 0 && sp == 0) a.stamps[(size_t)tile_id * 16 + (slot)] = wall_clock64(); } while (0)
 
 // flat parameter / gradient order: W_cls | W_inter | W_intra[0..R) | W_clf | b_clf
 __host__ __device__ inline int64_t off_cls(int F, int E, int R) { return 0; }
@@ -150,7 +151,8 @@ __global__ void __launch_bounds__(DENSE_WAVES *PCG_WAVE) dense_step_kernel(const
     float *s_tmp = s_wc + 2 * E + 2 * F + 4;        // [TB][4] logits scratch
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row0 = blockIdx.x * TB;
+    const int S = a.n_split, tile_id = (int)blockIdx.x / S, sp = (int)blockIdx.x % S;
+    const int row0 = tile_id * TB;
     const bool train = a.slabs != nullptr;
     if (train && a.step_counter && blockIdx.x == 0 && tid == 0) a.step_counter[0] += 1;
     DENSE_STAMP(0);
@@ -222,7 +224,7 @@ __global__ void __launch_bounds__(DENSE_WAVES *PCG_WAVE) dense_step_kernel(const
             const float v = fmaxf(c[i], 0.f);
             s_comb[(rq + i) * ldE + col] = v;
             const int b = row0 + rq + i;
-            if (a.combined && b < a.B) a.combined[(size_t)b * E + col] = v;
+            if (a.combined && b < a.B && sp == 0) a.combined[(size_t)b * E + col] = v;
         }
     }
     __syncthreads();
@@ -248,16 +250,18 @@ __global__ void __launch_bounds__(DENSE_WAVES *PCG_WAVE) dense_step_kernel(const
         const float g0 = s_tmp[t * 4 + 0], g1 = s_tmp[t * 4 + 1], c0 = s_tmp[t * 4 + 2], c1 = s_tmp[t * 4 + 3];
         float dg0 = 0.f, dg1 = 0.f, dc0 = 0.f, dc1 = 0.f;
         if (b < a.B) {
-            a.logits[2 * b] = g0;
-            a.logits[2 * b + 1] = g1;
-            a.center[2 * b] = c0;
-            a.center[2 * b + 1] = c1;
+            if (sp == 0) {
+                a.logits[2 * b] = g0;
+                a.logits[2 * b + 1] = g1;
+                a.center[2 * b] = c0;
+                a.center[2 * b + 1] = c1;
+            }
             if (a.labels) {
                 const int y = a.labels[b];
                 float lg, lc;
                 xent2(g0, g1, y, lg, dg0, dg1);
                 xent2(c0, c1, y, lc, dc0, dc1);
-                if (a.row_loss) a.row_loss[b] = lg + a.lambda_1 * lc;
+                if (a.row_loss && sp == 0) a.row_loss[b] = lg + a.lambda_1 * lc;
                 dg0 *= a.inv_count; dg1 *= a.inv_count;
                 dc0 *= a.inv_count * a.lambda_1; dc1 *= a.inv_count * a.lambda_1;
             }
@@ -269,7 +273,7 @@ __global__ void __launch_bounds__(DENSE_WAVES *PCG_WAVE) dense_step_kernel(const
     DENSE_STAMP(4);
     if (!train) return;
 
-    float *slab = a.slabs + (size_t)blockIdx.x * a.n_params;
+    float *slab = a.slabs + (size_t)tile_id * a.n_params;
     // ---- backward ----------------------------------------------------------------------------
     // dcomb = (dlogits W_cls) * relu'(combined);  dW_cls, dW_clf, db_clf
     for (int i = tid; i < TB * E; i += blockDim.x) {
@@ -278,21 +282,21 @@ __global__ void __launch_bounds__(DENSE_WAVES *PCG_WAVE) dense_step_kernel(const
         s_dcomb[t * ldE + e] = s_comb[t * ldE + e] > 0.f ? g : 0.f;
     }
     DENSE_STAMP(8);
-    for (int i = tid; i < 2 * E; i += blockDim.x) {
+    for (int i = tid; i < (sp == 0 ? 2 * E : 0); i += blockDim.x) {
         const int cidx = i / E, e = i - cidx * E;
         float sacc = 0.f;
         for (int t = 0; t < TB; ++t) sacc = fmaf(s_dlog[2 * t + cidx], s_comb[t * ldE + e], sacc);
         slab[off_cls(F, E, R) + i] = sacc;
     }
     DENSE_STAMP(9);
-    for (int i = tid; i < 2 * F; i += blockDim.x) {
+    for (int i = tid; i < (sp == 0 ? 2 * F : 0); i += blockDim.x) {
         const int cidx = i / F, f = i - cidx * F;
         float sacc = 0.f;
         for (int t = 0; t < TB; ++t) sacc = fmaf(s_dcl[2 * t + cidx], s_cat[t * ld2 + f], sacc);
         slab[off_clf(F, E, R) + i] = sacc;
     }
     DENSE_STAMP(10);
-    if (tid < 2) {
+    if (tid < 2 && sp == 0) {
         float sacc = 0.f;
         for (int t = 0; t < TB; ++t) sacc += s_dcl[2 * t + tid];
         slab[off_bias(F, E, R) + tid] = sacc;
@@ -304,7 +308,10 @@ __global__ void __launch_bounds__(DENSE_WAVES *PCG_WAVE) dense_step_kernel(const
         const int mt2 = (K2 + 15) / 16;
         const int n_dh = R * ntile_e, n_all = n_dh + mt2 * ntile_e;
         float *dst = slab + off_inter(F, E, R);
-        for (int tile = wave; tile < n_all; tile += DENSE_WAVES) {
+        // every workgroup of the tile needs all of dh_r; the dW_inter tiles are dealt out over the tile's S workgroups
+        for (int t0 = wave; t0 < n_dh + (n_all - n_dh + S - 1) / S; t0 += DENSE_WAVES) {
+            const int tile = t0 < n_dh ? t0 : n_dh + (t0 - n_dh) * S + sp;
+            if (tile >= n_all) continue;
             if (tile < n_dh) {
                 const int r = tile / ntile_e, ct = tile - r * ntile_e;
                 const float *Wr = a.W_inter + (size_t)(F + r * E) * E;   // rows of W_inter that multiply h_r
@@ -337,7 +344,7 @@ __global__ void __launch_bounds__(DENSE_WAVES *PCG_WAVE) dense_step_kernel(const
     // dW_r = [self|agg_r]^T dh_r for every r
     {
         const int mt1 = (K1 + 15) / 16, per_r = mt1 * ntile_e;
-        for (int tile = wave; tile < R * per_r; tile += DENSE_WAVES) {
+        for (int tile = sp + S * wave; tile < R * per_r; tile += S * DENSE_WAVES) {
             const int r = tile / per_r, tl = tile - r * per_r;
             const int m0 = (tl / ntile_e) * 16, n0 = (tl % ntile_e) * 16;
             const f32x4 c = tile_ldsT_lds(s_catr + r * TB * ld1, ld1, m0, K1, s_dh + r * TB * ldE, ldE, n0, lane);
@@ -474,6 +481,11 @@ int pcg_dense_step(const pcg_graph_desc *g, const float *theta, int32_t emb, con
     a.slabs = slabs;
     a.n_params = pcg::n_params_of(F, E, R);
     a.step_counter = step_counter;
+    // few tiles (small batches): up to 4 workgroups per tile, so that the weight-gradient tiles of a 16-row tile are not one
+    // CU's serial work while most of the chip idles
+    const int n_tiles = (B + pcg::TB - 1) / pcg::TB;
+    int n_split = slabs ? 256 / n_tiles : 1;
+    a.n_split = n_split < 1 ? 1 : (n_split > 4 ? 4 : n_split);
     a.stamps = pcg::g_dense_stamps;
     static bool attr = false;
     if (!attr) {
@@ -484,7 +496,7 @@ int pcg_dense_step(const pcg_graph_desc *g, const float *theta, int32_t emb, con
             return PCG_E_LAUNCH;
         attr = true;
     }
-    const dim3 grid((B + pcg::TB - 1) / pcg::TB), block(pcg::DENSE_WAVES * PCG_WAVE);
+    const dim3 grid(n_tiles * a.n_split), block(pcg::DENSE_WAVES * PCG_WAVE);
     if (wlds) hipLaunchKernelGGL(pcg::dense_step_kernel<true>, grid, block, smem, static_cast<hipStream_t>(stream), a);
     else hipLaunchKernelGGL(pcg::dense_step_kernel<false>, grid, block, smem, static_cast<hipStream_t>(stream), a);
     PCG_LAUNCH_CHECK();
