@@ -607,6 +607,32 @@ def test_full_size_properties_yelp_like(P):
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
 
 
+def test_epoch_as_one_graph_equals_step_by_step(P):
+    """A whole epoch as ONE graph launch (sampler + every batch, PCGNNTrainer.run_epoch_one_graph) leaves bit for bit the
+    parameters, Adam moments and epoch counter that the same epochs run launch by launch leave (staged sampler, then
+    FusedPCGNN.train_step per batch) - over three epochs, the last batch of each partial."""
+    from pcgnn_amd import synth
+    from pcgnn_amd.handler import PCGNNTrainer
+    w = synth.make_workload("mini", 6000, 32, (4000, 30000, 90000), 0.12, seed=3)
+    cfg = dict(engine="graph", batch_size=256, seed=5)
+    a, b = PCGNNTrainer(w, cfg, dev()), PCGNNTrainer(w, cfg, dev())
+    b.fused.theta.copy_(a.fused.theta)
+    nb = a.batches_per_epoch()
+    assert a.pick_size % a.batch_size != 0 and nb >= 3
+    for _ in range(3):
+        a.run_epoch_one_graph()
+        ids = b.start_epoch_staged()
+        for k in range(nb):
+            sl = slice(k * b.batch_size, min((k + 1) * b.batch_size, b.pick_size))
+            b.fused.train_step(ids[sl], b.fused._ep_lab[sl])
+    torch.cuda.synchronize()
+    assert int(a._epoch_dev[0]) == int(b._epoch_dev[0]) == 3
+    assert torch.equal(a.fused._ep_ids[:a.pick_size], b.fused._ep_ids[:b.pick_size])
+    for name in ("theta", "m", "v", "step_counter"):
+        assert torch.equal(getattr(a.fused, name), getattr(b.fused, name)), name
+    assert torch.isfinite(a.fused.theta).all() and not torch.equal(a.fused.theta, torch.zeros_like(a.fused.theta))
+
+
 def test_large_batch_two_pass_plan(P):
     """rows > 4096 take the two-launch, multi-workgroup plan: same result as the oracle / the small-batch path."""
     ops = P.ops
