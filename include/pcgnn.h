@@ -128,7 +128,7 @@ int pcg_pos_sort(const pcg_graph_desc *g, const float *s0, uint64_t *keys, void 
  *           PCG_ST_SEL_OVERFLOW is OR-ed into *status (uint32 device word; zero it yourself).
  *   pcg_choose_workspace_offset(..., which): byte offset inside the workspace of
  *           0 row_begin int64 [rows+1] | 1 len int32 [rows] | 2 list int32 [list_capacity]
- *           (3 chunk_begin, 4 chunk_row, 5 counters, 6 partial: internal, exposed for tests). */
+ *           (3 chunk_begin, 4 chunk descriptors, 5 counters, 6 partial: internal, exposed for tests). */
 int64_t pcg_choose_workspace_bytes(const pcg_graph_desc *g, int32_t B, int64_t list_capacity);
 int64_t pcg_choose_workspace_offset(const pcg_graph_desc *g, int32_t B, int64_t list_capacity, int32_t which);
 int pcg_choose_select(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B,

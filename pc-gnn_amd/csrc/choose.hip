@@ -60,7 +60,7 @@ struct Workspace {
     int32_t *q0, *q1, *q4, *q16;  // [rows] each: the rows of every degree tier
     struct RowRec *recs;   // [rows] what plan worked out per row
     unsigned char *plan_totals;   // [blocks of the two-pass plan] PlanTotals
-    int32_t *chunk_row;    // [chunk_cap]
+    int4 *chunk_desc;      // [chunk_cap] per gather chunk: {row, first list entry, entries of the row's region in it, chunks of the row}
     float *partial;        // [chunk_cap, feat_stride]
     int32_t *list;         // [list_capacity]  chosen ids; -1 = hole
     uint32_t *scratch;     // [SEL_BLOCKS * 2 * max_degree] when rows beyond the LDS tiers exist (max_degree > HUB_LDS_CAP)
@@ -89,7 +89,7 @@ static int64_t carve(const pcg_graph_desc *g, int32_t B, int64_t list_capacity, 
     p = take(4 * rows);                            if (w) w->q16 = reinterpret_cast<int32_t *>(p);
     p = take(32 * rows);                           if (w) w->recs = reinterpret_cast<RowRec *>(p);
     p = take(64 * (rows / 256 + 2));               if (w) w->plan_totals = p;   // PlanTotals (<= 64 B) per 256 rows
-    p = take(4 * chunk_cap);                       if (w) w->chunk_row = reinterpret_cast<int32_t *>(p);
+    p = take(16 * chunk_cap);                      if (w) w->chunk_desc = reinterpret_cast<int4 *>(p);
     p = take(4 * chunk_cap * g->feat_stride);      if (w) w->partial = reinterpret_cast<float *>(p);
     p = take(4 * list_capacity);                   if (w) w->list = reinterpret_cast<int32_t *>(p);
     p = take(g->max_degree > HUB_LDS_CAP ? (int64_t)SEL_BLOCKS * 2 * g->max_degree * 4 : 0);
@@ -288,7 +288,8 @@ __global__ void __launch_bounds__(PLAN_THREADS) plan_kernel(const ChooseArgs a) 
             a.w.chunk_begin[row] = o_chunk;
             a.w.recs[row] = rec[i];
             if (!overflow) {
-                for (int j = 0; j < nch; ++j) a.w.chunk_row[o_chunk + j] = row;
+                for (int j = 0; j < nch; ++j)
+                    a.w.chunk_desc[o_chunk + j] = make_int4(row, (int)o_cap + j * CHUNK, cap[i] - j * CHUNK < CHUNK ? cap[i] - j * CHUNK : CHUNK, nch);
                 tier_push(a.w, rec[i].d, row, o);
             }
             o_cap += cap[i];
@@ -393,7 +394,8 @@ __device__ __forceinline__ void plan_write_body(const ChooseArgs &a, const PlanT
         a.w.row_begin[row] = o_cap;
         a.w.chunk_begin[row] = o_chunk;
         if (!overflow) {
-            for (int j = 0; j < nch; ++j) a.w.chunk_row[o_chunk + j] = row;
+            for (int j = 0; j < nch; ++j)
+                a.w.chunk_desc[o_chunk + j] = make_int4(row, (int)o_cap + j * CHUNK, cap - j * CHUNK < CHUNK ? cap - j * CHUNK : CHUNK, nch);
             tier_push(a.w, rec.d, row, o);
         }
     }
@@ -1080,7 +1082,8 @@ struct AggArgs {
     const int32_t *chunk_begin;
     const int32_t *len;
     const int32_t *cnt;
-    const int32_t *chunk_row;
+    const int4 *chunk_desc;
+    int32_t chunk_cap;
     const int32_t *list;
     const uint32_t *n_chunks;   // device word
     float *partial;
@@ -1121,15 +1124,18 @@ template <int NACC>
 __global__ void __launch_bounds__(256) gather_chunks(const AggArgs a) {
     const int lane = lane_id();
     const RowGeom q = row_geom(a.feat_stride, lane);
-    const uint32_t total = *a.n_chunks;
     const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
-    for (uint32_t ch = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); ch < total; ch += nwaves) {
-        const int row = a.chunk_row[ch];
-        const int cb = a.chunk_begin[row];
-        const int j0 = ((int)ch - cb) * CHUNK;
-        const int len = a.len[row];
-        const int n = (len - j0 < CHUNK) ? len - j0 : CHUNK;          // may be <= 0 (cap is an upper bound)
-        const int32_t *__restrict__ list = a.list + a.row_begin[row] + j0;
+    const uint32_t ch0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    // the chunk's descriptor (written by the plan) is requested together with the chunk count: one load level instead of
+    // four (count -> row -> offsets -> list).  n is the chunk's share of the row's REGION: entries past the ones the
+    // select wrote are -1 (it fills the tail), so they add nothing.
+    int4 desc = a.chunk_desc[ch0 < (uint32_t)a.chunk_cap ? ch0 : 0u];
+    const uint32_t total = *a.n_chunks;
+    for (uint32_t ch = ch0; ch < total; ch += nwaves) {
+        if (ch != ch0) desc = a.chunk_desc[ch];
+        const int row = desc.x, n = desc.z, nch_row = desc.w;
+        const int32_t *__restrict__ list = a.list + desc.y;
+        const int cnt = nch_row == 1 ? a.cnt[row] : 1;
         float4 acc[NACC];
 #pragma unroll
         for (int x = 0; x < NACC; ++x) acc[x] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1168,9 +1174,7 @@ __global__ void __launch_bounds__(256) gather_chunks(const AggArgs a) {
                 acc[x].w += __shfl_xor(acc[x].w, o);
             }
         if (lane < q.lpr) {
-            const int nch_row = a.chunk_begin[row + 1] - cb;
             if (nch_row == 1) {
-                const int cnt = a.cnt[row];
                 const float den = a.norm == PCG_NORM_SQRT_COUNT ? sqrtf((float)cnt) : (float)cnt;
                 store_row<NACC>(a.agg + (size_t)row * a.agg_stride, acc, q, a.feat_dim, den);
             } else {
@@ -1287,7 +1291,7 @@ int64_t pcg_choose_workspace_offset(const pcg_graph_desc *g, int32_t B, int64_t 
         case 1: return reinterpret_cast<unsigned char *>(w.len) - base;
         case 2: return reinterpret_cast<unsigned char *>(w.list) - base;
         case 3: return reinterpret_cast<unsigned char *>(w.chunk_begin) - base;
-        case 4: return reinterpret_cast<unsigned char *>(w.chunk_row) - base;
+        case 4: return reinterpret_cast<unsigned char *>(w.chunk_desc) - base;
         case 5: return reinterpret_cast<unsigned char *>(w.counters) - base;
         case 6: return reinterpret_cast<unsigned char *>(w.partial) - base;
         default: return PCG_E_ARG;
@@ -1455,7 +1459,8 @@ int pcg_aggregate_lists(const float *X, int32_t feat_dim, int32_t feat_stride, i
     a.chunk_begin = w.chunk_begin;
     a.len = w.len;
     a.cnt = cnt;
-    a.chunk_row = w.chunk_row;
+    a.chunk_desc = w.chunk_desc;
+    a.chunk_cap = (int32_t)w.chunk_cap;
     a.list = w.list;
     a.n_chunks = w.counters + pcg::C_NCHUNK;
     a.partial = w.partial;
