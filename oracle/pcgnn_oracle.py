@@ -269,6 +269,17 @@ def sage_mean(nodes: Sequence[int], adj: AdjList, X: torch.Tensor, gcn: bool = F
     return dense_mask_aggregate(sets, X, "count")
 
 
+def sage_mean_fanout(nodes: Sequence[int], to_neighs: Sequence[Set[int]], X: torch.Tensor, num_sample: int, rng,
+                     gcn: bool = False) -> torch.Tensor:
+    """MeanAggregator.forward with the random fan-out (graphsage.py:70-74): a row with at least ``num_sample``
+    neighbours keeps ``set(random.sample(to_neigh, num_sample))``; ``random.sample`` on a set draws from
+    ``tuple(to_neigh)`` (CPython 3.10 Lib/random.py), i.e. in the set's iteration order.  ``rng``: a ``random.Random``."""
+    samp = [set(rng.sample(tuple(s), num_sample)) if len(s) >= num_sample else set(s) for s in to_neighs]
+    if gcn:
+        samp = [s | {int(nodes[i])} for i, s in enumerate(samp)]                # :78-79
+    return dense_mask_aggregate(samp, X, "count")
+
+
 def gcn_mean(nodes: Sequence[int], adj: AdjList, X: torch.Tensor) -> torch.Tensor:
     """GCNAggregator.forward: union self, divide by sqrt(row count) (graphsage.py:200-232)."""
     sets = [set(adj[int(n)]) | {int(n)} for n in nodes]

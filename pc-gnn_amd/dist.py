@@ -230,10 +230,14 @@ class DistributedPCGNN:
         gen = torch.Generator().manual_seed(cfg["seed"])
         theta = torch.zeros(n)
         for which, rel, shape in ([(0, 0, (2, self.E)), (1, 0, (F + self.R * self.E, self.E))]
-                                  + [(2, r, (2 * F, self.E)) for r in range(self.R)] + [(3, 0, (2, F))]):
+                                  + [(2, r, (2 * F, self.E)) for r in range(self.R)]):
             off = self.lib.pcg_dense_param_offset(F, self.E, self.R, which, rel)
-            bound = math.sqrt(6.0 / (shape[0] + shape[1]))                  # xavier_uniform_, as the reference
+            bound = math.sqrt(6.0 / (shape[0] + shape[1]))                  # xavier_uniform_ (model.py:30, layers.py:197,560)
             theta[off:off + shape[0] * shape[1]] = (torch.rand(shape[0] * shape[1], generator=gen) * 2 - 1) * bound
+        # label_clf is an nn.Linear (layers.py:200): torch's default init, U(+-1/sqrt(fan_in)) for weight and bias
+        for which, count in ((3, 2 * F), (4, 2)):
+            off = self.lib.pcg_dense_param_offset(F, self.E, self.R, which, 0)
+            theta[off:off + count] = (torch.rand(count, generator=gen) * 2 - 1) / math.sqrt(F)
         self.theta = theta.to(self.dev)
         self.m, self.v = torch.zeros_like(self.theta), torch.zeros_like(self.theta)
         self.grad = torch.zeros_like(self.theta)

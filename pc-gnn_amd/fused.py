@@ -27,7 +27,7 @@ _p = ops._p
 
 class FusedPCGNN:
     def __init__(self, model: PCALayer, lr: float, weight_decay: float, betas=(0.9, 0.999), eps: float = 1e-8,
-                 max_batch: int = 1024, global_batch_scale: int = 1):
+                 max_batch: int = 1024, global_batch_scale: int = 1, list_capacity: Optional[int] = None):
         lib = _lib.load()
         self.lib = lib
         self.model = model
@@ -64,18 +64,26 @@ class FusedPCGNN:
         self.step_counter = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self.grad = torch.zeros_like(self.theta)
 
-        self._alloc(max_batch)
+        self.list_capacity = list_capacity      # entries of every workspace's selection list (None: worst case of the graph)
+        self.status = torch.zeros(1, dtype=torch.int32, device=self.dev)   # ONE device status word for all workspaces
         self._graphs = {}
+        self._ep_graphs = {}
+        self._alloc(max_batch)
         self._prof = None          # bench.py: list of (start, end) events around the choose+aggregate launch
         self.last_counts = None
 
     # ------------------------------------------------------------------
     def _alloc(self, B: int):
         g, dev = self.g, self.dev
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.PcgnnLibraryError("batch larger than max_batch inside a graph capture: allocate before capturing")
+        # every captured graph holds raw pointers into the buffers replaced below
+        self._graphs.clear()
+        self._ep_graphs.clear()
         self.maxB = B
         self.s0 = torch.empty(g.n_nodes, dtype=torch.float32, device=dev)
         self.keys = torch.empty(self.lib.pcg_pos_sort_capacity(g.n_pos), dtype=torch.int64, device=dev)
-        self._ws_by_b = {B: ops.ChooseWorkspace(g, B)}
+        self._ws_by_b = {B: ops.ChooseWorkspace(g, B, self.list_capacity, status=self.status)}
         self.agg = torch.empty(g.R, B, g.feat_dim, dtype=torch.float32, device=dev)
         self.cnt = torch.empty(g.R, B, dtype=torch.int32, device=dev)
         self.logits = torch.empty(B, 2, dtype=torch.float32, device=dev)
@@ -98,7 +106,7 @@ class FusedPCGNN:
     def _ws(self, B):
         ws = self._ws_by_b.get(B)
         if ws is None:      # the workspace layout depends on the batch size: one per size
-            ws = self._ws_by_b[B] = ops.ChooseWorkspace(self.g, B)
+            ws = self._ws_by_b[B] = ops.ChooseWorkspace(self.g, B, self.list_capacity, status=self.status)
         return ws
 
     def _enqueue_front(self, ids, labels, B, train_flag):
@@ -156,7 +164,6 @@ class FusedPCGNN:
             return
         if B > self.maxB:
             self._alloc(B)
-            self._graphs.clear()
         self._lastB = B
         agg, _ = self._enqueue_sample(ids, labels, B, True)
         self._enqueue_dense(ids, labels, B, agg, True)
@@ -176,7 +183,6 @@ class FusedPCGNN:
             return
         if B > self.maxB:
             self._alloc(B)
-            self._graphs.clear()
         self._lastB = B
         gr = self._graphs.get(B)
         if gr is None:
@@ -323,7 +329,7 @@ class FusedPCGNN:
         if getattr(self, "_ep_ids", None) is None or self._ep_ids.numel() < n:
             self._ep_ids = torch.zeros(n, dtype=torch.int32, device=self.dev)
             self._ep_lab = torch.zeros(n, dtype=torch.int32, device=self.dev)
-            self._ep_graphs = {}
+            self._ep_graphs.clear()
         self._ep_n, self._ep_bs = n, batch_size
         return self._ep_ids[:n], self._ep_lab[:n]
 
@@ -361,7 +367,18 @@ class FusedPCGNN:
         gr.replay()
         return n_steps
 
+    def check(self):
+        """Raise if any batch since the last check did not fit its selection list (the kernels then select nothing and
+        only set the device status word).  Reads one word: synchronises - call it where the host waits anyway
+        (``last_loss``, the end of an evaluation pass or of an epoch, after a timed region)."""
+        st = int(self.status.item())
+        if st & _lib.PCG_ST_SEL_OVERFLOW:
+            self.status.zero_()
+            raise _lib.PcgnnLibraryError("selection list overflow: a batch needed more list entries than the workspace "
+                                         "holds - raise FusedPCGNN(list_capacity=...)")
+
     def last_loss(self) -> torch.Tensor:
+        self.check()
         B = self._lastB
         return self.row_loss[:B].sum() / (B * self.scale)
 
@@ -386,7 +403,6 @@ class FusedPCGNN:
         B = ids.numel()
         if B > self.maxB:
             self._alloc(B)
-            self._graphs.clear()
         agg, _ = self._enqueue_sample(ids, labels, B, train_flag)
         comb = torch.empty(B, self.E, dtype=torch.float32, device=self.dev) if want_combined else None
         self._enqueue_dense(ids, None, B, agg, False, combined=comb)

@@ -8,8 +8,8 @@ self union (:78-79, :214) and the ``sqrt(count)`` normaliser (:224-226); the sma
 (``relu(W . x^T)``, classifier, loss) is torch with autograd.
 
 ``MeanAggregator.forward(..., num_sample=k)`` (random fan-out, :70-74) draws the sample on the
-host with Python's ``random`` exactly like the reference and aggregates the explicit lists with
-``pcg_segment_mean``.
+host with Python's ``random`` exactly like the reference (same draws under the same seed: checked
+against a fixture) and aggregates the explicit lists with ``pcg_segment_mean``.
 
 One difference on purpose: ``to_prob`` accepts (and ignores) the ``labels`` / ``train_flag``
 arguments ``utils.test`` passes (utils.py:305), which the reference's ``GCN.to_prob(self, nodes)``
@@ -74,7 +74,9 @@ class MeanAggregator(_FullNeighbourhood):
         # explicit neighbour sets (and the optional random fan-out): pack the lists, segmented mean
         _set, _sample = set, random.sample
         if num_sample is not None:
-            samp = [_set(_sample(sorted(n), num_sample)) if len(n) >= num_sample else n for n in to_neighs]   # :70-74
+            # random.sample(set, k) draws from tuple(set) - the set's own iteration order - in CPython <= 3.10 (the
+            # reference's interpreter); spelled out so that the draws are the reference's under the same seed
+            samp = [_set(_sample(tuple(n), num_sample)) if len(n) >= num_sample else n for n in to_neighs]   # :70-74
         else:
             samp = to_neighs
         if self.gcn:

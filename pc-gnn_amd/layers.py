@@ -192,6 +192,11 @@ class InterAgg(nn.Module):
         combined = F.relu(torch.cat(feats, dim=1).mm(self.weight).t())                # :284-289
         return combined, center_scores
 
+    def check(self):
+        """Raise if any batch since the last check did not fit its workspace's selection list (synchronises)."""
+        for ws in self._ws_cache.values():
+            ws.check()
+
     def chosen_sets(self, nodes, labels, train_flag=True):
         """samp_neighs of every relation for a batch, as Python sets (debug / parity)."""
         g = self.graph()

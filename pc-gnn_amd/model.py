@@ -31,3 +31,9 @@ class PCALayer(nn.Module):
         label_loss = self.xent(label_scores, y)                          # Eq. (7)
         gnn_loss = self.xent(gnn_scores, y)                              # Eq. (10)
         return gnn_loss + self.lambda_1 * label_loss                     # Eq. (11)
+
+    def check(self):
+        """Raise if a batch overflowed its selection list since the last check (synchronises; not in the reference:
+        its Python sets cannot overflow).  ``utils.test`` calls it once per evaluation pass."""
+        if hasattr(self.inter1, "check"):
+            self.inter1.check()

@@ -80,19 +80,23 @@ class ChooseWorkspace:
     ``(deg > k+1 ? k : deg) + m (+1)``; the default is the worst case for this graph and batch
     size (every centre being the largest hub), clipped to ``max_list_bytes``."""
 
-    def __init__(self, g: DeviceGraph, B: int, list_capacity: Optional[int] = None, max_list_bytes: int = 8 << 30):
+    def __init__(self, g: DeviceGraph, B: int, list_capacity: Optional[int] = None, max_list_bytes: int = 8 << 30,
+                 status: Optional[torch.Tensor] = None):
         lib = _lib.load()
         self.B = B
+        self.clipped = False       # the default capacity was cut below the worst case: overflow is possible, check()!
         if list_capacity is None:
             # kept <= deg, minority m = int(ceil(deg/2) * rho) <= 2 * deg for rho <= 4 (and <= n_pos), +1 self
             per_row = g.max_degree + min(2 * max(g.max_degree, 1), g.n_pos) + 1
-            list_capacity = min(per_row * g.R * max(B, 1), max_list_bytes // 4, (1 << 31) - 1)
+            worst = per_row * g.R * max(B, 1)
+            list_capacity = min(worst, max_list_bytes // 4, (1 << 31) - 1)
+            self.clipped = list_capacity < worst
         self.list_capacity = int(max(list_capacity, 1))
         nbytes = lib.pcg_choose_workspace_bytes(g.desc_ref(), B, self.list_capacity)
         if nbytes < 0:
             raise _lib.PcgnnLibraryError("pcg_choose_workspace_bytes rejected the arguments")
         self.buf = torch.zeros(int(nbytes), dtype=torch.uint8, device=g.device)
-        self.status = torch.zeros(1, dtype=torch.int32, device=g.device)
+        self.status = status if status is not None else torch.zeros(1, dtype=torch.int32, device=g.device)
         self._g = g
 
     def view(self, which: int, dtype, count: int) -> torch.Tensor:
@@ -103,6 +107,7 @@ class ChooseWorkspace:
     def check(self):
         """Raise if a batch did not fit the selection list (reads the status word: synchronises)."""
         if int(self.status.item()) & _lib.PCG_ST_SEL_OVERFLOW:
+            self.status.zero_()
             raise _lib.PcgnnLibraryError("selection list overflow: raise ChooseWorkspace(list_capacity=...)")
 
 

@@ -74,6 +74,8 @@ def test(test_nodes, labels, model, batch_size: int, result=None, epoch: Optiona
             else:
                 outs.append(model.to_prob(batch.tolist(), blab, train_flag=False)[0])   # :305
     prob = torch.cat(outs).float().cpu().numpy() if outs else np.zeros((0, 2), np.float32)
+    if hasattr(model, "check"):
+        model.check()          # a batch that overflowed its selection list must not pass for a prediction
     pred = prob.argmax(axis=1)                                               # :306
     m = binary_metrics(labels, pred, prob[:, 1])                             # :308, :316-323
     line = (f"- F1: {m['f1']:.4f}\t- Recall: {m['recall']:.4f}\t- Precision: {m['precision']:.4f}\t"
@@ -130,6 +132,8 @@ def test_f1(test_nodes, labels, model, batch_size: int, flag: str = "valid", val
             else:
                 outs.append(model.to_prob(batch.tolist(), y[start:start + batch_size], train_flag=False)[0])
     prob = torch.cat(outs).float().cpu().numpy() if outs else np.zeros((0, 2), np.float32)
+    if hasattr(model, "check"):
+        model.check()
     threshold = None
     if flag == "valid":
         _, threshold = get_best_f1(y, prob[:, 1])                     # :316-317

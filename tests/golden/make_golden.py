@@ -160,6 +160,8 @@ def build_model(X, rels, train_pos, emb, rho, alpha, seed):
         inter = RL.InterAgg3(features, f, emb, train_pos, rels, intras, cuda=False)
     elif len(rels) == 1:
         inter = RL.InterAgg1(features, f, emb, train_pos, rels, intras, cuda=False)
+    elif len(rels) == 5:
+        inter = RL.InterAgg5(features, f, emb, train_pos, rels, intras, cuda=False)
     else:
         raise ValueError
     return PCALayer(2, inter, alpha)
@@ -265,6 +267,14 @@ def pcgnn_case(name, seed, n, f, rel_deg, pos_rate, emb, batch, rhos, nonneg=Fal
     genc = GCNEncoder(features, f, emb, homo, GCNAggregator(features, cuda=False), cuda=False)
     out["s1_gcn_enc_w"] = genc.weight.detach().numpy().copy()
     out["s1_gcn_enc"] = genc(sub).detach().numpy()
+    # random fan-out (graphsage.py:70-74): random.sample over each neighbour SET under a seeded `random`.  The sets are
+    # built as set(sorted(...)) so that a test can rebuild objects with the same CPython iteration order.
+    fan_k, fan_seed = 5, seed + 17
+    out["s1_fanout_k"], out["s1_fanout_seed"] = fan_k, fan_seed
+    for gcn_flag, key in ((False, "s1_fanout_mean"), (True, "s1_fanout_mean_gcn")):
+        random.seed(fan_seed)
+        fsets = [set(sorted(homo[int(v)])) for v in sub]
+        out[key] = MeanAggregator(features, cuda=False, gcn=gcn_flag).forward(sub, fsets, num_sample=fan_k).detach().numpy()
 
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
@@ -308,6 +318,15 @@ if __name__ == "__main__":
     pcgnn_case("yelp_small", seed=3, n=1500, f=32, rel_deg=(2.5, 9, 28), pos_rate=0.145, emb=64, batch=256,
                rhos=(0.5, 0.2, 0.8, 2.0))
     pcgnn_case("amazon_small", seed=5, n=900, f=25, rel_deg=(8, 40, 20), pos_rate=0.09, emb=64, batch=128,
-               rhos=(0.5, 0.8), nonneg=True, lr=0.005, wd=0.0005)
+               rhos=(0.5, 0.8, 0.2), nonneg=True, lr=0.005, wd=0.0005)
     pcgnn_case("single_rel", seed=9, n=800, f=32, rel_deg=(12,), pos_rate=0.12, emb=32, batch=100,
                rhos=(0.5,))
+    # BASELINE configs[2] shape: emb 128 (the dense tail's weights no longer fit the LDS: the L2-streamed kernel variant)
+    pcgnn_case("yelp_emb128", seed=13, n=1500, f=32, rel_deg=(2.5, 9, 28), pos_rate=0.145, emb=128, batch=256,
+               rhos=(0.5,))
+    # wide features (F=100: 400-B rows, 32 lanes per row; again the streamed-weights variant, for the K dimension this time)
+    pcgnn_case("feat100", seed=17, n=700, f=100, rel_deg=(4, 14, 9), pos_rate=0.15, emb=64, batch=96,
+               rhos=(0.5, 0.8))
+    # five relations (InterAgg5, layers.py:16-158), emb 48 (E/4 = 12 does not divide the 1024-thread staging pattern)
+    pcgnn_case("five_rel", seed=37, n=700, f=16, rel_deg=(3, 6, 10, 5, 16), pos_rate=0.14, emb=48, batch=90,
+               rhos=(0.5, 2.0))

@@ -16,7 +16,7 @@ from tests.util import GOLDEN, PARAM_KEYS, GoldenCase, csr_to_adj, synth_graph
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["yelp_small", "amazon_small", "single_rel"]
+CASES = ["yelp_small", "amazon_small", "single_rel", "yelp_emb128", "feat100", "five_rel"]   # emb128 / feat100 / five_rel: dense_step_kernel<false>
 LOGIT_TOL = 1e-4     # north_star tolerance for logits
 FEAT_TOL = 2e-5      # aggregated features / activations
 
@@ -442,11 +442,17 @@ def test_fused_forward_grads_adam_golden(P, case):
     assert abs(float(fz.last_loss()) - float(c.z[tag + "_loss"])) < LOGIT_TOL
     for k in PARAM_KEYS(c.R):
         np.testing.assert_allclose(grads[k].cpu().numpy(), c.z[f"{tag}_grad_{k}"], rtol=0, atol=2e-5, err_msg=k)
-    # one Adam step
+    # one Adam step: where the reference's own gradient is well away from zero the first update is -lr * g'/(|g'| + eps)
+    # with g' = g + wd * p (coupled decay) - elementwise tight there; loose where |g'| ~ the gradient tolerance
+    p0 = {k: v.clone() for k, v in c.params().items()}
     fz.train_step(ids, lab)
     sd = m.state_dict()
     for k in PARAM_KEYS(c.R):
-        np.testing.assert_allclose(sd[k].cpu().numpy(), c.z[f"{tag}_step_{k}"], rtol=0, atol=c.lr * 5e-2, err_msg=k)
+        got, want = sd[k].cpu().numpy(), c.z[f"{tag}_step_{k}"]
+        gp = c.z[f"{tag}_grad_{k}"] + c.wd * p0[k].numpy()
+        firm = np.abs(gp) > 2e-3
+        np.testing.assert_allclose(got[firm], want[firm], rtol=0, atol=c.lr * 2e-2, err_msg=k)
+        np.testing.assert_allclose(got, want, rtol=0, atol=c.lr * 2.001, err_msg=k)      # a step never exceeds lr
     assert int(fz.step_counter.item()) == 1
 
 
@@ -473,8 +479,43 @@ def test_fused_graph_equals_eager_and_torch(P, case):
     assert torch.equal(f1.theta, f2.theta), "graph replay must reproduce the eager fused step exactly"
     sd1, sd3 = m1.state_dict(), m3.state_dict()
     for k in PARAM_KEYS(c.R):
-        np.testing.assert_allclose(sd1[k].cpu().numpy(), sd3[k].cpu().numpy(), rtol=0, atol=c.lr * 0.25, err_msg=k)
+        a, b = sd1[k].cpu().numpy(), sd3[k].cpu().numpy()
+        np.testing.assert_allclose(a, b, rtol=0, atol=c.lr * 0.25, err_msg=k)
+        assert np.mean(np.abs(a - b)) < c.lr * 5e-3, k      # on average the two trajectories stay together
     assert abs(float(f1.last_loss()) - float(f2.last_loss())) == 0.0
+
+
+def test_adam_step_matches_torch_adam(P):
+    """pcg_adam_step alone against torch.optim.Adam (coupled weight decay, bias correction) on the same gradient
+    sequence: six steps, the gradient of every step handed over as 1..37 partial slabs (model_handler.py:124,153)."""
+    from pcgnn_amd import _lib
+    lib, ops = _lib.load(), P.ops
+    n = 26818
+    gen = torch.Generator().manual_seed(12)
+    p0 = torch.randn(n, generator=gen) * 0.1
+    for lr, wd, b1, b2, eps in ((0.01, 0.001, 0.9, 0.999, 1e-8), (0.005, 0.0, 0.8, 0.99, 1e-6), (0.02, 0.05, 0.9, 0.999, 1e-8)):
+        ref = torch.nn.Parameter(p0.clone().cuda())
+        opt = torch.optim.Adam([ref], lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd)
+        theta = p0.clone().cuda()
+        m, v = torch.zeros_like(theta), torch.zeros_like(theta)
+        counter = torch.zeros(1, dtype=torch.int32, device=dev())
+        grad_out = torch.empty_like(theta)
+        for step, n_slabs in enumerate((1, 2, 5, 16, 37, 64)):
+            slabs = (torch.randn(n_slabs, n, generator=gen) * (10.0 ** -(step % 3))).cuda()
+            if step == 3:
+                slabs[:, ::7] = 0.0                     # exact zeros: the update is then pure weight decay / momentum
+            counter += 1
+            _lib.check(lib.pcg_adam_step(ops._p(theta), ops._p(m), ops._p(v), ops._p(slabs), n_slabs, n, ops._p(counter),
+                                         lr, b1, b2, eps, wd, ops._p(grad_out), 1, ops._stream(dev())), "pcg_adam_step")
+            g = slabs.double().sum(0).float()
+            np.testing.assert_allclose(grad_out.cpu().numpy(), g.cpu().numpy(), rtol=2e-6, atol=1e-6 * n_slabs)
+            ref.grad = grad_out.clone()                 # the same summed gradient, so only the update rule is compared
+            opt.step()
+            np.testing.assert_allclose(theta.cpu().numpy(), ref.detach().cpu().numpy(), rtol=0, atol=lr * 2e-5,
+                                       err_msg=f"step {step} lr {lr} wd {wd}")
+        st = opt.state[ref]
+        np.testing.assert_allclose(m.cpu().numpy(), st["exp_avg"].cpu().numpy(), rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(v.cpu().numpy(), st["exp_avg_sq"].cpu().numpy(), rtol=1e-5, atol=1e-12)
 
 
 # ---------------------------------------------------------------------------
@@ -520,6 +561,25 @@ def test_graphsage_gcn_models_golden(P, case):
         assert tuple(prob.shape) == (len(sub), 2)
 
 
+def test_graphsage_random_fanout_golden(P, case):
+    """MeanAggregator.forward(..., num_sample=k) (graphsage.py:70-74) against the reference's output under the same seed."""
+    import random
+    from pcgnn_amd import graphsage as GS
+    c = case
+    feats = torch.nn.Embedding(c.n, c.f)
+    feats.weight = torch.nn.Parameter(torch.from_numpy(c.X.copy()), requires_grad=False)
+    homo = c.adj(None)
+    sub = c.z["s1_nodes"].tolist()
+    k, seed = int(c.z["s1_fanout_k"]), int(c.z["s1_fanout_seed"])
+    for gcn, key in ((False, "s1_fanout_mean"), (True, "s1_fanout_mean_gcn")):
+        agg = GS.MeanAggregator(feats, cuda=True, gcn=gcn)
+        agg._dev = dev()
+        random.seed(seed)
+        fsets = [set(sorted(homo[int(v)])) for v in sub]
+        got = agg.forward(sub, fsets, num_sample=k)
+        np.testing.assert_allclose(got.cpu().numpy(), c.z[key], rtol=0, atol=FEAT_TOL)
+
+
 def test_eval_loop_matches_reference_probabilities(P, case):
     """utils.test mirror (utils.py:280-333): batched inference -> metrics, torch path and fused path."""
     from pcgnn_amd import utils as U
@@ -546,37 +606,63 @@ def test_eval_loop_matches_reference_probabilities(P, case):
 # ---------------------------------------------------------------------------
 # BASELINE-size workload (configs[1]: YelpChi-shaped graph, batch 1024): size-independent properties
 # ---------------------------------------------------------------------------
-def test_full_size_properties_yelp_like(P):
+def _full_size_workload(name):
     from pcgnn_amd import synth
+    if name == "yelp":
+        return synth.yelp_like(0), 1024
+    if name == "amazon":
+        return synth.amazon_like(0), 256
+    # power-law: 200 K nodes / 4 M edges, the most popular node capped at 0.5 % of a relation's endpoints, so that rows of
+    # every degree tier (<= 128, <= 512, <= 4096, > 4096, > 12288 -> global scratch) occur
+    return synth.power_law(200_000, 4_000_000, 0, max_share=5e-3), 4096
+
+
+@pytest.mark.parametrize("wname,rho", [("yelp", 0.5), ("amazon", 0.2), ("amazon", 0.5), ("amazon", 0.8), ("powerlaw", 0.5)])
+def test_full_size_properties(P, wname, rho):
+    """BASELINE-size workloads (configs[1]: YelpChi-shaped batch 1024; configs[4]: Amazon-shaped batch 256, rho sweep;
+    configs[3] shape: power-law, batch 4096): properties that hold at any size - idempotence, the selection lists are
+    sets, kept neighbours an ascending subset of the row, the count law, every mean recomputed in float64 from the
+    materialised lists - plus the oracle's chosen sets on a strided sample of rows, plus a few training epochs."""
     from pcgnn_amd.handler import PCGNNTrainer
     ops = P.ops
-    w = synth.yelp_like(0)
-    tr = PCGNNTrainer(w, dict(engine="fused", batch_size=1024), dev())
+    w, B = _full_size_workload(wname)
+    tr = PCGNNTrainer(w, dict(engine="fused", batch_size=B, rho=rho), dev())
     g, fz = tr.graph, tr.fused
-    ids = tr.start_epoch(0)[:1024].contiguous()
+    ids = tr.start_epoch(0)[:B].contiguous()
+    if wname == "powerlaw":       # make sure the longest rows of every relation are in the batch
+        top = np.unique(np.concatenate([np.argsort(np.diff(ip))[-3:] for ip, _ in w.csr])).astype(np.int32)
+        ids[:len(top)] = torch.from_numpy(top).to(ids.device)
     lab = tr.labels_i32[ids.long()]
     s0 = ops.score_table(g, fz.w_clf, fz.b_clf)
     keys = ops.pos_sort(g, s0)
-    B, R = 1024, g.R
+    R = g.R
     ids_h, lab_h = ids.cpu().numpy(), lab.cpu().numpy()
+    s0_h = s0.cpu().numpy()
     tp = set(w.train_pos)
+    if wname == "powerlaw":
+        degs = np.concatenate([np.diff(ip)[ids_h] for ip, _ in w.csr])
+        assert (degs <= 128).any() and ((degs > 128) & (degs <= 512)).any() and ((degs > 512) & (degs <= 4096)).any() \
+            and (degs > 4096).any() and (degs > 12288).any(), "every degree tier must be exercised"
     for train in (False, True):
         ws = ops.ChooseWorkspace(g, B)
-        agg, cnt = ops.choose_aggregate(g, ids, lab if train else None, s0, keys if train else None, [0.5] * R, 0.5, train, ws=ws)
-        agg2, cnt2 = ops.choose_aggregate(g, ids, lab if train else None, s0, keys if train else None, [0.5] * R, 0.5, train, ws=ws)
+        agg, cnt = ops.choose_aggregate(g, ids, lab if train else None, s0, keys if train else None, [0.5] * R, rho, train, ws=ws)
+        agg2, cnt2 = ops.choose_aggregate(g, ids, lab if train else None, s0, keys if train else None, [0.5] * R, rho, train, ws=ws)
         torch.cuda.synchronize()
+        ws.check()
         assert torch.equal(agg, agg2) and torch.equal(cnt, cnt2), "idempotent and run-to-run bitwise reproducible"
         begin = ws.view(0, torch.int64, R * B + 1).cpu().numpy()
         length = ws.view(1, torch.int32, R * B).cpu().numpy()
         lst = ws.view(2, torch.int32, int(begin[-1])).cpu().numpy()
         cnt_h = cnt.cpu().numpy()
-        # recompute every mean from the materialised lists in float64 on the host (size-independent check of gather + combine)
+        agg_h = agg.cpu().numpy()
+        stride = 7 if B <= 1024 else 29
         for r in range(R):
             indptr, idx = w.csr[r]
             deg = np.diff(indptr)[ids_h]
             k = np.ceil(deg * 0.5).astype(np.int64)
             kept = np.where(deg > k + 1, k, deg)
-            for b in range(0, B, 7):                      # every 7th centre: ~150 rows per relation, hubs included
+            probe = sorted(set(range(0, B, stride)) | set(range(8)))       # strided rows + the forced hub rows
+            for b in probe:
                 row = r * B + b
                 seg = lst[begin[row]:begin[row] + length[row]]
                 chosen = seg[seg >= 0]
@@ -588,10 +674,17 @@ def test_full_size_properties_yelp_like(P):
                 if not train or lab_h[b] != 1:
                     assert len(extra) == 0 and cnt_h[r, b] == kept[b]
                 else:
-                    m = min(int(k[b] * 0.5), len(w.train_pos))
+                    m = min(int(k[b] * rho), len(w.train_pos))
                     assert len(extra) <= m and all(int(e) in tp for e in extra) and not np.isin(extra, first).any()
                 ref = w.X[chosen].astype(np.float64).mean(0)
-                np.testing.assert_allclose(agg[r, b].cpu().numpy(), ref, rtol=0, atol=2e-5)
+                np.testing.assert_allclose(agg_h[r, b], ref, rtol=0, atol=2e-5)
+            # the oracle's sets (same device scores => bit-exact) on the probed rows
+            want = oracle_sets(w.csr[r], w.n, [int(ids_h[b]) for b in probe], [int(lab_h[b]) for b in probe] if train else None,
+                               s0_h, w.train_pos, 0.5, rho, train)
+            for b, ws_ in zip(probe, want):
+                row = r * B + b
+                seg = lst[begin[row]:begin[row] + length[row]]
+                assert set(seg[seg >= 0].tolist()) == ws_, f"{wname} rel {r} row {b} (deg {deg[b]}) train={train}"
         # test mode count law over ALL rows at once
         if not train:
             for r in range(R):
@@ -599,7 +692,7 @@ def test_full_size_properties_yelp_like(P):
                 k = np.ceil(deg * 0.5).astype(np.int64)
                 assert np.array_equal(cnt_h[r], np.where(deg > k + 1, k, deg))
     # a few training epochs through the hipGraph engine: finite loss that goes down
-    tr2 = PCGNNTrainer(w, dict(engine="graph", batch_size=1024), dev())
+    tr2 = PCGNNTrainer(w, dict(engine="graph", batch_size=B, rho=rho), dev())
     losses = []
     for e in range(4):
         tr2.train_epoch(e)
@@ -732,3 +825,48 @@ def test_fused_trajectory_tracks_oracle(P, case):
     sd = m.state_dict()
     for k in PARAM_KEYS(c.R):
         np.testing.assert_allclose(sd[k].cpu().numpy(), om.p[k].detach().numpy(), rtol=0, atol=c.lr * 0.3, err_msg=k)
+
+
+def test_list_overflow_is_reported_not_silent(P):
+    """A selection list too small for a batch: the kernels select nothing and set the status word; the engine must raise at
+    its next check point (last_loss / check / utils.test) instead of training on stale aggregates."""
+    from pcgnn_amd import synth, utils as U
+    from pcgnn_amd.handler import PCGNNTrainer
+    from pcgnn_amd.fused import FusedPCGNN
+    w = synth.make_workload("mini", 4000, 32, (3000, 20000, 60000), 0.12, seed=2)
+    tr = PCGNNTrainer(w, dict(engine="fused", batch_size=256), dev())
+    small = FusedPCGNN(tr.model, 0.01, 0.001, max_batch=256, list_capacity=500)
+    ids = tr.start_epoch(0)[:256].contiguous()
+    lab = tr.labels_i32[ids.long()]
+    small.train_step(ids, lab)
+    with pytest.raises(P.PcgnnLibraryError, match="overflow"):
+        small.last_loss()
+    small.check()                                   # the word was cleared by the report
+    with pytest.raises(P.PcgnnLibraryError, match="overflow"):
+        U.test(ids.cpu().numpy(), lab.cpu().numpy(), small, batch_size=256, print_line=False)
+    # the same engine with room: no error, and the default capacity of this graph is not clipped
+    tr.fused.train_step(ids, lab)
+    assert np.isfinite(float(tr.fused.last_loss()))
+    assert not tr.fused._ws(256).clipped
+
+
+def test_realloc_between_epoch_graphs(P):
+    """predict() with a batch larger than max_batch re-allocates every buffer; the whole-epoch graphs captured before
+    (raw pointers into the old buffers) must not be replayed afterwards: the next epoch_run re-captures and the
+    trajectory equals a run that never re-allocated."""
+    from pcgnn_amd import synth
+    from pcgnn_amd.handler import PCGNNTrainer
+    w = synth.make_workload("mini", 6000, 32, (4000, 30000, 90000), 0.12, seed=3)
+    cfg = dict(engine="graph", batch_size=256, seed=5)
+    a, b = PCGNNTrainer(w, cfg, dev()), PCGNNTrainer(w, cfg, dev())
+    b.fused.theta.copy_(a.fused.theta)
+    big = torch.arange(700, dtype=torch.int32, device=dev())
+    for ep in range(3):
+        a.run_epoch_one_graph()
+        b.run_epoch_one_graph()
+        if ep == 0:
+            out = b.fused.predict(big, None, False)[0]          # B = 700 > 256: _alloc
+            assert out.shape == (700, 2) and b.fused.maxB == 700 and not b.fused._ep_graphs
+    torch.cuda.synchronize()
+    for name in ("theta", "m", "v", "step_counter"):
+        assert torch.equal(getattr(a.fused, name), getattr(b.fused, name)), name

@@ -10,7 +10,8 @@ import torch
 from oracle import pcgnn_oracle as O
 from tests.util import GOLDEN, PARAM_KEYS, GoldenCase
 
-CASES = ["yelp_small", "amazon_small", "single_rel"]
+CASES = ["yelp_small", "amazon_small", "single_rel", "yelp_emb128", "feat100", "five_rel"]
+SEEDS = {"yelp_small": 3, "amazon_small": 5, "single_rel": 9, "yelp_emb128": 13, "feat100": 17, "five_rel": 37}   # make_golden.py
 FTOL = 2e-6   # float outputs: oracle vs reference (different sgemm column order only)
 
 
@@ -52,7 +53,7 @@ def test_pick_matches_reference(case):
     got = O.pick_from_uniforms(idx_train, cum, c.z["pick_uniforms"].tolist())
     assert got == c.z["pick_out"].tolist()
     # and through random.choices itself with the generator's seed
-    seed = {"yelp_small": 3, "amazon_small": 5, "single_rel": 9}[c.name]
+    seed = SEEDS[c.name]
     assert O.pick_step(idx_train, y_train, homo, len(got), random.Random(seed)) == got
 
 
@@ -128,3 +129,19 @@ def test_graphsage_aggregators(case):
     np.testing.assert_allclose(enc.numpy(), c.z["s1_sage_enc"], rtol=0, atol=FTOL)
     enc = O.encoder_forward(O.gcn_mean(sub, homo, X), None, torch.from_numpy(c.z["s1_gcn_enc_w"]))
     np.testing.assert_allclose(enc.numpy(), c.z["s1_gcn_enc"], rtol=0, atol=5e-6)
+
+
+def test_graphsage_random_fanout(case):
+    """MeanAggregator.forward(..., num_sample=k) (graphsage.py:70-74): random.sample over each neighbour set under a
+    seeded `random`.  The fixture's sets were built as set(sorted(.)); rebuilt the same way they iterate in the same
+    order under the same CPython, so the same seed draws the same samples."""
+    c = case
+    X = torch.from_numpy(c.X)
+    homo = c.adj(None)
+    sub = c.z["s1_nodes"].tolist()
+    k, seed = int(c.z["s1_fanout_k"]), int(c.z["s1_fanout_seed"])
+    for gcn, key in ((False, "s1_fanout_mean"), (True, "s1_fanout_mean_gcn")):
+        fsets = [set(sorted(homo[int(v)])) for v in sub]
+        got = O.sage_mean_fanout(sub, fsets, X, k, random.Random(seed), gcn=gcn)
+        np.testing.assert_allclose(got.numpy(), c.z[key], rtol=0, atol=FTOL)
+    assert any(len(s) > k for s in fsets), "the fixture must exercise the sampling branch"
