@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBNAME = "libpcgnn_hip.so"
-SOURCES = ["score.hip", "sort.hip", "segmean_pick.hip", "choose.hip", "dense.hip", "halo.hip"]
+SOURCES = ["score.hip", "sort.hip", "segmean_pick.hip", "choose.hip", "select.hip", "gather.hip", "dense.hip", "halo.hip"]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 
@@ -30,7 +30,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found - cannot build libpcgnn_hip.so")
     os.makedirs(LIBDIR, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "pcgnn.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "choose.h"), os.path.join(HERE, "..", "include", "pcgnn.h")]
     objs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

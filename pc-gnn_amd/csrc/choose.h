@@ -1,0 +1,107 @@
+// Shared between the plan / front kernels (choose.hip), the select kernel (select.hip) and the gather kernel
+// (gather.hip): workspace layout, per-row records, launch arguments.
+#pragma once
+#include "common.h"
+
+namespace pcg {
+
+// ---- degree tiers of the select kernel --------------------------------------------------------------------------------
+constexpr int TA_CAP = 16;       // rows of <= 16 neighbours: four per wave, 16 lanes each, ranked with DPP row rotations
+constexpr int TB_CAP = 64;       // rows of <= 64: one wave, one key per lane, ranked lane against lane
+constexpr int T1_CAP = 512;      // rows of <= 512: one wave, up to 8 keys per lane in registers, 256-bin LDS histogram rounds
+constexpr int T4_CAP = 4096;     // workgroup rows are queued in two classes (> 4096 first) so that the longest start first
+constexpr int WG_KEYCAP = 10240; // workgroup rows up to this length keep their distance keys in LDS; longer ones recompute them
+constexpr int SEL_NW = 8;        // waves per select workgroup
+constexpr int SEL_BLOCKS = 512;  // persistent select workgroups: 2 per CU (96 VGPRs: 5 waves per SIMD)
+constexpr int HIST_WG = 2048;    // histogram bins of a workgroup row
+constexpr int HIST_W = 256;      // histogram bins of a single-wave row
+constexpr int WAVE_AREA = WG_KEYCAP / SEL_NW;   // LDS words a wave owns while it works on single-wave rows
+constexpr int CHUNK = 128;       // list entries per gather work item
+constexpr int PLAN_THREADS = 1024;
+constexpr int PLAN_PER = 4;      // rows per plan thread per tile
+constexpr int FRONT_COUNT_THREADS = 256;
+
+// counters (uint32) at the head of the workspace
+enum { C_N1 = 0, C_N4 = 1, C_N16 = 2, C_NCHUNK = 5, C_N0 = 8, C_NA = 9, C_TICKET = 16 /* .. 16 + 8: gather's arrival shards */ };
+
+struct RowRec {            // 32 bytes, written by the plan, read by select: one 32-B load instead of a 3-deep chain
+    int64_t start;         // offset of the row in indices[r]
+    int32_t node, d, k, m; // centre, degree, ceil(d * threshold), minority picks (0 unless a positive centre in training)
+    int32_t lbeg;          // first entry of the row's region in the selection list (list_capacity < 2^31)
+    int32_t chunk0;        // first gather chunk of the row
+};
+__host__ __device__ __forceinline__ bool rec_keep_all(const RowRec &p) { return !(p.d > p.k + 1); }   // layers.py:662
+__host__ __device__ __forceinline__ int rec_cap(const RowRec &p, int add_self) {
+    return (rec_keep_all(p) ? p.d : p.k) + p.m + (add_self ? 1 : 0);
+}
+
+struct Workspace {
+    uint32_t *counters;    // [64]
+    int64_t *row_begin;    // [rows + 1] start of every row's region in list
+    int32_t *chunk_begin;  // [rows + 1]
+    int32_t *len;          // [rows]     entries (holes included) actually written
+    int32_t *q0, *q1, *q4, *q16, *qa;  // [rows] each: the rows of every degree tier
+    struct RowRec *recs;   // [rows] what the plan worked out per row
+    unsigned char *plan_totals;   // [blocks of the two-pass plan] PlanTotals
+    int4 *chunk_desc;      // [chunk_cap] per gather chunk: {row, first list entry, entries in use (select), chunks of the row}
+    float *partial;        // [chunk_cap, feat_stride]
+    uint32_t *row_ticket;  // [rows] arrivals of a multi-chunk row's chunks (gather; reset by the row's last chunk)
+    int32_t *list;         // [list_capacity]  chosen ids; -1 = hole
+    int64_t list_capacity, chunk_cap;
+};
+
+static inline int64_t align256(int64_t x) { return (x + 255) / 256 * 256; }
+
+static inline int64_t carve(const pcg_graph_desc *g, int32_t B, int64_t list_capacity, unsigned char *base, Workspace *w) {
+    const int64_t rows = (int64_t)g->n_rel * B;
+    const int64_t chunk_cap = list_capacity / CHUNK + rows + 1;
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) {
+        const int64_t o = off;
+        off += align256(bytes);
+        return base ? base + o : nullptr;
+    };
+    unsigned char *p;
+    p = take(256);                                 if (w) w->counters = reinterpret_cast<uint32_t *>(p);
+    p = take(8 * (rows + 1));                      if (w) w->row_begin = reinterpret_cast<int64_t *>(p);
+    p = take(4 * (rows + 1));                      if (w) w->chunk_begin = reinterpret_cast<int32_t *>(p);
+    p = take(4 * rows);                            if (w) w->len = reinterpret_cast<int32_t *>(p);
+    p = take(4 * rows);                            if (w) w->q0 = reinterpret_cast<int32_t *>(p);
+    p = take(4 * rows);                            if (w) w->q1 = reinterpret_cast<int32_t *>(p);
+    p = take(4 * rows);                            if (w) w->q4 = reinterpret_cast<int32_t *>(p);
+    p = take(4 * rows);                            if (w) w->q16 = reinterpret_cast<int32_t *>(p);
+    p = take(4 * rows);                            if (w) w->qa = reinterpret_cast<int32_t *>(p);
+    p = take(32 * rows);                           if (w) w->recs = reinterpret_cast<RowRec *>(p);
+    p = take(64 * (rows / 256 + 2));               if (w) w->plan_totals = p;   // PlanTotals (<= 64 B) per 256 rows
+    p = take(16 * chunk_cap);                      if (w) w->chunk_desc = reinterpret_cast<int4 *>(p);
+    p = take(4 * chunk_cap * g->feat_stride);      if (w) w->partial = reinterpret_cast<float *>(p);
+    p = take(4 * rows);                            if (w) w->row_ticket = reinterpret_cast<uint32_t *>(p);
+    p = take(4 * list_capacity);                   if (w) w->list = reinterpret_cast<int32_t *>(p);
+    if (w) {
+        w->list_capacity = list_capacity;
+        w->chunk_cap = chunk_cap;
+    }
+    return off;
+}
+
+struct ChooseArgs {
+    pcg_graph_desc g;
+    const int32_t *nodes;
+    const int32_t *labels;
+    int32_t B;
+    const float *s0;
+    const float *center_s0;
+    const uint64_t *pos_keys;
+    double thr[PCG_MAX_REL];
+    double rho[PCG_MAX_REL];
+    int32_t train_flag, add_self;
+    int32_t *cnt;          // [rows] |chosen set|
+    uint32_t *status;
+    unsigned long long *stamps;   // diagnostic only (pcg_debug_set_stamps): [rows][8] wall-clock ticks per phase, else null
+    Workspace w;
+};
+
+// select.hip
+int launch_select_rows(const ChooseArgs &a, hipStream_t st);
+
+}  // namespace pcg

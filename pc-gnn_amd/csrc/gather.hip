@@ -1,0 +1,221 @@
+// Segmented mean over the selection lists (src/layers.py:594-624; src/graphsage.py:82-95, 216-231) for gfx950.
+//
+//   gather   chip-wide balanced: one wave per 128-entry chunk of a row's list, feature rows gathered 64/lpr per
+//            wave-instruction (128-B rows: 8 rows = 1 KiB), 8 in flight, f32 segmented sum; single-chunk rows are
+//            finished here
+//   combine  rows longer than one chunk: partial sums added in chunk order (bitwise reproducible), divided by |set|
+//            (or its sqrt)
+#include "choose.h"
+
+namespace pcg {
+
+constexpr int UNROLL = 8;        // row-gather instructions in flight per wave
+constexpr int GATHER_BLOCKS = 2048;
+
+struct AggArgs {
+    const float *X;
+    int32_t feat_dim, feat_stride;
+    int32_t n_rows;             // n_rel * B
+    const int64_t *row_begin;
+    const int32_t *chunk_begin;
+    const int32_t *len;
+    const int32_t *cnt;
+    const int4 *chunk_desc;
+    int32_t chunk_cap;
+    const int32_t *list;
+    const uint32_t *n_chunks;   // device word
+    float *partial;
+    float *agg;                 // [n_rows, agg_stride]
+    int32_t agg_stride, norm;
+};
+
+struct RowGeom {  // how one wave-instruction covers feature rows
+    int lpr, rpw, slot, sub, nch;
+};
+
+__device__ __forceinline__ RowGeom row_geom(int stride, int lane) {
+    RowGeom q;
+    q.lpr = lanes_per_row(stride);
+    q.rpw = PCG_WAVE / q.lpr;
+    q.slot = lane / q.lpr;
+    q.sub = lane % q.lpr;
+    q.nch = stride >> 2;
+    return q;
+}
+
+template <int NACC>
+__device__ __forceinline__ void store_row(float *out, const float4 (&acc)[NACC], const RowGeom &q, int feat_dim,
+                                          float den) {
+#pragma unroll
+    for (int x = 0; x < NACC; ++x) {
+        const int ch = x * q.lpr + q.sub;
+        if (ch >= q.nch) continue;
+        const int f = 4 * ch;
+        if (f + 0 < feat_dim) out[f + 0] = acc[x].x / den;
+        if (f + 1 < feat_dim) out[f + 1] = acc[x].y / den;
+        if (f + 2 < feat_dim) out[f + 2] = acc[x].z / den;
+        if (f + 3 < feat_dim) out[f + 3] = acc[x].w / den;
+    }
+}
+
+template <int NACC>
+__global__ void __launch_bounds__(256) gather_chunks(const AggArgs a) {
+    const int lane = lane_id();
+    const RowGeom q = row_geom(a.feat_stride, lane);
+    const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t ch0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    // the chunk's descriptor (written by the plan) is requested together with the chunk count: one load level instead of
+    // four (count -> row -> offsets -> list).  n = the entries of the chunk the select kernel filled (it overwrites the
+    // capacity share the plan put there; nothing fills a region's unused tail).
+    int4 desc = a.chunk_desc[ch0 < (uint32_t)a.chunk_cap ? ch0 : 0u];
+    const uint32_t total = *a.n_chunks;
+    for (uint32_t ch = ch0; ch < total; ch += nwaves) {
+        if (ch != ch0) desc = a.chunk_desc[ch];
+        const int row = desc.x, n = desc.z, nch_row = desc.w;
+        const int32_t *__restrict__ list = a.list + desc.y;
+        const int cnt = nch_row == 1 ? a.cnt[row] : 1;
+        float4 acc[NACC];
+#pragma unroll
+        for (int x = 0; x < NACC; ++x) acc[x] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int per_iter = q.rpw * UNROLL;
+        for (int base = 0; base < n; base += per_iter) {
+            float4 v[UNROLL][NACC];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int i = base + u * q.rpw + q.slot;
+                const int id = i < n ? list[i] : -1;                  // -1: hole left by a duplicate
+                const bool ok = id >= 0;
+                const float *rowp = a.X + (size_t)(ok ? id : 0) * a.feat_stride;
+#pragma unroll
+                for (int x = 0; x < NACC; ++x) {
+                    const int c4 = x * q.lpr + q.sub;
+                    v[u][x] = (ok && c4 < q.nch) ? *reinterpret_cast<const float4 *>(rowp + 4 * c4)
+                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+                for (int x = 0; x < NACC; ++x) {
+                    acc[x].x += v[u][x].x;
+                    acc[x].y += v[u][x].y;
+                    acc[x].z += v[u][x].z;
+                    acc[x].w += v[u][x].w;
+                }
+        }
+#pragma unroll
+        for (int x = 0; x < NACC; ++x)
+            for (int o = q.lpr; o < PCG_WAVE; o <<= 1) {
+                acc[x].x += __shfl_xor(acc[x].x, o);
+                acc[x].y += __shfl_xor(acc[x].y, o);
+                acc[x].z += __shfl_xor(acc[x].z, o);
+                acc[x].w += __shfl_xor(acc[x].w, o);
+            }
+        if (lane < q.lpr) {
+            if (nch_row == 1) {
+                const float den = a.norm == PCG_NORM_SQRT_COUNT ? sqrtf((float)cnt) : (float)cnt;
+                store_row<NACC>(a.agg + (size_t)row * a.agg_stride, acc, q, a.feat_dim, den);
+            } else {
+                float *pp = a.partial + (size_t)ch * a.feat_stride;
+#pragma unroll
+                for (int x = 0; x < NACC; ++x) {
+                    const int c4 = x * q.lpr + q.sub;
+                    if (c4 < q.nch) *reinterpret_cast<float4 *>(pp + 4 * c4) = acc[x];
+                }
+            }
+        }
+    }
+}
+
+// rows longer than one chunk: add the partial sums in chunk order
+template <int NACC>
+__global__ void __launch_bounds__(256) combine_rows(const AggArgs a) {
+    const int lane = lane_id();
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= a.n_rows || *a.n_chunks == 0) return;
+    const int cb = a.chunk_begin[row], nch_row = a.chunk_begin[row + 1] - cb;
+    if (nch_row <= 1) {
+        if (nch_row == 0 && lane < a.feat_dim) {   // cap == 0: empty set -> 0/0 like the reference's mask.div
+            for (int f = lane; f < a.feat_dim; f += PCG_WAVE) a.agg[(size_t)row * a.agg_stride + f] = 0.f / 0.f;
+        }
+        return;
+    }
+    const RowGeom q = row_geom(a.feat_stride, lane);
+    if (lane >= q.lpr) return;
+    const int cnt = a.cnt[row];
+    float4 acc[NACC];
+#pragma unroll
+    for (int x = 0; x < NACC; ++x) acc[x] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // the partial sums are added in chunk order; their loads are issued a batch at a time (the row with the most chunks
+    // sets this kernel's duration: one load latency per batch instead of one per chunk)
+    constexpr int CB = NACC == 1 ? 16 : 8;
+    for (int j0 = 0; j0 < nch_row; j0 += CB) {
+        float4 t[CB][NACC];
+#pragma unroll
+        for (int u = 0; u < CB; ++u) {
+            const float *pp = a.partial + (size_t)(cb + j0 + u) * a.feat_stride;
+#pragma unroll
+            for (int x = 0; x < NACC; ++x) {
+                const int c4 = x * q.lpr + q.sub;
+                t[u][x] = (j0 + u < nch_row && c4 < q.nch) ? *reinterpret_cast<const float4 *>(pp + 4 * c4)
+                                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < CB; ++u)
+#pragma unroll
+            for (int x = 0; x < NACC; ++x) {
+                if (j0 + u < nch_row) {
+                    acc[x].x += t[u][x].x; acc[x].y += t[u][x].y; acc[x].z += t[u][x].z; acc[x].w += t[u][x].w;
+                }
+            }
+    }
+    const float den = a.norm == PCG_NORM_SQRT_COUNT ? sqrtf((float)cnt) : (float)cnt;
+    store_row<NACC>(a.agg + (size_t)row * a.agg_stride, acc, q, a.feat_dim, den);
+}
+
+template <int NACC>
+static int launch_aggregate(const AggArgs &g, hipStream_t st) {
+    hipLaunchKernelGGL(gather_chunks<NACC>, dim3(GATHER_BLOCKS), dim3(256), 0, st, g);
+    PCG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(combine_rows<NACC>, dim3((g.n_rows + 3) / 4), dim3(256), 0, st, g);
+    PCG_LAUNCH_CHECK();
+    return PCG_OK;
+}
+
+}  // namespace pcg
+
+extern "C" {
+
+int pcg_aggregate_lists(const float *X, int32_t feat_dim, int32_t feat_stride, int32_t n_rows, const int32_t *cnt,
+                        const pcg_graph_desc *g, int32_t B, void *workspace, int64_t list_capacity, int32_t norm,
+                        float *agg, int32_t agg_stride, void *stream) {
+    if (!X || !cnt || !g || !workspace || !agg || n_rows < 0 || B < 0) return PCG_E_ARG;
+    if (n_rows == 0) return PCG_OK;
+    if (feat_stride % 4 != 0 || feat_stride < feat_dim || agg_stride < feat_dim) return PCG_E_ARG;
+    if (feat_stride > 512) return PCG_E_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(X) & 15u) != 0) return PCG_E_ARG;
+    pcg::Workspace w;
+    pcg::carve(g, B, list_capacity, static_cast<unsigned char *>(workspace), &w);
+    pcg::AggArgs a;
+    a.X = X;
+    a.feat_dim = feat_dim;
+    a.feat_stride = feat_stride;
+    a.n_rows = n_rows;
+    a.row_begin = w.row_begin;
+    a.chunk_begin = w.chunk_begin;
+    a.len = w.len;
+    a.cnt = cnt;
+    a.chunk_desc = w.chunk_desc;
+    a.chunk_cap = (int32_t)w.chunk_cap;
+    a.list = w.list;
+    a.n_chunks = w.counters + pcg::C_NCHUNK;
+    a.partial = w.partial;
+    a.agg = agg;
+    a.agg_stride = agg_stride;
+    a.norm = norm;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return feat_stride <= 256 ? pcg::launch_aggregate<1>(a, st) : pcg::launch_aggregate<2>(a, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,895 @@
+// The choose step (src/layers.py:633-738) for gfx950: ONE persistent launch selects every (relation, centre) row of a batch.
+//
+// Selection rule of a row with d neighbours (ascending ids), k = ceil(d * threshold):
+//   d <= k + 1 : keep all;  else keep the k smallest distance keys |s0[centre] - s0[j]|, ties by row position.
+// A distance is a non-negative float, so its bit pattern orders like its value: keys are uint32 and everything below is
+// integer work.  How a row finds its k-th smallest key depends on its length:
+//   <= 16  (four rows per wave, 16 lanes each) every lane ranks its key against the 15 others with DPP row rotations;
+//   <= 64  (one wave) one key per lane, ranked lane against lane (v_readlane), both exact with the positional tie-break
+//          built in: no k-th value is ever formed;
+//   <= 512 (one wave) up to 8 keys per lane stay in registers; rounds of a 256-bin LDS histogram over the bit range
+//          [lo, hi] that still holds the k-th key, until <= 64 candidates are left, which are ranked in one wave;
+//   longer (one workgroup of 8 waves) keys in LDS (rows <= 10240) or recomputed from the scores on every pass (longer
+//          still: no scratch memory anywhere), 2048-bin histogram rounds, same finish.
+// A histogram round narrows [lo, hi] by the factor of its bin count whatever the key distribution, so the number of
+// rounds is bounded (31 bits / 8 or 11 bits per round) and usually one round + the in-wave finish is all it takes.
+// Kept ids are compacted in row order (ascending ids) into the row's region of the selection list; positive centres in
+// training add their minority picks (64-ary window search in the per-step sorted train-pos keys, de-duplicated against
+// the kept ids by binary search; a duplicate leaves a -1 hole so slots - and sums - keep a fixed order).
+// Nothing fills the unused tail of a row's region: the row writes how many entries each of its gather chunks holds.
+//
+// Rows are assigned statically (no queue atomics): workgroup rows strided over the workgroups from the first one on,
+// longest class first; single-wave rows strided over the waves from the LAST workgroup on.
+#include <limits.h>
+
+#include "choose.h"
+
+namespace pcg {
+
+constexpr int KEY_UNROLL = 8;    // neighbour-score gathers in flight per lane
+constexpr int KPT = T1_CAP / PCG_WAVE;   // keys per lane of a single-wave register row
+
+#define PCG_STAMP(slot)                                                                \
+    do {                                                                               \
+        if (a.stamps && tid == 0) a.stamps[(size_t)row * 8 + (slot)] = wall_clock64(); \
+    } while (0)
+
+template <int NW>
+__device__ __forceinline__ void grp_sync() {
+    if constexpr (NW > 1) __syncthreads();
+}
+
+// exclusive prefix of a wave-uniform value over the group's waves, and the total
+template <int NW>
+__device__ __forceinline__ void grp_scan(int v, int wave, int lane, int *red, int &prefix, int &total) {
+    if constexpr (NW == 1) {
+        prefix = 0;
+        total = v;
+    } else {
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        int p = 0, t = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const int x = red[w];
+            if (w < wave) p += x;
+            t += x;
+        }
+        __syncthreads();
+        prefix = p;
+        total = t;
+    }
+}
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    for (int o = 1; o < PCG_WAVE; o <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_xor((int)v, o);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    for (int o = 1; o < PCG_WAVE; o <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_xor((int)v, o);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+    for (int o = 1; o < PCG_WAVE; o <<= 1) {
+        const int t = __shfl_up(v, o);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ bool sorted_contains(const uint32_t *list, int n, uint32_t x) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (list[mid] < x) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo < n && list[lo] == x;
+}
+
+__device__ __forceinline__ float pos_score(const uint64_t *pk, int i) { return from_orderable((uint32_t)(pk[i] >> 32)); }
+__device__ __forceinline__ uint32_t pos_dkey(const uint64_t *pk, int i, float c) { return dist_key(c, pos_score(pk, i)); }
+
+// First x in [lo, hi] with pred(x) false, pred being true on a prefix of [lo, hi).
+// 64 probes per step (one memory latency each) instead of one.
+template <class Pred>
+__device__ __forceinline__ int wave_partition_point(int lo, int hi, int lane, Pred pred) {
+    for (;;) {
+        const int n = hi - lo;
+        if (n <= 0) return lo;
+        if (n <= PCG_WAVE) {
+            const int idx = lo + lane;
+            return lo + wave_count(idx < hi && pred(idx));
+        }
+        const int step = (n + PCG_WAVE - 1) >> 6;
+        int q = lo + (lane + 1) * step - 1;
+        if (q > hi - 1) q = hi - 1;
+        const int c = wave_count(pred(q));
+        if (c == PCG_WAVE) return hi;
+        int qc = lo + (c + 1) * step - 1;   // first probe that answered false
+        if (qc > hi - 1) qc = hi - 1;
+        if (c > 0) {
+            int ql = lo + c * step - 1;
+            if (ql > hi - 1) ql = hi - 1;
+            lo = ql + 1;
+        }
+        hi = qc;
+    }
+}
+
+// first index in [i0, end) whose distance key != kstar (or end); all lanes take part
+__device__ __forceinline__ int run_end_fwd(const uint64_t *pk, float c, uint32_t kstar, int i0, int end, int lane) {
+    for (int i = i0; i < end; i += PCG_WAVE) {
+        const int j = i + lane;
+        const bool same = j < end && pos_dkey(pk, j, c) == kstar;
+        const uint64_t bad = ~__ballot(same);
+        if (bad) {
+            const int f = i + (__ffsll((unsigned long long)bad) - 1);
+            return f < end ? f : end;
+        }
+    }
+    return end;
+}
+// smallest x in [low, i0+1] such that every index in [x, i0] has key == kstar (i0+1 if none)
+__device__ __forceinline__ int run_begin_bwd(const uint64_t *pk, float c, uint32_t kstar, int i0, int low, int lane) {
+    for (int i = i0; i >= low; i -= PCG_WAVE) {
+        const int j = i - lane;
+        const bool same = j >= low && pos_dkey(pk, j, c) == kstar;
+        const uint64_t bad = ~__ballot(same);
+        if (bad) {
+            const int f = i - (__ffsll((unsigned long long)bad) - 1);  // first non-matching going down
+            return (f >= low ? f : low - 1) + 1;
+        }
+    }
+    return low;
+}
+
+// The k-th smallest (1-based rank `want`) of <= 64 candidate keys, one per lane (`have` lanes): its value, how many
+// candidates equal it and how many of those belong to the `want` smallest.  Every lane gets the same answer.
+__device__ __forceinline__ void wave_kth(uint32_t ck, bool have, int n, int want, uint32_t &kstar, int &need, int &n_equal) {
+    int lt = 0, eq = 0;
+    for (int j = 0; j < n; ++j) {                                            // n is wave-uniform
+        const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)ck, j);
+        lt += o < ck;
+        eq += o == ck;
+    }
+    const int r = want - 1;
+    const uint64_t hit = __ballot(have && lt <= r && r < lt + eq);
+    const int src = hit ? __ffsll((unsigned long long)hit) - 1 : 0;
+    kstar = (uint32_t)__builtin_amdgcn_readlane((int)ck, src);
+    n_equal = __builtin_amdgcn_readlane(eq, src);
+    need = want - __builtin_amdgcn_readlane(lt, src);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Shared tail of every row (layers.py:675-694): minority over-sampling for positive centres, GCN-style self union,
+// the kept ids to the list (unless the caller has stored them already), |set|, length and the chunk fill counts.
+// sel[0 .. ns): the kept neighbour ids, ascending - LDS, or (over-long rows) the row's own region of the global list.
+// NW waves work on the row (tid / NT: thread index and count inside the group); red: 2 * NW + 2 ints of LDS (NW > 1).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NW>
+__device__ __forceinline__ void finish_row(const ChooseArgs &a, int row, const RowRec &p, float c, const uint32_t *sel, int ns,
+                                           bool sel_stored, int wave, int lane, int *red) {
+    constexpr int NT = NW * PCG_WAVE;
+    const int tid = wave * PCG_WAVE + lane;
+    const int m = p.m, node = p.node;
+    int32_t *__restrict__ out = a.w.list + p.lbeg;
+    int mt = 0;        // slots used
+    int valid = 0;     // per-thread count of non-duplicate minority picks
+    if (m > 0) {
+        const uint64_t *__restrict__ pk = a.pos_keys;
+        const int P = a.g.n_pos;
+        int L, R, L2, R2, tau = INT_MAX, need_t = 0;
+        if (m >= P) {
+            L = L2 = 0;
+            R = R2 = P;
+        } else {
+            // window [lo, lo+m) of the m nearest: first lo whose left end is not farther than the element right of the window
+            const int lo = wave_partition_point(0, P - m, lane, [&](int x) {
+                return (c - pos_score(pk, x)) > (pos_score(pk, x + m) - c);
+            });
+            // one batch of six independent loads decides the usual tie-free case
+            const uint32_t NOKEY = 0xFFFFFFFEu;    // never equals a distance key (keys have bit 31 clear)
+            const uint32_t ka = pos_dkey(pk, lo, c), kb = pos_dkey(pk, lo + m - 1, c);
+            const uint32_t ka1 = m > 1 ? pos_dkey(pk, lo + 1, c) : NOKEY;
+            const uint32_t kb1 = m > 1 ? pos_dkey(pk, lo + m - 2, c) : NOKEY;
+            const uint32_t kl = lo > 0 ? pos_dkey(pk, lo - 1, c) : NOKEY;
+            const uint32_t kr = lo + m < P ? pos_dkey(pk, lo + m, c) : NOKEY;
+            const uint32_t ks = ka > kb ? ka : kb;  // m-th smallest distance
+            const bool tie_l = ka == ks, tie_r = kb == ks;
+            const bool none_outside = kl != ks && kr != ks;
+            if (none_outside && m == 1) {                  // the window is one element; it is the single tie
+                L2 = lo;
+                L = R = R2 = lo + 1;
+            } else if (none_outside && !(tie_l && tie_r) && (tie_l ? ka1 != ks : kb1 != ks)) {
+                // exactly one element at distance ks, at one end of the window; no tie outside it
+                L2 = L = tie_l ? lo + 1 : lo;
+                R = R2 = tie_l ? lo + m : lo + m - 1;
+                if (tie_l) L2 = lo; else R2 = lo + m;      // that one element is the (single) tie, and it is taken
+            } else {
+                L = run_end_fwd(pk, c, ks, lo, lo + m, lane);
+                R = (L == lo + m) ? L : run_begin_bwd(pk, c, ks, lo + m - 1, L, lane);
+                L2 = run_begin_bwd(pk, c, ks, lo - 1, 0, lane);
+                R2 = run_end_fwd(pk, c, ks, lo + m, P, lane);
+            }
+            // ties are [L2, L) and [R, R2); strictly nearer ones are [L, R)
+            need_t = m - (R - L);
+            const int T = (L - L2) + (R2 - R);
+            if (T == need_t) {               // every tie is taken (the usual case): one contiguous, fully parallel range
+                L = L2;
+                R = R2;
+                need_t = 0;
+            } else if (T > PCG_WAVE) {       // many ties: threshold on the train_pos position by bisection
+                int plo = 0, phi = P - 1;
+                while (plo < phi) {
+                    const int mid = (plo + phi) >> 1;
+                    int cn = 0;
+                    for (int i0 = L2; i0 < L; i0 += PCG_WAVE) {
+                        const int i = i0 + lane;
+                        cn += wave_count(i < L && (int)(uint32_t)pk[i] <= mid);
+                    }
+                    for (int i0 = R; i0 < R2; i0 += PCG_WAVE) {
+                        const int i = i0 + lane;
+                        cn += wave_count(i < R2 && (int)(uint32_t)pk[i] <= mid);
+                    }
+                    if (cn >= need_t) phi = mid;
+                    else plo = mid + 1;
+                }
+                tau = plo;
+            } else {                          // a few ties: one per lane, the need_t smallest positions by in-register ranking
+                const int nl = L - L2;
+                const int ti = lane < nl ? L2 + lane : R + (lane - nl);
+                const bool tv = lane < T;
+                const int tp = tv ? (int)(uint32_t)pk[ti] : INT_MAX;
+                int rank = 0;
+                for (int j = 0; j < T; ++j) rank += __builtin_amdgcn_readlane(tp, j) < tp;
+                // tau = the need_t-th smallest position among the ties (positions are distinct)
+                const uint64_t hit = __ballot(tv && rank == need_t - 1);
+                const int src = __ffsll((unsigned long long)hit) - 1;
+                tau = __builtin_amdgcn_readlane(tp, src < 0 ? 0 : src);
+            }
+        }
+        PCG_STAMP(4);
+        // strictly nearer ones: slot = i - L, every thread of the group strides over them
+        const int n_strict = R - L;
+        for (int base = tid; base < n_strict; base += NT * KEY_UNROLL) {
+            uint32_t pos[KEY_UNROLL], u[KEY_UNROLL];
+#pragma unroll
+            for (int x = 0; x < KEY_UNROLL; ++x) {
+                const int j = base + x * NT;
+                pos[x] = j < n_strict ? (uint32_t)pk[L + j] : 0u;
+            }
+#pragma unroll
+            for (int x = 0; x < KEY_UNROLL; ++x) u[x] = (uint32_t)a.g.train_pos[pos[x]];
+#pragma unroll
+            for (int x = 0; x < KEY_UNROLL; ++x) {
+                const int j = base + x * NT;
+                if (j < n_strict) {
+                    const bool dup = sorted_contains(sel, ns, u[x]) || (a.add_self && u[x] == (uint32_t)node);  // set(), :694
+                    out[ns + j] = dup ? -1 : (int32_t)u[x];
+                    valid += !dup;
+                }
+            }
+        }
+        mt = n_strict;
+        // the (rare) ties at the m-th distance: first wave, in window order
+        if (need_t > 0) {
+            int taken = 0;
+            for (int part = 0; part < 2; ++part) {
+                const int s0i = part == 0 ? L2 : R, e0i = part == 0 ? L : R2;
+                for (int i0 = s0i; i0 < e0i; i0 += PCG_WAVE) {
+                    const int i = i0 + lane;
+                    bool take = false;
+                    uint32_t u = 0;
+                    if (i < e0i) {
+                        const uint32_t pos = (uint32_t)pk[i];
+                        take = (int)pos <= tau;
+                        if (take) u = (uint32_t)a.g.train_pos[pos];
+                    }
+                    const uint64_t tmk = __ballot(take);
+                    if (take && wave == 0) {
+                        const bool dup = sorted_contains(sel, ns, u) || (a.add_self && u == (uint32_t)node);
+                        out[ns + n_strict + taken + __popcll(tmk & lanemask_lt())] = dup ? -1 : (int32_t)u;
+                        valid += !dup;
+                    }
+                    taken += __popcll(tmk);
+                }
+            }
+            mt += taken;
+        }
+    }
+    PCG_STAMP(5);
+    // GCN-style self union (graphsage.py:78-79, 214): the centre joins its own set
+    int n_self = 0;
+    if (a.add_self && !sorted_contains(sel, ns, (uint32_t)node)) {
+        n_self = 1;
+        if (tid == 0) out[ns + mt] = node;
+    }
+    // |set| = kept + non-duplicate minority picks + self
+    int vsum = valid;
+    for (int o = 1; o < PCG_WAVE; o <<= 1) vsum += __shfl_xor(vsum, o);
+    int vpre, vtot;
+    grp_scan<NW>(vsum, wave, lane, red, vpre, vtot);
+    if (!sel_stored)
+        for (int i = tid; i < ns; i += NT) out[i] = (int32_t)sel[i];
+    const int used = ns + mt + n_self;
+    const int nch = (rec_cap(p, a.add_self) + CHUNK - 1) / CHUNK;
+    for (int j = tid; j < nch; j += NT) {           // what every gather chunk of the row holds
+        const int left = used - j * CHUNK;
+        a.w.chunk_desc[p.chunk0 + j].z = left < 0 ? 0 : (left > CHUNK ? CHUNK : left);
+    }
+    if (tid == 0) {
+        a.w.len[row] = used;
+        a.cnt[row] = ns + vtot + n_self;
+    }
+    grp_sync<NW>();
+    PCG_STAMP(6);
+}
+
+// A row that needs neither minority picks nor the self union: everything it has to report, by one lane.
+__device__ __forceinline__ void report_plain_row(const ChooseArgs &a, int row, const RowRec &p, int ns) {
+    a.w.len[row] = ns;
+    a.cnt[row] = ns;
+    const int nch = (rec_cap(p, 0) + CHUNK - 1) / CHUNK;      // (kept <= 512 here: at most 4 chunks)
+    for (int j = 0; j < nch; ++j) {
+        const int left = ns - j * CHUNK;
+        a.w.chunk_desc[p.chunk0 + j].z = left < 0 ? 0 : (left > CHUNK ? CHUNK : left);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// single-wave rows
+// ---------------------------------------------------------------------------------------------------------------------
+// rotate a (key, position) pair by N lanes inside every 16-lane row
+#define PCG_ROR_STEP(N)                                                                                     \
+    do {                                                                                                    \
+        const uint32_t ok = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x120 + (N), 0xF, 0xF, false); \
+        const int op = __builtin_amdgcn_update_dpp(0, pos, 0x120 + (N), 0xF, 0xF, false);                  \
+        rank += (ok < key) || (ok == key && op < pos);                                                      \
+    } while (0)
+
+// Four rows of <= 16 neighbours, one per 16-lane row of the wave.  area: WAVE_AREA words of LDS.
+__device__ __forceinline__ void select_four_short_rows(const ChooseArgs &a, int q_first, int na, uint32_t *area,
+                                                       const int32_t *const *t_indices, int lane) {
+    const int g = lane >> 4, pos = lane & 15;
+    const int qi = q_first + g;
+    const bool active = qi < na;
+    const int row = a.w.qa[active ? qi : na - 1];
+    const RowRec p = a.w.recs[row];
+    const int r = row / a.B;
+    const int32_t *__restrict__ nbr = t_indices[r] + p.start;
+    const bool have = active && pos < p.d;
+    const uint32_t id = have ? (uint32_t)nbr[pos] : 0u;
+    const float c = a.center_s0 ? a.center_s0[row - r * a.B] : a.s0[p.node];
+    const bool keep_all = rec_keep_all(p);
+    const float sc = a.s0[id];
+    const uint32_t key = have ? dist_key(c, sc) : 0xFFFFFFFFu;     // (valid keys have bit 31 clear)
+    int rank = 0;
+    PCG_ROR_STEP(1); PCG_ROR_STEP(2); PCG_ROR_STEP(3); PCG_ROR_STEP(4); PCG_ROR_STEP(5);
+    PCG_ROR_STEP(6); PCG_ROR_STEP(7); PCG_ROR_STEP(8); PCG_ROR_STEP(9); PCG_ROR_STEP(10);
+    PCG_ROR_STEP(11); PCG_ROR_STEP(12); PCG_ROR_STEP(13); PCG_ROR_STEP(14); PCG_ROR_STEP(15);
+    const bool sel = have && (keep_all || rank < p.k);             // stable order: (key, position)
+    const uint32_t gm = (uint32_t)(__ballot(sel) >> (16 * g)) & 0xFFFFu;
+    const int at = __popc(gm & ((1u << pos) - 1u)), ns = __popc(gm);
+    const bool tail = active && (p.m > 0 || a.add_self);           // needs the shared tail (minority picks / self union)
+    uint32_t *sel_lds = area + HIST_W + g * TA_CAP;
+    if (sel) {
+        if (tail) sel_lds[at] = id;
+        else a.w.list[p.lbeg + at] = (int32_t)id;
+    }
+    if (active && !tail && pos == 0) report_plain_row(a, row, p, ns);
+    // the rows that go on, one after the other, the whole wave on each
+    const uint64_t tails = __ballot(tail && pos == 0);
+    for (int gg = 0; gg < 4; ++gg) {
+        if (!((tails >> (16 * gg)) & 1ull)) continue;             // wave-uniform
+        const int src = 16 * gg;
+        RowRec q;
+        q.start = 0;
+        q.node = __builtin_amdgcn_readlane(p.node, src);
+        q.d = __builtin_amdgcn_readlane(p.d, src);
+        q.k = __builtin_amdgcn_readlane(p.k, src);
+        q.m = __builtin_amdgcn_readlane(p.m, src);
+        q.lbeg = __builtin_amdgcn_readlane(p.lbeg, src);
+        q.chunk0 = __builtin_amdgcn_readlane(p.chunk0, src);
+        const int qrow = __builtin_amdgcn_readlane(row, src);
+        const int qns = __builtin_amdgcn_readlane(ns, src);
+        const float qc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), src));
+        finish_row<1>(a, qrow, q, qc, area + HIST_W + gg * TA_CAP, qns, false, 0, lane, nullptr);
+    }
+}
+
+// One row of 17 .. 64 neighbours on one wave: one key per lane, ranked lane against lane in the stable (key, position)
+// order - no k-th value is formed.  area: WAVE_AREA words of LDS (the kept ids go behind the histogram's place).
+__device__ __forceinline__ void select_lane_row(const ChooseArgs &a, int row, uint32_t *area, int lane) {
+    const int tid = lane;
+    if (a.stamps && tid == 0) a.stamps[(size_t)row * 8] = wall_clock64() | ((unsigned long long)blockIdx.x << 54);   // + who ran it
+    const RowRec p = a.w.recs[row];
+    const int d = p.d, k = p.k;
+    const bool keep_all = rec_keep_all(p);
+    const int r = row / a.B;
+    const int32_t *__restrict__ nbr = a.g.indices[r] + p.start;
+    const float c = a.center_s0 ? a.center_s0[row - r * a.B] : a.s0[p.node];
+    uint32_t *sel_lds = area + HIST_W;
+    const bool tail = p.m > 0 || a.add_self;
+    const bool have = lane < d;
+    const uint32_t id = have ? (uint32_t)nbr[lane] : 0u;
+    const float sc = keep_all ? 0.f : a.s0[id];
+    const uint32_t mine = have ? dist_key(c, sc) : 0xFFFFFFFFu;
+    PCG_STAMP(1);
+    int rank = 0;
+    if (!keep_all)
+        for (int j = 0; j < d; ++j) {                                            // d is wave-uniform
+            const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)mine, j);
+            rank += (o < mine) || (o == mine && j < lane);
+        }
+    const bool s = have && (keep_all || rank < k);
+    const uint64_t sm = __ballot(s);
+    const int ns = __popcll(sm);
+    PCG_STAMP(2);
+    if (s) {
+        const int at = __popcll(sm & lanemask_lt());
+        if (tail) sel_lds[at] = id;
+        else a.w.list[p.lbeg + at] = (int32_t)id;
+    }
+    PCG_STAMP(3);
+    if (tail) finish_row<1>(a, row, p, c, sel_lds, ns, false, 0, lane, nullptr);
+    else {
+        if (lane == 0) report_plain_row(a, row, p, ns);
+        PCG_STAMP(6);
+    }
+}
+
+// One row of 65 .. 512 neighbours on one wave: keys in registers.  area: WAVE_AREA words of LDS
+// (histogram HIST_W | kept ids T1_CAP | candidates 64).
+__device__ __forceinline__ void select_wave_row(const ChooseArgs &a, int row, uint32_t *area, int lane) {
+    const int tid = lane;
+    if (a.stamps && tid == 0) a.stamps[(size_t)row * 8] = wall_clock64() | ((unsigned long long)blockIdx.x << 54);   // + who ran it
+    const RowRec p = a.w.recs[row];
+    const int d = p.d, k = p.k;
+    const bool keep_all = rec_keep_all(p);
+    const int r = row / a.B;
+    const int32_t *__restrict__ nbr = a.g.indices[r] + p.start;
+    const float c = a.center_s0 ? a.center_s0[row - r * a.B] : a.s0[p.node];
+    uint32_t *hist = area, *sel_lds = area + HIST_W, *cand = area + HIST_W + T1_CAP;
+    const bool tail = p.m > 0 || a.add_self;
+    int32_t *__restrict__ out = a.w.list + p.lbeg;
+
+    // ---- 1. neighbour ids and distance keys -> registers (position u * 64 + lane) ----
+    uint32_t id[KPT], key[KPT];
+    {
+        float sc[KPT];
+#pragma unroll
+        for (int u = 0; u < KPT; ++u) {
+            const int i = u * PCG_WAVE + lane;
+            id[u] = i < d ? (uint32_t)nbr[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < KPT; ++u) sc[u] = (keep_all || u * PCG_WAVE >= d) ? 0.f : a.s0[id[u]];
+#pragma unroll
+        for (int u = 0; u < KPT; ++u) key[u] = (u * PCG_WAVE + lane < d) ? dist_key(c, sc[u]) : 0xFFFFFFFFu;
+    }
+    PCG_STAMP(1);
+
+    // ---- 2. the k-th smallest key: kstar, and how many of the keys equal to it stay ----
+    uint32_t kstar = 0xFFFFFFFEu;       // keep_all: every real key is below it
+    int need = 0, n_equal = 0;
+    if (!keep_all) {
+        uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+#pragma unroll
+        for (int u = 0; u < KPT; ++u)
+            if (u * PCG_WAVE + lane < d) {
+                kmin = key[u] < kmin ? key[u] : kmin;
+                kmax = key[u] > kmax ? key[u] : kmax;
+            }
+        uint32_t lo = wave_min_u32(kmin), hi = wave_max_u32(kmax);
+        int below = 0, cnt = d;
+        // invariant: the k-th smallest key lies in [lo, hi]; below = #keys < lo; cnt = #keys in [lo, hi]
+        while (lo < hi && cnt > PCG_WAVE) {
+            const uint32_t range = hi - lo;
+            const int bits = 32 - __clz((int)range);
+            const int shift = bits > 8 ? bits - 8 : 0;                      // (range >> shift) < HIST_W
+            *reinterpret_cast<uint4 *>(hist + 4 * lane) = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int u = 0; u < KPT; ++u)
+                if (key[u] >= lo && key[u] <= hi) atomicAdd(&hist[(key[u] - lo) >> shift], 1u);   // (pad keys are > hi)
+            const uint4 v = *reinterpret_cast<const uint4 *>(hist + 4 * lane);
+            const int s = (int)(v.x + v.y + v.z + v.w);
+            const int incl = wave_incl_scan(s, lane);
+            const int want = k - below;
+            const uint64_t reach = __ballot(incl >= want);
+            const int L = __ffsll((unsigned long long)reach) - 1;           // total = cnt >= want: some lane reaches it
+            int c0 = incl - s, b = 0, hb = (int)v.x;
+            if (c0 + (int)v.x < want) {
+                c0 += (int)v.x; b = 1; hb = (int)v.y;
+                if (c0 + (int)v.y < want) {
+                    c0 += (int)v.y; b = 2; hb = (int)v.z;
+                    if (c0 + (int)v.z < want) { c0 += (int)v.z; b = 3; hb = (int)v.w; }
+                }
+            }
+            const int bin = __builtin_amdgcn_readlane(4 * lane + b, L);
+            below += __builtin_amdgcn_readlane(c0, L);
+            cnt = __builtin_amdgcn_readlane(hb, L);
+            lo += (uint32_t)bin << shift;
+            const uint32_t top = lo + ((1u << shift) - 1u);
+            hi = top < hi ? top : hi;
+        }
+        kstar = lo;
+        need = k - below;
+        n_equal = cnt;
+        if (lo < hi) {
+            // <= 64 candidates in [lo, hi]: one per lane, ranked in-wave
+            int at = 0;
+#pragma unroll
+            for (int u = 0; u < KPT; ++u) {
+                const bool isc = key[u] >= lo && key[u] <= hi;
+                const uint64_t bm = __ballot(isc);
+                if (isc) cand[at + __popcll(bm & lanemask_lt())] = key[u];
+                at += __popcll(bm);
+            }
+            const bool hv = lane < cnt;
+            const uint32_t ck = hv ? cand[lane] : 0xFFFFFFFFu;
+            wave_kth(ck, hv, cnt, k - below, kstar, need, n_equal);
+        }
+    }
+    PCG_STAMP(2);
+
+    // ---- 3. kept ids, ascending (row order), to LDS (the tail needs them) or straight to the list ----
+    const bool ranked = n_equal != need;       // some, not all, of the keys equal to kstar stay: the first `need` by position
+    int ns = 0, ties_seen = 0;
+#pragma unroll
+    for (int u = 0; u < KPT; ++u) {
+        if (u * PCG_WAVE >= d) break;           // wave-uniform
+        const bool in = u * PCG_WAVE + lane < d;
+        bool s = in && key[u] <= kstar;
+        if (ranked) {
+            const bool tie = in && key[u] == kstar;
+            const uint64_t tm = __ballot(tie);
+            s = in && (key[u] < kstar || (tie && ties_seen + __popcll(tm & lanemask_lt()) < need));
+            ties_seen += __popcll(tm);
+        }
+        const uint64_t sm = __ballot(s);
+        if (s) {
+            const int at = ns + __popcll(sm & lanemask_lt());
+            if (tail) sel_lds[at] = id[u];
+            else out[at] = (int32_t)id[u];
+        }
+        ns += __popcll(sm);
+    }
+    PCG_STAMP(3);
+    if (tail) finish_row<1>(a, row, p, c, sel_lds, ns, false, 0, lane, nullptr);
+    else {
+        if (lane == 0) report_plain_row(a, row, p, ns);
+        PCG_STAMP(6);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// workgroup rows (> 512 neighbours): 8 waves, keys in LDS (LDSK) or recomputed from the scores on every pass
+// ---------------------------------------------------------------------------------------------------------------------
+// f(i, key) for every position i in [begin, end) with stride NT from `first`; recomputing variant: KEY_UNROLL gathers in flight
+template <bool LDSK, class F>
+__device__ __forceinline__ void for_keys(const uint32_t *keys, const int32_t *__restrict__ nbr, const float *__restrict__ s0, float c,
+                                         int first, int end, int step, F f) {
+    if constexpr (LDSK) {
+        for (int i = first; i < end; i += step) f(i, keys[i]);
+    } else {
+        for (int base = first; base < end; base += step * KEY_UNROLL) {
+            uint32_t id[KEY_UNROLL];
+            float sc[KEY_UNROLL];
+#pragma unroll
+            for (int u = 0; u < KEY_UNROLL; ++u) {
+                const int i = base + u * step;
+                id[u] = i < end ? (uint32_t)nbr[i] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < KEY_UNROLL; ++u) sc[u] = s0[id[u]];
+#pragma unroll
+            for (int u = 0; u < KEY_UNROLL; ++u) {
+                const int i = base + u * step;
+                if (i < end) f(i, dist_key(c, sc[u]));
+            }
+        }
+    }
+}
+
+// lds: WG_KEYCAP words (keys, later the kept ids) | hist HIST_WG | cand 64 | red
+template <bool LDSK>
+__device__ __forceinline__ void select_wg_row(const ChooseArgs &a, int row, uint32_t *keys, uint32_t *hist, uint32_t *cand,
+                                              int *red) {
+    constexpr int NW = SEL_NW, NT = SEL_NW * PCG_WAVE;
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6), tid = (int)threadIdx.x;
+    if (a.stamps && tid == 0) a.stamps[(size_t)row * 8] = wall_clock64() | ((unsigned long long)blockIdx.x << 54);
+    const RowRec p = a.w.recs[row];
+    const int d = p.d, k = p.k;
+    const bool keep_all = rec_keep_all(p);
+    const int r = row / a.B;
+    const int32_t *__restrict__ nbr = a.g.indices[r] + p.start;
+    const float *__restrict__ s0 = a.s0;
+    const float c = a.center_s0 ? a.center_s0[row - r * a.B] : s0[p.node];
+    int32_t *__restrict__ out = a.w.list + p.lbeg;
+    // res: what one thread / wave found, for everybody: red[2 * NW + 2 ..]
+    int *res = red + 2 * NW + 2;
+
+    uint32_t kstar = 0xFFFFFFFFu;
+    int need = 0, n_equal = 0;
+    if (!keep_all) {
+        // ---- 1. distance keys (-> LDS), their range ----
+        uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+        for (int base = tid; base < d; base += NT * KEY_UNROLL) {
+            uint32_t id[KEY_UNROLL];
+            float sc[KEY_UNROLL];
+#pragma unroll
+            for (int u = 0; u < KEY_UNROLL; ++u) {
+                const int i = base + u * NT;
+                id[u] = i < d ? (uint32_t)nbr[i] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < KEY_UNROLL; ++u) sc[u] = s0[id[u]];
+#pragma unroll
+            for (int u = 0; u < KEY_UNROLL; ++u) {
+                const int i = base + u * NT;
+                if (i < d) {
+                    const uint32_t key = dist_key(c, sc[u]);
+                    if constexpr (LDSK) keys[i] = key;
+                    kmin = key < kmin ? key : kmin;
+                    kmax = key > kmax ? key : kmax;
+                }
+            }
+        }
+        kmin = wave_min_u32(kmin);
+        kmax = wave_max_u32(kmax);
+        if (lane == 0) {
+            red[wave] = (int)kmin;
+            red[NW + wave] = (int)kmax;
+        }
+        __syncthreads();
+        for (int w = 0; w < NW; ++w) {
+            const uint32_t x = (uint32_t)red[w], y = (uint32_t)red[NW + w];
+            kmin = x < kmin ? x : kmin;
+            kmax = y > kmax ? y : kmax;
+        }
+        PCG_STAMP(1);
+        // ---- 2. k-th smallest key: histogram rounds over the bit range [lo, hi] ----
+        uint32_t lo = kmin, hi = kmax;
+        int below = 0, cnt = d;
+        while (lo < hi && cnt > PCG_WAVE) {
+            const uint32_t range = hi - lo;
+            const int bits = 32 - __clz((int)range);
+            const int shift = bits > 11 ? bits - 11 : 0;                    // (range >> shift) < HIST_WG
+            *reinterpret_cast<uint4 *>(hist + 4 * tid) = make_uint4(0u, 0u, 0u, 0u);       // HIST_WG == 4 * NT
+            __syncthreads();                                                 // (also: everybody is done with red / res)
+            for_keys<LDSK>(keys, nbr, s0, c, tid, d, NT, [&](int, uint32_t key) {
+                if (key >= lo && key <= hi) atomicAdd(&hist[(key - lo) >> shift], 1u);
+            });
+            __syncthreads();
+            const uint4 v = *reinterpret_cast<const uint4 *>(hist + 4 * tid);
+            const int s = (int)(v.x + v.y + v.z + v.w);
+            const int incl_w = wave_incl_scan(s, lane);
+            if (lane == PCG_WAVE - 1) red[wave] = incl_w;
+            __syncthreads();
+            int pre = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) pre += (w < wave) ? red[w] : 0;
+            const int incl = pre + incl_w, excl = incl - s;
+            const int want = k - below;
+            if (excl < want && want <= incl) {                               // exactly one thread
+                int c0 = excl, b = 0, hb = (int)v.x;
+                if (c0 + (int)v.x < want) {
+                    c0 += (int)v.x; b = 1; hb = (int)v.y;
+                    if (c0 + (int)v.y < want) {
+                        c0 += (int)v.y; b = 2; hb = (int)v.z;
+                        if (c0 + (int)v.z < want) { c0 += (int)v.z; b = 3; hb = (int)v.w; }
+                    }
+                }
+                res[0] = 4 * tid + b;
+                res[1] = c0;
+                res[2] = hb;
+            }
+            __syncthreads();
+            below += res[1];
+            cnt = res[2];
+            lo += (uint32_t)res[0] << shift;
+            const uint32_t top = lo + ((1u << shift) - 1u);
+            hi = top < hi ? top : hi;
+        }
+        kstar = lo;
+        need = k - below;
+        n_equal = cnt;
+        if (lo < hi) {
+            // <= 64 candidates in [lo, hi]: gathered (in any order) and ranked by every wave for itself
+            __syncthreads();
+            if (tid == 0) res[3] = 0;
+            __syncthreads();
+            for_keys<LDSK>(keys, nbr, s0, c, tid, d, NT, [&](int, uint32_t key) {
+                if (key >= lo && key <= hi) cand[atomicAdd(&res[3], 1)] = key;
+            });
+            __syncthreads();
+            const bool hv = lane < cnt;
+            const uint32_t ck = hv ? cand[lane] : 0xFFFFFFFFu;
+            wave_kth(ck, hv, cnt, k - below, kstar, need, n_equal);
+        }
+        __syncthreads();
+    }
+    PCG_STAMP(2);
+
+    // ---- 3. kept ids, ascending: every wave owns a contiguous stretch of the row ----
+    const bool ranked = !keep_all && n_equal != need;
+    const int seg = (((d + NW - 1) / NW) + PCG_WAVE - 1) & ~(PCG_WAVE - 1);
+    const int b0 = wave * seg < d ? wave * seg : d;
+    const int e0 = b0 + seg < d ? b0 + seg : d;
+    int tie_base = 0;
+    if (ranked) {                                                            // ties before this wave's stretch
+        int tc = 0;
+        for_keys<LDSK>(keys, nbr, s0, c, b0 + lane, e0, PCG_WAVE, [&](int, uint32_t key) { tc += key == kstar; });
+        for (int o = 1; o < PCG_WAVE; o <<= 1) tc += __shfl_xor(tc, o);
+        int ttot;
+        grp_scan<NW>(tc, wave, lane, red, tie_base, ttot);
+    }
+    int ns = 0;
+    uint32_t *selbuf = LDSK ? keys : reinterpret_cast<uint32_t *>(out);     // the keys are dead once every wave has its mask
+    if constexpr (LDSK) {
+        // pass A: which positions stay (a bit per iteration in a register; seg <= 1280 -> <= 20 iterations), pass B: their
+        // ids, re-read from the CSR row (coalesced, L2-hot), into the keys' own LDS
+        uint32_t mask = 0;
+        int mine = 0, ties_seen = tie_base;
+        int it = 0;
+        for (int i0 = b0; i0 < e0; i0 += PCG_WAVE, ++it) {
+            const int i = i0 + lane;
+            const bool in = i < e0;
+            const uint32_t key = (in && !keep_all) ? keys[i] : 0u;
+            bool s = in && (keep_all || key <= kstar);
+            if (ranked) {
+                const bool tie = in && key == kstar;
+                const uint64_t tm = __ballot(tie);
+                s = in && (key < kstar || (tie && ties_seen + __popcll(tm & lanemask_lt()) < need));
+                ties_seen += __popcll(tm);
+            }
+            mask |= (uint32_t)s << it;
+            mine += wave_count(s);
+        }
+        int run;
+        grp_scan<NW>(mine, wave, lane, red, run, ns);                        // (its barriers part pass A's reads from pass B's writes)
+        constexpr int CU = 4;
+        it = 0;
+        for (int i0 = b0; i0 < e0; i0 += CU * PCG_WAVE, it += CU) {
+            uint32_t idv[CU];
+#pragma unroll
+            for (int u = 0; u < CU; ++u) {
+                const int i = i0 + u * PCG_WAVE + lane;
+                idv[u] = i < e0 ? (uint32_t)nbr[i] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < CU; ++u) {
+                const bool s = (mask >> (it + u)) & 1u;
+                const uint64_t sm = __ballot(s);
+                if (s) selbuf[run + __popcll(sm & lanemask_lt())] = idv[u];
+                run += __popcll(sm);
+            }
+        }
+        __syncthreads();
+    } else {
+        // over-long row: count per stretch, scan, then the same pass again writing straight into the list region
+        int mine = 0, ties_seen = tie_base;
+        for (int i0 = b0; i0 < e0; i0 += PCG_WAVE * KEY_UNROLL) {
+            uint32_t id[KEY_UNROLL];
+            float sc[KEY_UNROLL];
+#pragma unroll
+            for (int u = 0; u < KEY_UNROLL; ++u) {
+                const int i = i0 + u * PCG_WAVE + lane;
+                id[u] = i < e0 ? (uint32_t)nbr[i] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < KEY_UNROLL; ++u) sc[u] = keep_all ? 0.f : s0[id[u]];
+#pragma unroll
+            for (int u = 0; u < KEY_UNROLL; ++u) {
+                const int i = i0 + u * PCG_WAVE + lane;
+                const bool in = i < e0;
+                const uint32_t key = dist_key(c, sc[u]);
+                bool s = in && (keep_all || key <= kstar);
+                if (ranked) {
+                    const bool tie = in && key == kstar;
+                    const uint64_t tm = __ballot(tie);
+                    s = in && (key < kstar || (tie && ties_seen + __popcll(tm & lanemask_lt()) < need));
+                    ties_seen += __popcll(tm);
+                }
+                mine += wave_count(s);
+            }
+        }
+        int run;
+        grp_scan<NW>(mine, wave, lane, red, run, ns);
+        ties_seen = tie_base;
+        for (int i0 = b0; i0 < e0; i0 += PCG_WAVE * KEY_UNROLL) {
+            uint32_t id[KEY_UNROLL];
+            float sc[KEY_UNROLL];
+#pragma unroll
+            for (int u = 0; u < KEY_UNROLL; ++u) {
+                const int i = i0 + u * PCG_WAVE + lane;
+                id[u] = i < e0 ? (uint32_t)nbr[i] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < KEY_UNROLL; ++u) sc[u] = keep_all ? 0.f : s0[id[u]];
+#pragma unroll
+            for (int u = 0; u < KEY_UNROLL; ++u) {
+                const int i = i0 + u * PCG_WAVE + lane;
+                const bool in = i < e0;
+                const uint32_t key = dist_key(c, sc[u]);
+                bool s = in && (keep_all || key <= kstar);
+                if (ranked) {
+                    const bool tie = in && key == kstar;
+                    const uint64_t tm = __ballot(tie);
+                    s = in && (key < kstar || (tie && ties_seen + __popcll(tm & lanemask_lt()) < need));
+                    ties_seen += __popcll(tm);
+                }
+                const uint64_t sm = __ballot(s);
+                if (s) selbuf[run + __popcll(sm & lanemask_lt())] = id[u];
+                run += __popcll(sm);
+            }
+        }
+        // the kept ids are read back (binary search of the minority picks) by every wave of this workgroup: same CU, same L1
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    PCG_STAMP(3);
+    finish_row<NW>(a, row, p, c, selbuf, ns, !LDSK, wave, lane, red);
+}
+
+// One persistent launch selects every row of the batch, longest rows first.
+__global__ void __launch_bounds__(SEL_NW *PCG_WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))) select_rows(const ChooseArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t *lds = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *hist = lds + WG_KEYCAP;
+    uint32_t *cand = hist + HIST_WG;
+    int *red = reinterpret_cast<int *>(cand + PCG_WAVE);                   // 2 * SEL_NW + 2 + 4 ints
+    // per-relation neighbour arrays in LDS: a per-lane relation index (four short rows per wave) then costs one ds_read
+    // instead of a waterfall over the kernel arguments
+    const int32_t **t_indices = reinterpret_cast<const int32_t **>(red + 2 * SEL_NW + 8);
+    if (threadIdx.x < PCG_MAX_REL) t_indices[threadIdx.x] = a.g.indices[threadIdx.x < (unsigned)a.g.n_rel ? threadIdx.x : 0];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    // workgroup rows: the virtual queue [> 4096 | 513 .. 4096], strided over the workgroups from the first one on
+    const int n16 = (int)a.w.counters[C_N16], n4 = (int)a.w.counters[C_N4];
+    for (int j = (int)blockIdx.x; j < n16 + n4; j += SEL_BLOCKS) {
+        const int row = __builtin_amdgcn_readfirstlane(j < n16 ? a.w.q16[j] : a.w.q4[j - n16]);     // one row per workgroup: scalar
+        const int d = a.w.recs[row].d;
+        if (d <= WG_KEYCAP) select_wg_row<true>(a, row, lds, hist, cand, red);
+        else select_wg_row<false>(a, row, lds, hist, cand, red);
+    }
+    // single-wave rows: the virtual queue [65 .. 512 | 17 .. 64 | groups of four rows of <= 16], strided over the waves from
+    // the LAST workgroup on, so that with few workgroup rows the workgroups holding those are not the ones holding these too
+    const int n1 = (int)a.w.counters[C_N1], n0 = (int)a.w.counters[C_N0], na = (int)a.w.counters[C_NA];
+    const int n_items = n1 + n0 + (na + 3) / 4;
+    uint32_t *area = lds + wave * WAVE_AREA;
+    for (int j = (SEL_BLOCKS - 1 - (int)blockIdx.x) * SEL_NW + wave; j < n_items; j += SEL_BLOCKS * SEL_NW) {
+        if (j < n1) {
+            select_wave_row(a, __builtin_amdgcn_readfirstlane(a.w.q1[j]), area, lane);
+        } else if (j < n1 + n0) {
+            select_lane_row(a, __builtin_amdgcn_readfirstlane(a.w.q0[j - n1]), area, lane);
+        } else {
+            select_four_short_rows(a, 4 * (j - n1 - n0), na, area, t_indices, lane);
+        }
+    }
+}
+
+static size_t select_smem_bytes() {
+    return sizeof(uint32_t) * (WG_KEYCAP + HIST_WG + PCG_WAVE) + sizeof(int) * (2 * SEL_NW + 8) + sizeof(void *) * PCG_MAX_REL;
+}
+
+int launch_select_rows(const ChooseArgs &a, hipStream_t st) {
+    static_assert(HIST_WG == 4 * SEL_NW * PCG_WAVE, "one uint4 of bins per thread");
+    static_assert(HIST_W == 4 * PCG_WAVE, "one uint4 of bins per lane");
+    static_assert(WAVE_AREA >= HIST_W + T1_CAP + PCG_WAVE, "a wave's LDS area: histogram | kept ids | candidates");
+    static_assert(((WG_KEYCAP / SEL_NW + PCG_WAVE - 1) / PCG_WAVE) <= 32, "pass A keeps one bit per iteration in a uint32");
+    static_assert((2 * SEL_NW + 8) % 2 == 0, "the pointer table behind red stays 8-byte aligned");
+    hipLaunchKernelGGL(select_rows, dim3(SEL_BLOCKS), dim3(SEL_NW * PCG_WAVE), select_smem_bytes(), st, a);
+    PCG_LAUNCH_CHECK();
+    return PCG_OK;
+}
+
+}  // namespace pcg
