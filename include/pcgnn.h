@@ -174,6 +174,18 @@ int pcg_choose_select_planned(const pcg_graph_desc *g, const int32_t *nodes, con
                               const float *s0, const float *center_s0, const uint64_t *pos_keys,
                               const double *thresholds, const double *rho, int32_t train_flag, int32_t add_self,
                               int32_t *cnt, void *workspace, int64_t list_capacity, uint32_t *status, void *stream);
+/* select + gather WITHOUT the combine launch (two launches): rows whose list fits one 128-entry gather chunk are finished
+ * (their mean is in agg), longer rows are left as per-chunk partial sums in the workspace; pcg_train_dense, given the same
+ * workspace and cnt, adds them up in chunk order (bit-identical to pcg_choose_aggregate_planned's agg) while it stages its
+ * tile.  pcg_gather_lists is the gather half on its own (norm = PCG_NORM_COUNT). */
+int pcg_choose_gather_planned(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B,
+                              const float *s0, const float *center_s0, const uint64_t *pos_keys,
+                              const double *thresholds, const double *rho, int32_t train_flag, int32_t add_self,
+                              float *agg, int32_t agg_stride, int32_t *cnt, void *workspace, int64_t list_capacity,
+                              uint32_t *status, void *stream);
+int pcg_gather_lists(const float *X, int32_t feat_dim, int32_t feat_stride, int32_t n_rows, const int32_t *cnt,
+                     const pcg_graph_desc *g, int32_t B, void *workspace, int64_t list_capacity, float *agg,
+                     int32_t agg_stride, void *stream);
 int pcg_choose_aggregate_planned(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B,
                                  const float *s0, const float *center_s0, const uint64_t *pos_keys,
                                  const double *thresholds, const double *rho, int32_t train_flag,
@@ -250,6 +262,36 @@ int pcg_dense_step(const pcg_graph_desc *g, const float *theta, int32_t emb,
 int pcg_adam_step(float *theta, float *m, float *v, const float *slabs, int32_t n_slabs, int64_t n_params,
                   const int32_t *step_counter, double lr, double beta1, double beta2, double eps,
                   double weight_decay, float *grad_out, int32_t apply, void *stream);
+
+/* The training step's tail and front with Adam taken off the critical path (src/model_handler.py:149-153).
+ *
+ * pcg_train_dense = pcg_dense_step, plus
+ *   - workspace != NULL (with cnt, list_capacity as given to pcg_choose_gather_planned): aggregates of rows the gather left
+ *     as partial sums are added up here (no combine launch);
+ *   - adam_clf != 0 (training: slabs, m, v, sync_words required): the workgroup that arrives last (device-scope ticket,
+ *     write-through partial gradients) sums the label classifier's gradient over the tiles in tile order and applies
+ *     Adam to those 2 * feat_dim + 2 parameters - the only ones the next step's score pass reads - and the launch marks the
+ *     slabs as holding a gradient the OTHER parameters have not seen yet: sync_words[1] = 1, sync_words[2] = #slabs.
+ *   sync_words: FOUR zero-initialised uint32 device words owned by the caller ([0] arrival ticket, 0 between launches).
+ * pcg_step_front_train = pcg_step_front(train_flag = 1) reading the label classifier from theta, with that deferred update
+ *   (parameters [0, offset of label_clf.weight), same arithmetic and summation order as pcg_adam_step) applied by extra
+ *   workgroups beside the score pass when sync_words[1] is set; its second launch clears sync_words[1].
+ * pcg_adam_flush applies a still-deferred update now (two small launches) - before parameters are read or saved. */
+int pcg_train_dense(const pcg_graph_desc *g, float *theta, float *m, float *v, int32_t emb, const int32_t *ids,
+                    const int32_t *labels, int32_t B, const float *agg, int32_t agg_stride, const int32_t *cnt,
+                    const void *workspace, int64_t list_capacity, float lambda_1, float inv_count, float *logits,
+                    float *center, float *combined, float *row_loss, float *slabs, int32_t *step_counter,
+                    uint32_t *sync_words, double lr, double beta1, double beta2, double eps, double weight_decay,
+                    int32_t adam_clf, void *stream);
+int pcg_step_front_train(const pcg_graph_desc *g, float *theta, float *m, float *v, int32_t emb, float *s0,
+                         uint64_t *pos_keys, const int32_t *nodes, const int32_t *labels, int32_t B,
+                         const double *thresholds, const double *rho, int32_t add_self, void *workspace,
+                         int64_t list_capacity, uint32_t *status, const float *slabs, const int32_t *step_counter,
+                         uint32_t *sync_words, double lr, double beta1, double beta2, double eps, double weight_decay,
+                         void *stream);
+int pcg_adam_flush(float *theta, float *m, float *v, const float *slabs, int32_t n_slabs, int64_t n_params, int64_t p_end,
+                   const int32_t *step_counter, uint32_t *sync_words, double lr, double beta1, double beta2, double eps,
+                   double weight_decay, void *stream);
 
 /* ---- multi-GPU halo exchange helpers (no counterpart in the reference) ----------
  * The selection list of a partitioned run holds GLOBAL ids.  `total` is a device int64: the

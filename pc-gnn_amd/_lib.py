@@ -60,6 +60,14 @@ PROTOTYPES = {
                                             _P, _P, _I64, _P, _P]),
     "pcg_choose_aggregate_planned": (C.c_int, [_G, _P, _P, _I32, _P, _P, _P, C.POINTER(_F64), C.POINTER(_F64), _I32, _I32,
                                                _I32, _P, _I32, _P, _P, _I64, _P, _P]),
+    "pcg_choose_gather_planned": (C.c_int, [_G, _P, _P, _I32, _P, _P, _P, C.POINTER(_F64), C.POINTER(_F64), _I32, _I32,
+                                            _P, _I32, _P, _P, _I64, _P, _P]),
+    "pcg_gather_lists": (C.c_int, [_P, _I32, _I32, _I32, _P, _G, _I32, _P, _I64, _P, _I32, _P]),
+    "pcg_train_dense": (C.c_int, [_G, _P, _P, _P, _I32, _P, _P, _I32, _P, _I32, _P, _P, _I64, C.c_float, C.c_float, _P, _P, _P,
+                                  _P, _P, _P, _P, _F64, _F64, _F64, _F64, _F64, _I32, _P]),
+    "pcg_step_front_train": (C.c_int, [_G, _P, _P, _P, _I32, _P, _P, _P, _P, _I32, C.POINTER(_F64), C.POINTER(_F64), _I32, _P,
+                                       _I64, _P, _P, _P, _P, _F64, _F64, _F64, _F64, _F64, _P]),
+    "pcg_adam_flush": (C.c_int, [_P, _P, _P, _P, _I32, _I64, _I64, _P, _P, _F64, _F64, _F64, _F64, _F64, _P]),
     "pcg_debug_set_stamps": (None, [_P]),
     "pcg_debug_set_dense_stamps": (None, [_P]),
     "pcg_sel_capacity_row": (_I64, [_I64, _F64, _F64, _I32, _I32, _I32]),

@@ -327,26 +327,36 @@ __global__ void __launch_bounds__(PLAN_THREADS) plan_write(const ChooseArgs a, c
 // and the train-pos sort (both have idle CUs at dataset scale, and the plan needs neither's result):
 //   front_a: [plan pass 1 workgroups | score_table workgroups]          (256 threads)
 //   front_b: [plan pass 2 workgroups | rank-sort workgroups]            (1024 threads)
+//            + [Adam blocks]: the previous training step's deferred parameter update (everything but the label classifier,
+//              whose 2F + 2 parameters - the ones this pass reads - that step's dense kernel has updated itself)
 __global__ void __launch_bounds__(FRONT_COUNT_THREADS) front_a_kernel(const ChooseArgs a, PlanTotals *totals, int n_plan_blocks,
                                                                       int n_key_blocks, uint64_t *__restrict__ raw_keys,
                                                                       const float *__restrict__ W, const float *__restrict__ bias,
-                                                                      int64_t row_begin, int64_t row_end, float *__restrict__ s0) {
+                                                                      int64_t row_begin, int64_t row_end, float *__restrict__ s0,
+                                                                      const DeferredAdam ad, int n_adam_blocks) {
+    __shared__ float part[4][PCG_WAVE];
     const int b = (int)blockIdx.x;
     if (b < n_plan_blocks)
         plan_count_body<FRONT_COUNT_THREADS>(a, totals, b);
     else if (b < n_plan_blocks + n_key_blocks)      // the train positives' sort keys, from their feature rows
         pos_key_body(a.g.X, a.g.feat_dim, a.g.feat_stride, W, bias, a.g.train_pos, a.g.n_pos, raw_keys, b - n_plan_blocks,
                      n_key_blocks);
-    else
+    else if (b < n_plan_blocks + n_key_blocks + n_adam_blocks) {
+        if (ad.pending[0] != 0u)                    // (one word, the same for every thread)
+            adam_reduce_body(ad.theta, ad.m, ad.v, ad.slabs, (int)ad.pending[1], ad.n_params, 0, ad.p_end, ad.step_counter, ad.h,
+                             nullptr, 1, b - n_plan_blocks - n_key_blocks, part);
+    } else
         score_table_body(a.g.X, a.g.feat_dim, a.g.feat_stride, W, bias, row_begin, row_end, s0,
-                         b - n_plan_blocks - n_key_blocks, (int)gridDim.x - n_plan_blocks - n_key_blocks);
+                         b - n_plan_blocks - n_key_blocks - n_adam_blocks,
+                         (int)gridDim.x - n_plan_blocks - n_key_blocks - n_adam_blocks);
 }
 
 __global__ void __launch_bounds__(PLAN_THREADS) front_b_kernel(const ChooseArgs a, const PlanTotals *totals, int n_write_blocks,
                                                                int n_count_blocks, uint64_t *__restrict__ keys, int cap,
-                                                               const uint64_t *__restrict__ raw_keys) {
+                                                               const uint64_t *__restrict__ raw_keys, uint32_t *pending) {
     __shared__ uint64_t sh[RANK_TILE];
     __shared__ int part[RANK_WAVES * PCG_WAVE];
+    if (pending && blockIdx.x == 0 && threadIdx.x == 0) pending[0] = 0u;   // front_a (the launch before) has applied the deferred update
     if ((int)blockIdx.x < n_write_blocks)
         plan_write_body<PLAN_THREADS, FRONT_COUNT_THREADS>(a, totals, (int)blockIdx.x, n_count_blocks);
     else
@@ -477,11 +487,11 @@ int pcg_choose_select_planned(const pcg_graph_desc *g, const int32_t *nodes, con
                          workspace, list_capacity, status, stream);
 }
 
-/* first half: class-0 logits of rows [row_begin, row_end) -> s0_out[row]  ||  plan pass 1 */
-int pcg_step_front_a(const pcg_graph_desc *g, const float *W, const float *b, int64_t row_begin, int64_t row_end,
-                     float *s0_out, uint64_t *pos_keys, const int32_t *nodes, const int32_t *labels, int32_t B,
-                     const double *thresholds, const double *rho, int32_t train_flag, int32_t add_self, void *workspace,
-                     int64_t list_capacity, uint32_t *status, void *stream) {
+/* first half: class-0 logits of rows [row_begin, row_end) -> s0_out[row]  ||  plan pass 1  (|| a deferred Adam update) */
+static int front_a(const pcg_graph_desc *g, const float *W, const float *b, int64_t row_begin, int64_t row_end,
+                   float *s0_out, uint64_t *pos_keys, const int32_t *nodes, const int32_t *labels, int32_t B,
+                   const double *thresholds, const double *rho, int32_t train_flag, int32_t add_self, void *workspace,
+                   int64_t list_capacity, uint32_t *status, const pcg::DeferredAdam *ad, void *stream) {
     if (!g || !g->X || !W || !b || !s0_out || B < 0) return PCG_E_ARG;
     if (g->feat_dim < 1 || g->feat_stride < g->feat_dim || g->feat_stride % 4 != 0) return PCG_E_ARG;
     if ((reinterpret_cast<uintptr_t>(g->X) & 15u) != 0) return PCG_E_ARG;
@@ -501,17 +511,28 @@ int pcg_step_front_a(const pcg_graph_desc *g, const float *W, const float *b, in
     int n_key = raw ? (g->n_pos + rows_per_block - 1) / rows_per_block : 0;
     if (n_key > 256) n_key = 256;
     uint64_t *raw_keys = raw ? pos_keys + pcg_pos_sort_capacity(g->n_pos) / 2 : nullptr;
-    hipLaunchKernelGGL(pcg::front_a_kernel, dim3(n_count + n_key + n_score), dim3(pcg::FRONT_COUNT_THREADS), 0,
-                       static_cast<hipStream_t>(stream), a, tot, n_count, n_key, raw_keys, W, b, row_begin, row_end, s0_out);
+    pcg::DeferredAdam none = {};
+    const int n_adam = ad ? (int)((ad->p_end + PCG_WAVE - 1) / PCG_WAVE) : 0;
+    hipLaunchKernelGGL(pcg::front_a_kernel, dim3(n_count + n_key + n_adam + n_score), dim3(pcg::FRONT_COUNT_THREADS), 0,
+                       static_cast<hipStream_t>(stream), a, tot, n_count, n_key, raw_keys, W, b, row_begin, row_end, s0_out,
+                       ad ? *ad : none, n_adam);
     PCG_LAUNCH_CHECK();
     return PCG_OK;
 }
 
+int pcg_step_front_a(const pcg_graph_desc *g, const float *W, const float *b, int64_t row_begin, int64_t row_end,
+                     float *s0_out, uint64_t *pos_keys, const int32_t *nodes, const int32_t *labels, int32_t B,
+                     const double *thresholds, const double *rho, int32_t train_flag, int32_t add_self, void *workspace,
+                     int64_t list_capacity, uint32_t *status, void *stream) {
+    return front_a(g, W, b, row_begin, row_end, s0_out, pos_keys, nodes, labels, B, thresholds, rho, train_flag, add_self,
+                   workspace, list_capacity, status, nullptr, stream);
+}
+
 /* second half: train-pos sort by s0 (if train_flag and n_pos > 0)  ||  plan pass 2 */
-int pcg_step_front_b(const pcg_graph_desc *g, const float *s0, uint64_t *pos_keys, int32_t raw_keys_ready,
-                     const int32_t *nodes, const int32_t *labels, int32_t B, const double *thresholds, const double *rho,
-                     int32_t train_flag, int32_t add_self, void *workspace, int64_t list_capacity, uint32_t *status,
-                     void *stream) {
+static int front_b(const pcg_graph_desc *g, const float *s0, uint64_t *pos_keys, int32_t raw_keys_ready,
+                   const int32_t *nodes, const int32_t *labels, int32_t B, const double *thresholds, const double *rho,
+                   int32_t train_flag, int32_t add_self, void *workspace, int64_t list_capacity, uint32_t *status,
+                   uint32_t *pending, void *stream) {
     if (!g || !s0 || B < 0) return PCG_E_ARG;
     const bool sort = train_flag && g->n_pos > 0;
     if (sort && (!pos_keys || !g->train_pos)) return PCG_E_ARG;
@@ -529,10 +550,43 @@ int pcg_step_front_b(const pcg_graph_desc *g, const float *s0, uint64_t *pos_key
     const int64_t cap = sort ? pcg_pos_sort_capacity(g->n_pos) / 2 : 0;
     const uint64_t *raw_keys = (rank && raw_keys_ready) ? pos_keys + cap : nullptr;
     hipLaunchKernelGGL(pcg::front_b_kernel, dim3(n_write + n_sort), dim3(pcg::PLAN_THREADS), 0, static_cast<hipStream_t>(stream), a,
-                       tot, n_write, n_count, pos_keys, (int)cap, raw_keys);
+                       tot, n_write, n_count, pos_keys, (int)cap, raw_keys, pending);
     PCG_LAUNCH_CHECK();
     if (sort && !rank) return pcg_pos_sort(g, s0, pos_keys, stream);    // many positives: the chunk sort's own launches
     return PCG_OK;
+}
+
+int pcg_step_front_b(const pcg_graph_desc *g, const float *s0, uint64_t *pos_keys, int32_t raw_keys_ready,
+                     const int32_t *nodes, const int32_t *labels, int32_t B, const double *thresholds, const double *rho,
+                     int32_t train_flag, int32_t add_self, void *workspace, int64_t list_capacity, uint32_t *status,
+                     void *stream) {
+    return front_b(g, s0, pos_keys, raw_keys_ready, nodes, labels, B, thresholds, rho, train_flag, add_self, workspace,
+                   list_capacity, status, nullptr, stream);
+}
+
+/* pcg_step_front of a TRAINING step, with the previous step's deferred Adam update riding along the score pass */
+int pcg_step_front_train(const pcg_graph_desc *g, float *theta, float *m, float *v, int32_t emb, float *s0, uint64_t *pos_keys,
+                         const int32_t *nodes, const int32_t *labels, int32_t B, const double *thresholds, const double *rho,
+                         int32_t add_self, void *workspace, int64_t list_capacity, uint32_t *status, const float *slabs,
+                         const int32_t *step_counter, uint32_t *sync_words, double lr, double beta1, double beta2, double eps,
+                         double weight_decay, void *stream) {
+    if (!g || !theta || !m || !v || !slabs || !step_counter || !sync_words || B < 1) return PCG_E_ARG;
+    const int64_t n_params = pcg_dense_n_params(g->feat_dim, emb, g->n_rel);
+    const int64_t o_clf = pcg_dense_param_offset(g->feat_dim, emb, g->n_rel, 3, 0), o_b = pcg_dense_param_offset(g->feat_dim, emb, g->n_rel, 4, 0);
+    if (n_params < 0 || o_clf < 0) return PCG_E_ARG;
+    pcg::DeferredAdam ad;
+    ad.theta = theta; ad.m = m; ad.v = v;
+    ad.slabs = slabs;
+    ad.n_params = n_params;
+    ad.p_end = o_clf;
+    ad.step_counter = step_counter;
+    ad.pending = sync_words + 1;
+    ad.h = {(float)lr, (float)beta1, (float)beta2, (float)eps, (float)weight_decay};
+    const int rc = front_a(g, theta + o_clf, theta + o_b, 0, g->n_nodes, s0, pos_keys, nodes, labels, B, thresholds, rho, 1, add_self,
+                           workspace, list_capacity, status, &ad, stream);
+    if (rc != PCG_OK) return rc;
+    return front_b(g, s0, pos_keys, 1, nodes, labels, B, thresholds, rho, 1, add_self, workspace, list_capacity, status,
+                   sync_words + 1, stream);
 }
 
 int pcg_step_front(const pcg_graph_desc *g, const float *W, const float *b, float *s0, uint64_t *pos_keys,
@@ -560,6 +614,20 @@ int pcg_choose_aggregate(const pcg_graph_desc *g, const int32_t *nodes, const in
     if (rc != PCG_OK) return rc;
     return pcg_aggregate_lists(g->X, g->feat_dim, g->feat_stride, g->n_rel * B, cnt, g, B, workspace, list_capacity,
                                norm, agg, agg_stride, stream);
+}
+
+int pcg_choose_gather_planned(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B, const float *s0,
+                              const float *center_s0, const uint64_t *pos_keys, const double *thresholds, const double *rho,
+                              int32_t train_flag, int32_t add_self, float *agg, int32_t agg_stride, int32_t *cnt, void *workspace,
+                              int64_t list_capacity, uint32_t *status, void *stream) {
+    if (!g || B < 0) return PCG_E_ARG;
+    if (B == 0) return PCG_OK;
+    if (!g->X || !agg) return PCG_E_ARG;
+    const int rc = pcg_choose_select_planned(g, nodes, labels, B, s0, center_s0, pos_keys, thresholds, rho, train_flag,
+                                             add_self, cnt, workspace, list_capacity, status, stream);
+    if (rc != PCG_OK) return rc;
+    return pcg_gather_lists(g->X, g->feat_dim, g->feat_stride, g->n_rel * B, cnt, g, B, workspace, list_capacity, agg, agg_stride,
+                            stream);
 }
 
 int pcg_choose_aggregate_planned(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B,

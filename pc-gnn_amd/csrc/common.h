@@ -250,4 +250,83 @@ __device__ __forceinline__ void rank_sort_body(const float *__restrict__ s0, con
         for (int t = n_pos + threadIdx.x; t < cap; t += blockDim.x) keys[t] = ~0ull;
 }
 
+// ---- Adam update of a range of the flat parameter buffer from per-tile gradient slabs -----------------------------------
+// (torch.optim.Adam with coupled L2 weight decay, src/model_handler.py:124,153).  Shared by the stand-alone kernel
+// (dense.hip) and the step-front kernel, where the update of the previous step rides along the score pass (choose.hip).
+// g = sum over slabs in a fixed order (8 interleaved partial sums per wave, then a fixed tree), so 8 slab reads are in
+// flight per thread and the result is bitwise reproducible.  Workgroup `block` (256 threads) owns 64 parameters
+// [p_begin + 64 * block, ...) below p_end; the slabs are split over its 4 waves.  part: 4 * 64 floats of LDS.
+struct AdamHyper {
+    float lr, beta1, beta2, eps, wd;
+};
+constexpr int ADAM_ACC = 8;
+__device__ __forceinline__ void adam_reduce_body(float *__restrict__ theta, float *__restrict__ m, float *__restrict__ v,
+                                                 const float *__restrict__ slabs, int n_slabs, int64_t n_params,
+                                                 int64_t p_begin, int64_t p_end, const int32_t *__restrict__ step_counter,
+                                                 AdamHyper h, float *__restrict__ grad_out, int apply, int block,
+                                                 float (*part)[PCG_WAVE]) {
+    const int lane = threadIdx.x & (PCG_WAVE - 1), w = threadIdx.x >> 6;
+    const int64_t i = p_begin + (int64_t)block * PCG_WAVE + lane;
+    const bool ok = i < p_end;
+    const int per = (n_slabs + 3) / 4;
+    const int s_begin = w * per, s_end = (s_begin + per < n_slabs) ? s_begin + per : n_slabs;
+    // the optimizer state of wave 0's parameters is requested up front, behind nothing
+    float p = 0.f, m_old = 0.f, v_old = 0.f, t = 1.f;
+    if (w == 0 && ok && apply) {
+        p = theta[i];
+        m_old = m[i];
+        v_old = v[i];
+        t = (float)step_counter[0];
+    }
+    float acc[ADAM_ACC];
+#pragma unroll
+    for (int u = 0; u < ADAM_ACC; ++u) acc[u] = 0.f;
+    int s = s_begin;
+    if (ok) {
+        for (; s + ADAM_ACC <= s_end; s += ADAM_ACC) {
+#pragma unroll
+            for (int u = 0; u < ADAM_ACC; ++u) acc[u] += slabs[(size_t)(s + u) * n_params + i];
+        }
+        for (int u = 0; s < s_end; ++s, ++u) acc[u] += slabs[(size_t)s * n_params + i];
+    }
+    part[w][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    __syncthreads();
+    if (w != 0 || !ok) return;
+    float g = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    if (grad_out) grad_out[i] = g;
+    if (!apply) return;
+    g = fmaf(h.wd, p, g);
+    const float mi = h.beta1 * m_old + (1.f - h.beta1) * g;
+    const float vi = h.beta2 * v_old + (1.f - h.beta2) * g * g;
+    m[i] = mi;
+    v[i] = vi;
+    const float bc1 = 1.f - powf(h.beta1, t), bc2 = 1.f - powf(h.beta2, t);
+    const float denom = sqrtf(vi) / sqrtf(bc2) + h.eps;
+    theta[i] = p - (h.lr / bc1) * (mi / denom);
+}
+
+// the same update for one parameter whose summed gradient g is already known
+__device__ __forceinline__ void adam_apply_one(float *theta, float *m, float *v, int64_t i, float g, float t, AdamHyper h) {
+    const float p = theta[i];
+    g = fmaf(h.wd, p, g);
+    const float mi = h.beta1 * m[i] + (1.f - h.beta1) * g;
+    const float vi = h.beta2 * v[i] + (1.f - h.beta2) * g * g;
+    m[i] = mi;
+    v[i] = vi;
+    const float bc1 = 1.f - powf(h.beta1, t), bc2 = 1.f - powf(h.beta2, t);
+    const float denom = sqrtf(vi) / sqrtf(bc2) + h.eps;
+    theta[i] = p - (h.lr / bc1) * (mi / denom);
+}
+
+// what the step-front kernel needs to apply the previous step's deferred update (all parameters below p_end)
+struct DeferredAdam {
+    float *theta, *m, *v;
+    const float *slabs;
+    int64_t n_params, p_end;
+    const int32_t *step_counter;
+    uint32_t *pending;       // device words: [0] = 1: the slabs hold a gradient that has not been applied to [0, p_end) yet,
+                             // [1] = in how many slabs (pcg_train_dense sets both; the launch after the update clears [0])
+    AdamHyper h;
+};
+
 }  // namespace pcg

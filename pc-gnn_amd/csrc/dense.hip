@@ -1,19 +1,26 @@
-// Dense tail of the PC-GNN step for gfx950: relation GEMMs, inter GEMM, classifier,
-// the two cross-entropy terms, their backward and Adam - two launches per step.
+// Dense tail of the PC-GNN step for gfx950: relation GEMMs, inter GEMM, classifier, the two cross-entropy terms,
+// their backward and Adam.
 //
-//   dense_step : one 256-thread workgroup per tile of 16 batch rows does the whole
-//                forward for its rows, the loss gradients, and this tile's partial
-//                weight gradients (split-K over the batch: one partial "slab" per
-//                tile, no atomics => bitwise reproducible).  GEMMs run on the f32
-//                matrix cores (v_mfma_f32_16x16x4_f32: exact fmaf chains).
-//   adam_reduce: sums the slabs in tile order and applies torch.optim.Adam's update
-//                (coupled L2 weight decay) to the flat parameter buffer.
+//   dense_step : one 1024-thread workgroup per tile of 16 batch rows (up to 4 of them when the batch has few tiles: all
+//                run the forward pass, the weight-gradient tiles are dealt out among them) does the whole forward for its
+//                rows, the loss gradients, and this tile's partial weight gradients (split-K over the batch: one partial
+//                "slab" per tile, no atomics => bitwise reproducible).  GEMMs run on the f32 matrix cores
+//                (v_mfma_f32_16x16x4_f32: exact fmaf chains).  Rows whose selection list the gather left as several
+//                partial sums are summed (in chunk order) while the tile is staged - no combine launch.  Optionally the
+//                workgroup whose label-classifier gradient arrives last applies Adam to those 2F + 2 parameters - the only
+//                ones the next step's score pass needs - so that the update of all others can ride along that pass.
+//   adam_reduce: sums the slabs in tile order and applies torch.optim.Adam's update (coupled L2 weight decay) to a
+//                range of the flat parameter buffer.
+//
+// f32 MFMA runs at the f32 vector rate (256 FLOP / clk / CU): one tile is ~2.6 MFLOP forward + backward, i.e. >= 4 us of
+// matrix time on ONE CU, which is why a tile's work is spread over several workgroups rather than several tiles looped
+// over by one (the slabs that costs are summed by the Adam pass, beside the next step's score pass).
 //
 // Reference lines replaced: src/layers.py:273-289, 625-629; src/model.py:34-62;
 // src/model_handler.py:124,149-153 (optimizer.zero_grad / loss.backward / optimizer.step).
 // Gradients never flow into the gathered features or the selection (features frozen,
 // model_handler.py:86; selection is index-only), so backward is dense GEMMs only.
-#include "common.h"
+#include "choose.h"
 
 namespace pcg {
 
@@ -21,6 +28,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TB = 16;          // batch rows per workgroup (one MFMA M-tile)
 constexpr int DENSE_WAVES = 16;
+constexpr int DENSE_THREADS = DENSE_WAVES * PCG_WAVE;
+constexpr int WSTAGE = 8;       // weight float4 loads in flight per thread while staging
 
 struct DenseArgs {
     const float *X;
@@ -30,6 +39,11 @@ struct DenseArgs {
     int32_t B;
     const float *agg;           // [R, B, agg_stride]
     int32_t agg_stride;
+    // optional: rows of more than one gather chunk are summed here from the gather's partial sums (no combine launch)
+    const int32_t *chunk_begin; // [R * B + 1] or null (agg is complete)
+    const float *partial;       // [chunks, partial_stride]
+    const int32_t *cnt;         // [R * B]
+    int32_t partial_stride;
     const float *W_cls;         // [2, E]
     const float *W_inter;       // [F + R*E, E]
     const float *W_intra[PCG_MAX_REL];  // [2F, E]
@@ -44,6 +58,11 @@ struct DenseArgs {
     int64_t n_params;
     int32_t *step_counter;      // incremented once per training launch (Adam's t), or null
     int32_t n_split;            // training: workgroups per 16-row tile; they all run the forward pass, the weight-gradient tiles are dealt out
+    // optional: Adam for the label classifier's parameters by the workgroup whose gradient arrives last
+    float *theta, *m, *v;       // null => off
+    uint32_t *ticket;           // device word, 0 between launches
+    uint32_t *pending;          // two device words: [0] = 1 "the slabs hold a gradient not yet applied to the other parameters", [1] = its slab count
+    AdamHyper h;
     unsigned long long *stamps; // diagnostic only (pcg_debug_set_dense_stamps): [tiles][16] wall-clock ticks, else null
 };
 #define DENSE_STAMP(slot) do { if (a.stamps && threadIdx.x == 0 && sp == 0) a.stamps[(size_t)tile_id * 16 + (slot)] = wall_clock64(); } while (0)
@@ -58,13 +77,13 @@ __host__ __device__ inline int64_t off_clf(int F, int E, int R) { return off_int
 __host__ __device__ inline int64_t off_bias(int F, int E, int R) { return off_clf(F, E, R) + 2 * (int64_t)F; }
 __host__ __device__ inline int64_t n_params_of(int F, int E, int R) { return off_bias(F, E, R) + 2; }
 
-// C[16x16] += A[16 x K] (LDS, row-major, leading dim lda, zero-padded to Kp) * B[K x ..] (global, ld ldb, column n0..n0+15)
+// C[16x16] += A[16 x k-steps] (LDS, row-major, leading dim lda) * B (global, ld ldb, column n0..n0+15), k in [k_lo, k_hi)
 __device__ __forceinline__ f32x4 tile_lds_glob(const float *A, int lda, const float *__restrict__ Bg, int ldb, int n0,
-                                               int K, int Kp, int lane) {
+                                               int K, int k_lo, int k_hi, int lane) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const int r = lane & 15, kq = lane >> 4;
 #pragma unroll 4
-    for (int k0 = 0; k0 < Kp; k0 += 4) {
+    for (int k0 = k_lo; k0 < k_hi; k0 += 4) {
         const int k = k0 + kq;
         const float a = A[r * lda + k];
         const float b = (k < K) ? Bg[(size_t)k * ldb + n0 + r] : 0.f;
@@ -73,33 +92,17 @@ __device__ __forceinline__ f32x4 tile_lds_glob(const float *A, int lda, const fl
     return acc;
 }
 
-// C[16x16] += A[16 x K] (LDS) * B[K x ..] (LDS copy of a weight matrix, leading dim ldb, column n0..n0+15)
-__device__ __forceinline__ f32x4 tile_lds_lds(const float *A, int lda, const float *Bl, int ldb, int n0, int Kp,
+// the same with B an LDS copy of the weight matrix (leading dim ldb; rows beyond K are zero)
+__device__ __forceinline__ f32x4 tile_lds_lds(const float *A, int lda, const float *Bl, int ldb, int n0, int k_lo, int k_hi,
                                               int lane) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const int r = lane & 15, kq = lane >> 4;
 #pragma unroll 8
-    for (int k0 = 0; k0 < Kp; k0 += 4) {
+    for (int k0 = k_lo; k0 < k_hi; k0 += 4) {
         const int k = k0 + kq;
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[r * lda + k], Bl[k * ldb + n0 + r], acc, 0, 0, 0);
     }
     return acc;
-}
-
-// cooperative copy of a row-major [rows x cols] weight matrix into LDS with leading dim ld; rows..rows_pad-1 zeroed
-__device__ __forceinline__ void stage_weights(float *dst, int ld, const float *__restrict__ src, int rows, int rows_pad,
-                                              int cols) {
-    const int c4 = cols >> 2;                       // cols % 4 == 0 (E % 16 == 0)
-    for (int i = threadIdx.x; i < rows * c4; i += blockDim.x) {
-        const int rr = i / c4, cc = (i - rr * c4) * 4;
-        const float4 v = *reinterpret_cast<const float4 *>(src + (size_t)rr * cols + cc);
-        float *d = dst + rr * ld + cc;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-    }
-    for (int i = threadIdx.x; i < (rows_pad - rows) * cols; i += blockDim.x) {
-        const int rr = rows + i / cols, cc = i % cols;
-        dst[rr * ld + cc] = 0.f;
-    }
 }
 
 // C[16x16] = At^T * Bt with both operands row tiles in LDS: C[m][n] = sum_t At[t][m0+m] * Bt[t][n0+n], t < 16
@@ -128,19 +131,31 @@ __device__ __forceinline__ void xent2(float a, float b, int y, float &loss, floa
     db = eb / s - (y == 1 ? 1.f : 0.f);
 }
 
+// sum over the 16 lanes of a DPP row (every lane gets it): quad permutes, then the half-row / row mirrors
+__device__ __forceinline__ float row16_sum(float p) {
+    p = dpp_add<0xB1>(p);
+    p = dpp_add<0x4E>(p);
+    p = dpp_add<0x141>(p);
+    p = dpp_add<0x140>(p);
+    return p;
+}
+
 // WLDS: the weight matrices are staged in LDS once per workgroup (when they fit), so every MFMA operand
 // is an LDS read; otherwise the B operands stream from global memory / L2.
-// Phases (one barrier between them): stage -> h_r for all relations -> combined -> logits ->
-// loss grads -> dcomb + small dW -> {dh_r for all r, dW_inter} -> dW_r for all r.
+// Phases (one barrier between them): stage -> h_r for all relations -> combined (K split over the waves) -> logits + loss
+// grads -> dcomb + small dW -> {dh_r for all r, dW_inter} -> dW_r for all r.
 template <bool WLDS>
-__global__ void __launch_bounds__(DENSE_WAVES *PCG_WAVE) dense_step_kernel(const DenseArgs a) {
+__global__ void __launch_bounds__(DENSE_THREADS) dense_step_kernel(const DenseArgs a) {
     extern __shared__ __align__(16) float sm[];
     const int F = a.feat_dim, E = a.emb, R = a.n_rel;
     const int K1 = 2 * F, K1p = (K1 + 3) & ~3, K2 = F + R * E, K2p = (K2 + 3) & ~3;
     const int ld1 = K1p + 1, ld2 = K2p + 1, ldE = E + 1, ldW = E + 4;   // ldW: rows stay 16-B aligned (ds_write_b128)
+    const int ntile_e = E / 16;
+    const int kparts = ntile_e <= DENSE_WAVES ? DENSE_WAVES / ntile_e : 1;      // waves sharing one output tile of `combined`
     float *s_wi = sm;                               // WLDS: [K2p][ldW] copy of W_inter   (first: 16-B aligned)
-    float *s_wr = s_wi + (WLDS ? K2p * ldW : 0);    // WLDS: [R][K1p][ldW] copies of W_intra
-    float *s_catr = s_wr + (WLDS ? R * K1p * ldW : 0);   // [R][TB][ld1]  [self | agg_r]
+    float *s_wr = s_wi + (WLDS ? K2p * ldW : 0);    // WLDS: [R][K1p][ldW] copies of W_intra; later the K-split partial tiles
+    float *s_part = WLDS ? s_wr : s_wr;             // [kparts][TB][E] partial sums of `combined` (W_intra is dead by then)
+    float *s_catr = s_wr + (WLDS ? R * K1p * ldW : kparts * TB * E);   // [R][TB][ld1]  [self | agg_r]
     float *s_cat = s_catr + R * TB * ld1;           // [TB][ld2]  [self | h_1 .. h_R]
     float *s_comb = s_cat + TB * ld2;               // [TB][ldE]
     float *s_dcomb = s_comb + TB * ldE;             // [TB][ldE]
@@ -148,160 +163,273 @@ __global__ void __launch_bounds__(DENSE_WAVES *PCG_WAVE) dense_step_kernel(const
     float *s_dlog = s_dh + R * TB * ldE;            // [TB][2] d loss / d gnn logits
     float *s_dcl = s_dlog + TB * 2;                 // [TB][2] d loss / d centre scores (already times lambda_1)
     float *s_wc = s_dcl + TB * 2;                   // [2][E] W_cls, [2][F] W_clf, [2] b_clf
-    float *s_tmp = s_wc + 2 * E + 2 * F + 4;        // [TB][4] logits scratch
+    int *s_flag = reinterpret_cast<int *>(s_wc + 2 * E + 2 * F + 4);   // [4] "this workgroup's classifier gradient arrived last"
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int S = a.n_split, tile_id = (int)blockIdx.x / S, sp = (int)blockIdx.x % S;
     const int row0 = tile_id * TB;
     const bool train = a.slabs != nullptr;
-    if (train && a.step_counter && blockIdx.x == 0 && tid == 0) a.step_counter[0] += 1;
+    if (train && blockIdx.x == 0 && tid == 0) {
+        // (an agent-scope atomic: the workgroup that applies the classifier's Adam reads the new count from another XCD)
+        if (a.step_counter) __hip_atomic_fetch_add(a.step_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a.pending) {
+            a.pending[0] = 1u;                                  // the slabs hold a gradient the other parameters still need
+            a.pending[1] = (unsigned)(gridDim.x / S);           // ... in this many slabs
+        }
+    }
     DENSE_STAMP(0);
 
-    // ---- stage: weights (16-B global loads -> 16-B LDS stores), classifier weights, zeroed tiles, self rows
-    if constexpr (WLDS) {
-        // thread -> (row, 16-B column chunk) fixed once: no per-element division, 4 rows in flight
-        const int c4 = E >> 2;
-        const int cc = (tid % c4) * 4, r0 = tid / c4, rstep = blockDim.x / c4;   // blockDim.x % c4 == 0 (host-checked)
-        auto stage = [&](float *dst, const float *__restrict__ src, int rows, int rows_pad) {
-            int rr = r0;
-            for (; rr + 3 * rstep < rows; rr += 4 * rstep) {
-                float4 v[4];
+    // ---- stage ----------------------------------------------------------------------------------------------------
+    // every global load of the prologue is requested before the first LDS store: weights (<= WSTAGE float4 per thread in
+    // flight), the tile's self rows (ids -> rows), its aggregated rows (or their partial sums)
+    {
+        // self rows and aggregates: element e of [TB][F] (self) and [R][TB][F] (agg), one or two per thread
+        const int n_self = TB * F, n_agg = R * TB * F;
+        float v_self = 0.f;
+        int self_t = 0, self_f = 0;
+        const bool do_self = tid < n_self;                                 // (TB * F <= 1024 for F <= 64; a loop covers the rest)
+        if (do_self) {
+            self_t = tid / F;
+            self_f = tid - self_t * F;
+            const int b = row0 + self_t;
+            if (b < a.B) v_self = a.X[(size_t)a.ids[b] * a.feat_stride + self_f];
+        }
+        constexpr int NAGG = 2;
+        float v_agg[NAGG];
+        int agg_at[NAGG];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4 *>(src + (size_t)(rr + u * rstep) * E + cc);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) *reinterpret_cast<float4 *>(dst + (rr + u * rstep) * ldW + cc) = v[u];
+        for (int u = 0; u < NAGG; ++u) {
+            const int i = tid + u * DENSE_THREADS;
+            v_agg[u] = 0.f;
+            agg_at[u] = -1;
+            if (i < n_agg) {
+                const int r = i / (TB * F), j = i - r * TB * F, t = j / F, f = j - t * F;
+                const int b = row0 + t;
+                agg_at[u] = (r * TB + t) * ld1 + F + f;
+                if (b < a.B) {
+                    const size_t row = (size_t)r * a.B + b;
+                    int cb = 0, nch = 1;
+                    if (a.chunk_begin) {
+                        cb = a.chunk_begin[row];
+                        nch = a.chunk_begin[row + 1] - cb;
+                    }
+                    if (nch == 0) v_agg[u] = 0.f / 0.f;      // empty set: 0 / 0 like the reference's mask.div (layers.py:612-614)
+                    else if (nch > 1) {     // sum of the gather's partial sums, in chunk order, / |set|  (== combine_rows)
+                        float acc = 0.f;
+                        const float *pp = a.partial + (size_t)cb * a.partial_stride + f;
+                        int jx = 0;
+                        for (; jx + 4 <= nch; jx += 4) {
+                            const float p0 = pp[(size_t)(jx + 0) * a.partial_stride], p1 = pp[(size_t)(jx + 1) * a.partial_stride];
+                            const float p2 = pp[(size_t)(jx + 2) * a.partial_stride], p3 = pp[(size_t)(jx + 3) * a.partial_stride];
+                            acc += p0; acc += p1; acc += p2; acc += p3;
+                        }
+                        for (; jx < nch; ++jx) acc += pp[(size_t)jx * a.partial_stride];
+                        v_agg[u] = acc / (float)a.cnt[row];
+                    } else {
+                        v_agg[u] = a.agg[row * a.agg_stride + f];
+                    }
+                }
             }
-            for (; rr < rows; rr += rstep)
-                *reinterpret_cast<float4 *>(dst + rr * ldW + cc) = *reinterpret_cast<const float4 *>(src + (size_t)rr * E + cc);
-            for (int i = tid; i < (rows_pad - rows) * E; i += blockDim.x) dst[(rows + i / E) * ldW + i % E] = 0.f;
-        };
-        stage(s_wi, a.W_inter, K2, K2p);
-        for (int r = 0; r < R; ++r) stage(s_wr + r * K1p * ldW, a.W_intra[r], K1, K1p);
-    }
-    for (int i = tid; i < 2 * E; i += blockDim.x) s_wc[i] = a.W_cls[i];
-    for (int i = tid; i < 2 * F; i += blockDim.x) s_wc[2 * E + i] = a.W_clf[i];
-    if (tid < 2) s_wc[2 * E + 2 * F + tid] = a.b_clf[tid];
-    for (int i = tid; i < TB * ld2; i += blockDim.x) s_cat[i] = 0.f;
-    for (int i = tid; i < R * TB * ld1; i += blockDim.x) s_catr[i] = 0.f;
-    __syncthreads();
-    for (int i = tid; i < TB * F; i += blockDim.x) {
-        const int t = i / F, f = i - t * F;
-        const int b = row0 + t;
-        if (b < a.B) {
-            const float v = a.X[(size_t)a.ids[b] * a.feat_stride + f];
+        }
+        if constexpr (WLDS) {
+            // the weight matrices as one list of rows [W_inter | W_intra[0] | ...] (contiguous in theta); thread -> (row, 16-B column chunk)
+            const int c4 = E >> 2;
+            const int cc = (tid % c4) * 4, r0 = tid / c4, rstep = DENSE_THREADS / c4;   // DENSE_THREADS % c4 == 0 (host-checked)
+            const int n_rows = K2 + R * K1;
+            for (int base = r0; base < n_rows; base += WSTAGE * rstep) {
+                float4 wv[WSTAGE];
+#pragma unroll
+                for (int u = 0; u < WSTAGE; ++u) {
+                    const int rr = base + u * rstep;
+                    // (theta is flat: W_inter's K2 rows are followed directly by W_intra[0]'s K1 rows, W_intra[1]'s, ...)
+                    wv[u] = *reinterpret_cast<const float4 *>(a.W_inter + (size_t)(rr < n_rows ? rr : n_rows - 1) * E + cc);
+                }
+#pragma unroll
+                for (int u = 0; u < WSTAGE; ++u) {
+                    const int rr = base + u * rstep;
+                    if (rr < n_rows) {
+                        float *dst = rr < K2 ? s_wi + rr * ldW
+                                             : s_wr + ((rr - K2) / K1) * K1p * ldW + ((rr - K2) % K1) * ldW;
+                        *reinterpret_cast<float4 *>(dst + cc) = wv[u];
+                    }
+                }
+            }
+            for (int i = tid; i < (K2p - K2) * E; i += DENSE_THREADS) s_wi[(K2 + i / E) * ldW + i % E] = 0.f;
+            for (int i = tid; i < R * (K1p - K1) * E; i += DENSE_THREADS) {
+                const int r = i / ((K1p - K1) * E), j = i - r * (K1p - K1) * E;
+                s_wr[r * K1p * ldW + (K1 + j / E) * ldW + j % E] = 0.f;
+            }
+        }
+        for (int i = tid; i < 2 * E; i += DENSE_THREADS) s_wc[i] = a.W_cls[i];
+        for (int i = tid; i < 2 * F; i += DENSE_THREADS) s_wc[2 * E + i] = a.W_clf[i];
+        if (tid < 2) s_wc[2 * E + 2 * F + tid] = a.b_clf[tid];
+        if (tid == 0) s_flag[0] = 0;
+        // activations: self into [self | .] of every concatenation, aggregates, zero pad columns
+        if (do_self) {
+            s_cat[self_t * ld2 + self_f] = v_self;
+            for (int r = 0; r < R; ++r) s_catr[(r * TB + self_t) * ld1 + self_f] = v_self;
+        }
+        for (int i = tid + DENSE_THREADS; i < n_self; i += DENSE_THREADS) {           // F > 64
+            const int t = i / F, f = i - t * F, b = row0 + t;
+            const float v = b < a.B ? a.X[(size_t)a.ids[b] * a.feat_stride + f] : 0.f;
             s_cat[t * ld2 + f] = v;
             for (int r = 0; r < R; ++r) s_catr[(r * TB + t) * ld1 + f] = v;
         }
-    }
-    for (int i = tid; i < R * TB * F; i += blockDim.x) {
-        const int r = i / (TB * F), j = i - r * TB * F, t = j / F, f = j - t * F;
-        const int b = row0 + t;
-        if (b < a.B) s_catr[(r * TB + t) * ld1 + F + f] = a.agg[((size_t)r * a.B + b) * a.agg_stride + f];
+#pragma unroll
+        for (int u = 0; u < NAGG; ++u)
+            if (agg_at[u] >= 0) s_catr[agg_at[u]] = v_agg[u];
+        for (int i = tid + NAGG * DENSE_THREADS; i < n_agg; i += DENSE_THREADS) {     // R * F > 128
+            const int r = i / (TB * F), j = i - r * TB * F, t = j / F, f = j - t * F, b = row0 + t;
+            float v = 0.f;
+            if (b < a.B) {
+                const size_t row = (size_t)r * a.B + b;
+                int cb = 0, nch = 1;
+                if (a.chunk_begin) {
+                    cb = a.chunk_begin[row];
+                    nch = a.chunk_begin[row + 1] - cb;
+                }
+                if (nch == 0) v = 0.f / 0.f;
+                else if (nch > 1) {
+                    float acc = 0.f;
+                    for (int jx = 0; jx < nch; ++jx) acc += a.partial[(size_t)(cb + jx) * a.partial_stride + f];
+                    v = acc / (float)a.cnt[row];
+                } else {
+                    v = a.agg[row * a.agg_stride + f];
+                }
+            }
+            s_catr[(r * TB + t) * ld1 + F + f] = v;
+        }
+        for (int i = tid; i < R * TB * (ld1 - K1); i += DENSE_THREADS) {              // pad columns K1 .. ld1
+            const int rt = i / (ld1 - K1), c = K1 + i % (ld1 - K1);
+            s_catr[rt * ld1 + c] = 0.f;
+        }
+        for (int i = tid; i < TB * (ld2 - K2); i += DENSE_THREADS) s_cat[(i / (ld2 - K2)) * ld2 + K2 + i % (ld2 - K2)] = 0.f;
     }
     __syncthreads();
     DENSE_STAMP(1);
 
     // ---- forward: h_r = relu([self | agg_r] W_r) for every relation   (layers.py:625-629) ---------
-    const int ntile_e = E / 16;
     for (int tile = wave; tile < R * ntile_e; tile += DENSE_WAVES) {
         const int r = tile / ntile_e, ct = tile - r * ntile_e;
         const float *A = s_catr + r * TB * ld1;
-        const f32x4 c = WLDS ? tile_lds_lds(A, ld1, s_wr + r * K1p * ldW, ldW, ct * 16, K1p, lane)
-                             : tile_lds_glob(A, ld1, a.W_intra[r], E, ct * 16, K1, K1p, lane);
+        const f32x4 c = WLDS ? tile_lds_lds(A, ld1, s_wr + r * K1p * ldW, ldW, ct * 16, 0, K1p, lane)
+                             : tile_lds_glob(A, ld1, a.W_intra[r], E, ct * 16, K1, 0, K1p, lane);
         const int col = ct * 16 + (lane & 15), rq = (lane >> 4) * 4;
 #pragma unroll
         for (int i = 0; i < 4; ++i) s_cat[(rq + i) * ld2 + F + r * E + col] = fmaxf(c[i], 0.f);
     }
     __syncthreads();
     DENSE_STAMP(2);
-    // ---- combined = relu(cat W)   (layers.py:284-289) -------------------------------------
-    for (int ct = wave; ct < ntile_e; ct += DENSE_WAVES) {
-        const f32x4 c = WLDS ? tile_lds_lds(s_cat, ld2, s_wi, ldW, ct * 16, K2p, lane)
-                             : tile_lds_glob(s_cat, ld2, a.W_inter, E, ct * 16, K2, K2p, lane);
-        const int col = ct * 16 + (lane & 15), rq = (lane >> 4) * 4;
+    // ---- combined = relu(cat W)   (layers.py:284-289): the K dimension of every output tile split over `kparts` waves,
+    //      their partial tiles added in a fixed order ----------------------------------------------------------------
+    {
+        const int ksteps = K2p / 4;
+        const int per = (ksteps + kparts - 1) / kparts;
+        for (int item = wave; item < ntile_e * kparts; item += DENSE_WAVES) {
+            const int ct = item % ntile_e, kp = item / ntile_e;
+            const int k_lo = kp * per * 4, k_hi = (kp + 1) * per * 4 < K2p ? (kp + 1) * per * 4 : K2p;
+            const f32x4 c = WLDS ? tile_lds_lds(s_cat, ld2, s_wi, ldW, ct * 16, k_lo, k_hi, lane)
+                                 : tile_lds_glob(s_cat, ld2, a.W_inter, E, ct * 16, K2, k_lo, k_hi, lane);
+            const int col = ct * 16 + (lane & 15), rq = (lane >> 4) * 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float v = fmaxf(c[i], 0.f);
-            s_comb[(rq + i) * ldE + col] = v;
-            const int b = row0 + rq + i;
-            if (a.combined && b < a.B && sp == 0) a.combined[(size_t)b * E + col] = v;
+            for (int i = 0; i < 4; ++i) s_part[(kp * TB + rq + i) * E + col] = c[i];
+        }
+        __syncthreads();
+        for (int i = tid; i < TB * E; i += DENSE_THREADS) {
+            const int t = i / E, e = i - t * E;
+            float acc = s_part[t * E + e];
+            for (int kp = 1; kp < kparts; ++kp) acc += s_part[(kp * TB + t) * E + e];
+            const float v = fmaxf(acc, 0.f);
+            s_comb[t * ldE + e] = v;
+            const int b = row0 + t;
+            if (a.combined && b < a.B && sp == 0) a.combined[(size_t)b * E + e] = v;
         }
     }
     __syncthreads();
     DENSE_STAMP(3);
-    // ---- logits, centre scores, loss gradients (model.py:38, layers.py:243, model.py:54-61) ---
-    if (tid < TB * 16) {   // 16 rows x 4 dot products, each split over 4 lanes, combined by a 2-step butterfly
-        const int part = tid & 3, which = (tid >> 2) & 3, t = tid >> 4;
+    // ---- logits, centre scores, loss gradients (model.py:38, layers.py:243, model.py:54-61): wave t has row t; its four
+    //      dot products run on 16 lanes each and are added with DPP row operations; no LDS, no barrier in between ----
+    {
+        const int t = wave, which = lane >> 4, part = lane & 15, b = row0 + t;
         float acc = 0.f;
         if (which < 2) {
             const float *wv = s_wc + which * E;
-            for (int e = part; e < E; e += 4) acc = fmaf(s_comb[t * ldE + e], wv[e], acc);
+            for (int e = part; e < E; e += 16) acc = fmaf(s_comb[t * ldE + e], wv[e], acc);
         } else {
             const float *wv = s_wc + 2 * E + (which - 2) * F;
-            for (int f = part; f < F; f += 4) acc = fmaf(s_cat[t * ld2 + f], wv[f], acc);
+            for (int f = part; f < F; f += 16) acc = fmaf(s_cat[t * ld2 + f], wv[f], acc);
         }
-        acc += __shfl_xor(acc, 1);
-        acc += __shfl_xor(acc, 2);
-        if (part == 0) s_tmp[t * 4 + which] = acc + (which >= 2 ? s_wc[2 * E + 2 * F + (which - 2)] : 0.f);
-    }
-    __syncthreads();
-    if (tid < TB) {
-        const int t = tid, b = row0 + t;
-        const float g0 = s_tmp[t * 4 + 0], g1 = s_tmp[t * 4 + 1], c0 = s_tmp[t * 4 + 2], c1 = s_tmp[t * 4 + 3];
-        float dg0 = 0.f, dg1 = 0.f, dc0 = 0.f, dc1 = 0.f;
-        if (b < a.B) {
-            if (sp == 0) {
-                a.logits[2 * b] = g0;
-                a.logits[2 * b + 1] = g1;
-                a.center[2 * b] = c0;
-                a.center[2 * b + 1] = c1;
+        acc = row16_sum(acc);
+        const float g0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 0));
+        const float g1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 16));
+        const float c0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 32)) + s_wc[2 * E + 2 * F];
+        const float c1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 48)) + s_wc[2 * E + 2 * F + 1];
+        if (lane == 0) {
+            float dg0 = 0.f, dg1 = 0.f, dc0 = 0.f, dc1 = 0.f;
+            if (b < a.B) {
+                if (sp == 0) {
+                    a.logits[2 * b] = g0;
+                    a.logits[2 * b + 1] = g1;
+                    a.center[2 * b] = c0;
+                    a.center[2 * b + 1] = c1;
+                }
+                if (a.labels) {
+                    const int y = a.labels[b];
+                    float lg, lc;
+                    xent2(g0, g1, y, lg, dg0, dg1);
+                    xent2(c0, c1, y, lc, dc0, dc1);
+                    if (a.row_loss && sp == 0) a.row_loss[b] = lg + a.lambda_1 * lc;
+                    dg0 *= a.inv_count; dg1 *= a.inv_count;
+                    dc0 *= a.inv_count * a.lambda_1; dc1 *= a.inv_count * a.lambda_1;
+                }
             }
-            if (a.labels) {
-                const int y = a.labels[b];
-                float lg, lc;
-                xent2(g0, g1, y, lg, dg0, dg1);
-                xent2(c0, c1, y, lc, dc0, dc1);
-                if (a.row_loss && sp == 0) a.row_loss[b] = lg + a.lambda_1 * lc;
-                dg0 *= a.inv_count; dg1 *= a.inv_count;
-                dc0 *= a.inv_count * a.lambda_1; dc1 *= a.inv_count * a.lambda_1;
-            }
+            s_dlog[2 * t] = dg0; s_dlog[2 * t + 1] = dg1;
+            s_dcl[2 * t] = dc0; s_dcl[2 * t + 1] = dc1;
         }
-        s_dlog[2 * t] = dg0; s_dlog[2 * t + 1] = dg1;
-        s_dcl[2 * t] = dc0; s_dcl[2 * t + 1] = dc1;
     }
     __syncthreads();
     DENSE_STAMP(4);
     if (!train) return;
 
     float *slab = a.slabs + (size_t)tile_id * a.n_params;
-    // ---- backward ----------------------------------------------------------------------------
+    const bool adam_clf = a.theta != nullptr;
+    // ---- backward ----------------------------------------------------------------------------------------------------
     // dcomb = (dlogits W_cls) * relu'(combined);  dW_cls, dW_clf, db_clf
-    for (int i = tid; i < TB * E; i += blockDim.x) {
+    for (int i = tid; i < TB * E; i += DENSE_THREADS) {
         const int t = i / E, e = i - t * E;
         const float g = s_dlog[2 * t] * s_wc[e] + s_dlog[2 * t + 1] * s_wc[E + e];
         s_dcomb[t * ldE + e] = s_comb[t * ldE + e] > 0.f ? g : 0.f;
     }
     DENSE_STAMP(8);
-    for (int i = tid; i < (sp == 0 ? 2 * E : 0); i += blockDim.x) {
+    for (int i = tid; i < (sp == 0 ? 2 * E : 0); i += DENSE_THREADS) {
         const int cidx = i / E, e = i - cidx * E;
         float sacc = 0.f;
         for (int t = 0; t < TB; ++t) sacc = fmaf(s_dlog[2 * t + cidx], s_comb[t * ldE + e], sacc);
         slab[off_cls(F, E, R) + i] = sacc;
     }
     DENSE_STAMP(9);
-    for (int i = tid; i < (sp == 0 ? 2 * F : 0); i += blockDim.x) {
-        const int cidx = i / F, f = i - cidx * F;
+    // the label classifier's partial gradient: write-through (sc1) stores when another workgroup of this launch will read it
+    for (int i = tid; i < (sp == 0 ? 2 * F + 2 : 0); i += DENSE_THREADS) {
         float sacc = 0.f;
-        for (int t = 0; t < TB; ++t) sacc = fmaf(s_dcl[2 * t + cidx], s_cat[t * ld2 + f], sacc);
-        slab[off_clf(F, E, R) + i] = sacc;
+        if (i < 2 * F) {
+            const int cidx = i / F, f = i - cidx * F;
+            for (int t = 0; t < TB; ++t) sacc = fmaf(s_dcl[2 * t + cidx], s_cat[t * ld2 + f], sacc);
+        } else {
+            for (int t = 0; t < TB; ++t) sacc += s_dcl[2 * t + (i - 2 * F)];
+        }
+        float *dst = slab + off_clf(F, E, R) + i;
+        if (adam_clf) __hip_atomic_store(dst, sacc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *dst = sacc;
     }
+    if (adam_clf) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains before the barrier
     DENSE_STAMP(10);
-    if (tid < 2 && sp == 0) {
-        float sacc = 0.f;
-        for (int t = 0; t < TB; ++t) sacc += s_dcl[2 * t + tid];
-        slab[off_bias(F, E, R) + tid] = sacc;
-    }
     __syncthreads();
+    if (adam_clf && tid == 0) {
+        // arrival ticket, taken by EVERY workgroup (the partial gradients above are write-through and drained; and a
+        // workgroup that has arrived has long read the classifier's weights): the last to arrive applies Adam to them
+        const unsigned old = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == (unsigned)gridDim.x - 1u) s_flag[0] = 1;
+    }
     DENSE_STAMP(5);
     // one phase: dh_r = (dcomb W[F+rE.., :]^T) * relu'(h_r) for every r   and   dW_inter = cat^T dcomb
     {
@@ -355,70 +483,149 @@ __global__ void __launch_bounds__(DENSE_WAVES *PCG_WAVE) dense_step_kernel(const
                 if (m0 + rq + i < K1) dst[(size_t)(m0 + rq + i) * E + col] = c[i];
         }
     }
-    __syncthreads();
     DENSE_STAMP(7);
+    // ---- the workgroup whose classifier gradient arrived last: sum of every tile's share (tile order), Adam for those
+    //      2F + 2 parameters (model_handler.py:153) - the only ones the next step's score pass reads --------------------
+    if (adam_clf && s_flag[0]) {            // (s_flag was written before the barrier that follows the dh_r phase)
+        if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int n_tiles = (int)gridDim.x / S;
+        const int64_t oc = off_clf(F, E, R);
+        for (int i = tid; i < 2 * F + 2; i += DENSE_THREADS) {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            int s = 0;
+            for (; s + 4 <= n_tiles; s += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    acc[u] += __hip_atomic_load(a.slabs + (size_t)(s + u) * a.n_params + oc + i, __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT);
+            }
+            for (; s < n_tiles; ++s)
+                acc[0] += __hip_atomic_load(a.slabs + (size_t)s * a.n_params + oc + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float g = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            // t: the step this launch counted (block 0 incremented the counter at its start; read it past the L1)
+            const float t = (float)__hip_atomic_load(a.step_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            adam_apply_one(a.theta, a.m, a.v, oc + i, g, t, a.h);
+        }
+        if (tid == 0) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
-// g = sum over slabs in a fixed order (8 interleaved partial sums, then a fixed tree), so 8 slab
-// reads are in flight per thread; torch.optim.Adam step with coupled weight decay.
-constexpr int ADAM_ACC = 8;
 __global__ void __launch_bounds__(256) adam_reduce_kernel(float *__restrict__ theta, float *__restrict__ m,
                                                           float *__restrict__ v, const float *__restrict__ slabs,
-                                                          int n_slabs, int64_t n_params,
-                                                          const int32_t *__restrict__ step_counter, float lr,
-                                                          float beta1, float beta2, float eps, float wd,
-                                                          float *__restrict__ grad_out, int apply) {
-    // 64 parameters per workgroup; the slabs are split over its 4 waves (each: 8 interleaved accumulators = 8 loads in
-    // flight), the four partial sums are added in wave order: a fixed order, and a quarter of the dependent load batches
+                                                          int n_slabs, int64_t n_params, int64_t p_begin, int64_t p_end,
+                                                          const int32_t *__restrict__ step_counter, AdamHyper h,
+                                                          float *__restrict__ grad_out, int apply, const uint32_t *pending) {
     __shared__ float part[4][PCG_WAVE];
-    const int lane = threadIdx.x & (PCG_WAVE - 1), w = threadIdx.x >> 6;
-    const int64_t i = (int64_t)blockIdx.x * PCG_WAVE + lane;
-    const bool ok = i < n_params;
-    const int per = (n_slabs + 3) / 4;
-    const int s_begin = w * per, s_end = (s_begin + per < n_slabs) ? s_begin + per : n_slabs;
-    // the optimizer state of wave 0's parameters is requested up front, behind nothing
-    float p = 0.f, m_old = 0.f, v_old = 0.f, t = 1.f;
-    if (w == 0 && ok && apply) {
-        p = theta[i];
-        m_old = m[i];
-        v_old = v[i];
-        t = (float)step_counter[0];
+    if (pending) {                                    // the deferred update: nothing to do unless a gradient is waiting
+        if (pending[0] == 0u) return;                 // (wave-uniform: one word)
+        n_slabs = (int)pending[1];
     }
-    float acc[ADAM_ACC];
-#pragma unroll
-    for (int u = 0; u < ADAM_ACC; ++u) acc[u] = 0.f;
-    int s = s_begin;
-    if (ok) {
-        for (; s + ADAM_ACC <= s_end; s += ADAM_ACC) {
-#pragma unroll
-            for (int u = 0; u < ADAM_ACC; ++u) acc[u] += slabs[(size_t)(s + u) * n_params + i];
-        }
-        for (int u = 0; s < s_end; ++s, ++u) acc[u] += slabs[(size_t)s * n_params + i];
-    }
-    part[w][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
-    __syncthreads();
-    if (w != 0 || !ok) return;
-    float g = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
-    if (grad_out) grad_out[i] = g;
-    if (!apply) return;
-    g = fmaf(wd, p, g);
-    const float mi = beta1 * m_old + (1.f - beta1) * g;
-    const float vi = beta2 * v_old + (1.f - beta2) * g * g;
-    m[i] = mi;
-    v[i] = vi;
-    const float bc1 = 1.f - powf(beta1, t), bc2 = 1.f - powf(beta2, t);
-    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
-    theta[i] = p - (lr / bc1) * (mi / denom);
+    adam_reduce_body(theta, m, v, slabs, n_slabs, n_params, p_begin, p_end, step_counter, h, grad_out, apply, (int)blockIdx.x, part);
 }
+
+__global__ void clear_word_kernel(uint32_t *w) { w[0] = 0u; }
 
 static size_t dense_smem_bytes(int F, int E, int R, bool wlds) {
     const int K1p = (2 * F + 3) & ~3, K2p = (F + R * E + 3) & ~3;
-    size_t fl = (size_t)(R * TB * (K1p + 1) + TB * (K2p + 1) + (2 + R) * TB * (E + 1) + 4 * TB + 2 * E + 2 * F + 4 + 4 * TB);
+    const int ntile_e = E / 16, kparts = ntile_e <= DENSE_WAVES ? DENSE_WAVES / ntile_e : 1;
+    size_t fl = (size_t)(R * TB * (K1p + 1) + TB * (K2p + 1) + (2 + R) * TB * (E + 1) + 4 * TB + 2 * E + 2 * F + 4 + 4);
     if (wlds) fl += (size_t)(K2p + R * K1p) * (E + 4);
+    else fl += (size_t)kparts * TB * E;
     return sizeof(float) * fl;
 }
 
+static bool dense_wlds(int F, int E, int R) {
+    const int K1p = (2 * F + 3) & ~3;
+    const int ntile_e = E / 16, kparts = ntile_e <= DENSE_WAVES ? DENSE_WAVES / ntile_e : 1;
+    // the K-split partial tiles of `combined` live where the W_intra copies were
+    return dense_smem_bytes(F, E, R, true) <= 160 * 1024 && DENSE_THREADS % (E / 4) == 0 && (size_t)kparts * TB * E <= (size_t)R * K1p * (E + 4);
+}
+
 static unsigned long long *g_dense_stamps = nullptr;
+
+struct DenseExtra {          // the optional parts of a launch
+    const int32_t *chunk_begin = nullptr;
+    const float *partial = nullptr;
+    const int32_t *cnt = nullptr;
+    int32_t partial_stride = 0;
+    float *theta_rw = nullptr, *m = nullptr, *v = nullptr;
+    uint32_t *ticket = nullptr, *pending = nullptr;
+    AdamHyper h = {0.f, 0.f, 0.f, 0.f, 0.f};
+};
+
+static int launch_dense(const pcg_graph_desc *g, const float *theta, int32_t emb, const int32_t *ids, const int32_t *labels,
+                        int32_t B, const float *agg, int32_t agg_stride, float lambda_1, float inv_count, float *logits,
+                        float *center, float *combined, float *row_loss, float *slabs, int32_t *step_counter,
+                        const DenseExtra &x, void *stream) {
+    if (!g || !g->X || !theta || B < 0) return PCG_E_ARG;
+    if (B == 0) return PCG_OK;
+    if (!ids || !agg || !logits || !center) return PCG_E_ARG;
+    if (emb < 16 || emb % 16 != 0 || g->n_rel < 1 || g->n_rel > PCG_MAX_REL) return PCG_E_UNSUPPORTED;
+    if (slabs && !labels) return PCG_E_ARG;
+    if (x.theta_rw && (!slabs || !x.m || !x.v || !x.ticket || !step_counter)) return PCG_E_ARG;
+    if (x.chunk_begin && (!x.partial || !x.cnt)) return PCG_E_ARG;
+    const int F = g->feat_dim, E = emb, R = g->n_rel;
+    const bool wlds = dense_wlds(F, E, R);
+    const size_t smem = dense_smem_bytes(F, E, R, wlds);
+    if (smem > 160 * 1024) return PCG_E_UNSUPPORTED;
+    DenseArgs a;
+    a.X = g->X;
+    a.feat_dim = F;
+    a.feat_stride = g->feat_stride;
+    a.n_rel = R;
+    a.emb = E;
+    a.ids = ids;
+    a.labels = labels;
+    a.B = B;
+    a.agg = agg;
+    a.agg_stride = agg_stride;
+    a.chunk_begin = x.chunk_begin;
+    a.partial = x.partial;
+    a.cnt = x.cnt;
+    a.partial_stride = x.partial_stride;
+    a.W_cls = theta + off_cls(F, E, R);
+    a.W_inter = theta + off_inter(F, E, R);
+    for (int r = 0; r < PCG_MAX_REL; ++r) a.W_intra[r] = r < R ? theta + off_intra(F, E, R, r) : nullptr;
+    a.W_clf = theta + off_clf(F, E, R);
+    a.b_clf = theta + off_bias(F, E, R);
+    a.lambda_1 = lambda_1;
+    a.inv_count = inv_count;
+    a.logits = logits;
+    a.center = center;
+    a.combined = combined;
+    a.row_loss = row_loss;
+    a.slabs = slabs;
+    a.n_params = n_params_of(F, E, R);
+    a.step_counter = step_counter;
+    a.theta = x.theta_rw;
+    a.m = x.m;
+    a.v = x.v;
+    a.ticket = x.ticket;
+    a.pending = x.pending;
+    a.h = x.h;
+    // few tiles (small batches): up to 4 workgroups per tile, so that the weight-gradient tiles of a 16-row tile are not one
+    // CU's serial work while most of the chip idles
+    const int n_tiles = (B + TB - 1) / TB;
+    int n_split = slabs ? 256 / n_tiles : 1;
+    a.n_split = n_split < 1 ? 1 : (n_split > 4 ? 4 : n_split);
+    a.stamps = g_dense_stamps;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(dense_step_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(dense_step_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return PCG_E_LAUNCH;
+        attr = true;
+    }
+    const dim3 grid(n_tiles * a.n_split), block(DENSE_THREADS);
+    if (wlds) hipLaunchKernelGGL(dense_step_kernel<true>, grid, block, smem, static_cast<hipStream_t>(stream), a);
+    else hipLaunchKernelGGL(dense_step_kernel<false>, grid, block, smem, static_cast<hipStream_t>(stream), a);
+    PCG_LAUNCH_CHECK();
+    return PCG_OK;
+}
 
 }  // namespace pcg
 
@@ -447,60 +654,37 @@ int32_t pcg_dense_n_tiles(int32_t B) { return B < 0 ? PCG_E_ARG : (B + pcg::TB -
 int pcg_dense_step(const pcg_graph_desc *g, const float *theta, int32_t emb, const int32_t *ids, const int32_t *labels,
                    int32_t B, const float *agg, int32_t agg_stride, float lambda_1, float inv_count, float *logits,
                    float *center, float *combined, float *row_loss, float *slabs, int32_t *step_counter, void *stream) {
-    if (!g || !g->X || !theta || B < 0) return PCG_E_ARG;
-    if (B == 0) return PCG_OK;
-    if (!ids || !agg || !logits || !center) return PCG_E_ARG;
-    if (emb < 16 || emb % 16 != 0 || g->n_rel < 1 || g->n_rel > PCG_MAX_REL) return PCG_E_UNSUPPORTED;
-    if (slabs && !labels) return PCG_E_ARG;
-    const int F = g->feat_dim, E = emb, R = g->n_rel;
-    const bool wlds = pcg::dense_smem_bytes(F, E, R, true) <= 160 * 1024 && (pcg::DENSE_WAVES * PCG_WAVE) % (E / 4) == 0;
-    const size_t smem = pcg::dense_smem_bytes(F, E, R, wlds);
-    if (smem > 160 * 1024) return PCG_E_UNSUPPORTED;
-    pcg::DenseArgs a;
-    a.X = g->X;
-    a.feat_dim = F;
-    a.feat_stride = g->feat_stride;
-    a.n_rel = R;
-    a.emb = E;
-    a.ids = ids;
-    a.labels = labels;
-    a.B = B;
-    a.agg = agg;
-    a.agg_stride = agg_stride;
-    a.W_cls = theta + pcg::off_cls(F, E, R);
-    a.W_inter = theta + pcg::off_inter(F, E, R);
-    for (int r = 0; r < PCG_MAX_REL; ++r) a.W_intra[r] = r < R ? theta + pcg::off_intra(F, E, R, r) : nullptr;
-    a.W_clf = theta + pcg::off_clf(F, E, R);
-    a.b_clf = theta + pcg::off_bias(F, E, R);
-    a.lambda_1 = lambda_1;
-    a.inv_count = inv_count;
-    a.logits = logits;
-    a.center = center;
-    a.combined = combined;
-    a.row_loss = row_loss;
-    a.slabs = slabs;
-    a.n_params = pcg::n_params_of(F, E, R);
-    a.step_counter = step_counter;
-    // few tiles (small batches): up to 4 workgroups per tile, so that the weight-gradient tiles of a 16-row tile are not one
-    // CU's serial work while most of the chip idles
-    const int n_tiles = (B + pcg::TB - 1) / pcg::TB;
-    int n_split = slabs ? 256 / n_tiles : 1;
-    a.n_split = n_split < 1 ? 1 : (n_split > 4 ? 4 : n_split);
-    a.stamps = pcg::g_dense_stamps;
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(pcg::dense_step_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(pcg::dense_step_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return PCG_E_LAUNCH;
-        attr = true;
+    return pcg::launch_dense(g, theta, emb, ids, labels, B, agg, agg_stride, lambda_1, inv_count, logits, center, combined,
+                             row_loss, slabs, step_counter, pcg::DenseExtra(), stream);
+}
+
+int pcg_train_dense(const pcg_graph_desc *g, float *theta, float *m, float *v, int32_t emb, const int32_t *ids,
+                    const int32_t *labels, int32_t B, const float *agg, int32_t agg_stride, const int32_t *cnt,
+                    const void *workspace, int64_t list_capacity, float lambda_1, float inv_count, float *logits, float *center,
+                    float *combined, float *row_loss, float *slabs, int32_t *step_counter, uint32_t *sync_words, double lr,
+                    double beta1, double beta2, double eps, double weight_decay, int32_t adam_clf, void *stream) {
+    if (!g || B < 0) return PCG_E_ARG;
+    pcg::DenseExtra x;
+    if (workspace) {
+        if (!cnt || list_capacity < 1) return PCG_E_ARG;
+        pcg::Workspace w;
+        pcg::carve(g, B, list_capacity, static_cast<unsigned char *>(const_cast<void *>(workspace)), &w);
+        x.chunk_begin = w.chunk_begin;
+        x.partial = w.partial;
+        x.cnt = cnt;
+        x.partial_stride = g->feat_stride;
     }
-    const dim3 grid(n_tiles * a.n_split), block(pcg::DENSE_WAVES * PCG_WAVE);
-    if (wlds) hipLaunchKernelGGL(pcg::dense_step_kernel<true>, grid, block, smem, static_cast<hipStream_t>(stream), a);
-    else hipLaunchKernelGGL(pcg::dense_step_kernel<false>, grid, block, smem, static_cast<hipStream_t>(stream), a);
-    PCG_LAUNCH_CHECK();
-    return PCG_OK;
+    if (adam_clf) {
+        if (!slabs || !m || !v || !sync_words) return PCG_E_ARG;
+        x.theta_rw = theta;
+        x.m = m;
+        x.v = v;
+        x.ticket = sync_words;
+        x.pending = sync_words + 1;
+        x.h = {(float)lr, (float)beta1, (float)beta2, (float)eps, (float)weight_decay};
+    }
+    return pcg::launch_dense(g, theta, emb, ids, labels, B, agg, agg_stride, lambda_1, inv_count, logits, center, combined,
+                             row_loss, slabs, step_counter, x, stream);
 }
 
 int pcg_adam_step(float *theta, float *m, float *v, const float *slabs, int32_t n_slabs, int64_t n_params,
@@ -509,9 +693,29 @@ int pcg_adam_step(float *theta, float *m, float *v, const float *slabs, int32_t 
     if (!slabs || n_slabs < 0 || n_params < 1) return PCG_E_ARG;
     if (apply && (!theta || !m || !v || !step_counter)) return PCG_E_ARG;
     if (!apply && !grad_out) return PCG_E_ARG;
+    const pcg::AdamHyper h = {(float)lr, (float)beta1, (float)beta2, (float)eps, (float)weight_decay};
     hipLaunchKernelGGL(pcg::adam_reduce_kernel, dim3((unsigned)((n_params + PCG_WAVE - 1) / PCG_WAVE)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), theta, m, v, slabs, n_slabs, n_params, step_counter, (float)lr,
-                       (float)beta1, (float)beta2, (float)eps, (float)weight_decay, grad_out, apply);
+                       static_cast<hipStream_t>(stream), theta, m, v, slabs, n_slabs, n_params, (int64_t)0, n_params,
+                       step_counter, h, grad_out, apply, (const uint32_t *)nullptr);
+    PCG_LAUNCH_CHECK();
+    return PCG_OK;
+}
+
+int pcg_adam_flush(float *theta, float *m, float *v, const float *slabs, int32_t n_slabs, int64_t n_params, int64_t p_end,
+                   const int32_t *step_counter, uint32_t *sync_words, double lr, double beta1, double beta2, double eps,
+                   double weight_decay, void *stream) {
+    if (!theta || !m || !v || !slabs || !step_counter || !sync_words || n_slabs < 0 || n_params < 1 || p_end < 0 ||
+        p_end > n_params)
+        return PCG_E_ARG;
+    const pcg::AdamHyper h = {(float)lr, (float)beta1, (float)beta2, (float)eps, (float)weight_decay};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (p_end > 0) {
+        hipLaunchKernelGGL(pcg::adam_reduce_kernel, dim3((unsigned)((p_end + PCG_WAVE - 1) / PCG_WAVE)), dim3(256), 0, st, theta, m,
+                           v, slabs, n_slabs, n_params, (int64_t)0, p_end, step_counter, h, (float *)nullptr, 1,
+                           (const uint32_t *)(sync_words + 1));
+        PCG_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(pcg::clear_word_kernel, dim3(1), dim3(1), 0, st, sync_words + 1);
     PCG_LAUNCH_CHECK();
     return PCG_OK;
 }

@@ -175,11 +175,13 @@ __global__ void __launch_bounds__(256) combine_rows(const AggArgs a) {
 }
 
 template <int NACC>
-static int launch_aggregate(const AggArgs &g, hipStream_t st) {
+static int launch_aggregate(const AggArgs &g, hipStream_t st, bool combine) {
     hipLaunchKernelGGL(gather_chunks<NACC>, dim3(GATHER_BLOCKS), dim3(256), 0, st, g);
     PCG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(combine_rows<NACC>, dim3((g.n_rows + 3) / 4), dim3(256), 0, st, g);
-    PCG_LAUNCH_CHECK();
+    if (combine) {
+        hipLaunchKernelGGL(combine_rows<NACC>, dim3((g.n_rows + 3) / 4), dim3(256), 0, st, g);
+        PCG_LAUNCH_CHECK();
+    }
     return PCG_OK;
 }
 
@@ -187,9 +189,9 @@ static int launch_aggregate(const AggArgs &g, hipStream_t st) {
 
 extern "C" {
 
-int pcg_aggregate_lists(const float *X, int32_t feat_dim, int32_t feat_stride, int32_t n_rows, const int32_t *cnt,
-                        const pcg_graph_desc *g, int32_t B, void *workspace, int64_t list_capacity, int32_t norm,
-                        float *agg, int32_t agg_stride, void *stream) {
+static int aggregate(const float *X, int32_t feat_dim, int32_t feat_stride, int32_t n_rows, const int32_t *cnt,
+                     const pcg_graph_desc *g, int32_t B, void *workspace, int64_t list_capacity, int32_t norm,
+                     float *agg, int32_t agg_stride, bool combine, void *stream) {
     if (!X || !cnt || !g || !workspace || !agg || n_rows < 0 || B < 0) return PCG_E_ARG;
     if (n_rows == 0) return PCG_OK;
     if (feat_stride % 4 != 0 || feat_stride < feat_dim || agg_stride < feat_dim) return PCG_E_ARG;
@@ -215,7 +217,22 @@ int pcg_aggregate_lists(const float *X, int32_t feat_dim, int32_t feat_stride, i
     a.agg_stride = agg_stride;
     a.norm = norm;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    return feat_stride <= 256 ? pcg::launch_aggregate<1>(a, st) : pcg::launch_aggregate<2>(a, st);
+    return feat_stride <= 256 ? pcg::launch_aggregate<1>(a, st, combine) : pcg::launch_aggregate<2>(a, st, combine);
+}
+
+int pcg_aggregate_lists(const float *X, int32_t feat_dim, int32_t feat_stride, int32_t n_rows, const int32_t *cnt,
+                        const pcg_graph_desc *g, int32_t B, void *workspace, int64_t list_capacity, int32_t norm,
+                        float *agg, int32_t agg_stride, void *stream) {
+    return aggregate(X, feat_dim, feat_stride, n_rows, cnt, g, B, workspace, list_capacity, norm, agg, agg_stride, true, stream);
+}
+
+/* gather only: rows of one chunk are finished (mean in agg), rows of several are left as per-chunk partial sums in the
+ * workspace for pcg_train_dense to add up while it stages its tile (no combine launch) */
+int pcg_gather_lists(const float *X, int32_t feat_dim, int32_t feat_stride, int32_t n_rows, const int32_t *cnt,
+                     const pcg_graph_desc *g, int32_t B, void *workspace, int64_t list_capacity, float *agg, int32_t agg_stride,
+                     void *stream) {
+    return aggregate(X, feat_dim, feat_stride, n_rows, cnt, g, B, workspace, list_capacity, PCG_NORM_COUNT, agg, agg_stride, false,
+                     stream);
 }
 
 }  // extern "C"

@@ -1,10 +1,15 @@
 """Whole-step driver: every launch of one PC-GNN train step, back to back on one
-stream, no torch ops and no host synchronisation in between:
+stream, no torch ops and no host synchronisation in between - five launches:
 
-    score_table -> pos_sort -> choose_aggregate -> dense_step -> adam_step
+    front_a [scores || plan 1 || train-pos keys || Adam of the previous step's gradient (all but the label classifier)]
+    front_b [train-pos sort || plan 2]
+    select_rows -> gather_chunks
+    dense_step [sums of multi-chunk rows, forward, loss, backward partials, Adam of the label classifier]
 
-and the same sequence captured once per batch size into a hipGraph
-(``torch.cuda.CUDAGraph``) so that a step costs one graph launch on the host.
+(``pcg_step_front_train`` / ``pcg_choose_gather_planned`` / ``pcg_train_dense``); a deferred update is flushed
+(``pcg_adam_flush``) before any public call returns unless the caller asks otherwise, so the parameters a caller
+sees are always complete.  The same sequence is captured into hipGraphs (``torch.cuda.CUDAGraph``) - per batch, or a
+whole epoch in one - so that a step costs no host work at all.
 
 The model's parameters are re-pointed into ONE flat f32 buffer (order: see
 ``pcg_dense_step`` in include/pcgnn.h); the ``nn.Parameter`` objects, their names
@@ -63,6 +68,8 @@ class FusedPCGNN:
         self.v = torch.zeros_like(self.theta)
         self.step_counter = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self.grad = torch.zeros_like(self.theta)
+        self.sync = torch.zeros(4, dtype=torch.int32, device=self.dev)    # [ticket, update pending, its slab count, -]
+        self.n_rest = int(lib.pcg_dense_param_offset(self.F, self.E, self.R, 3, 0))   # parameters before the label classifier
 
         self.list_capacity = list_capacity      # entries of every workspace's selection list (None: worst case of the graph)
         self.status = torch.zeros(1, dtype=torch.int32, device=self.dev)   # ONE device status word for all workspaces
@@ -115,7 +122,19 @@ class FusedPCGNN:
         return ops.step_front(g, self.w_clf, self.b_clf, self.s0, self.keys if (train_flag and g.n_pos) else None,
                               ids, labels if train_flag else None, self.thresholds, self.rho, train_flag, self._ws(B))
 
-    def _enqueue_choose(self, ids, labels, B, keys, train_flag, planned=False):
+    def _enqueue_front_train(self, ids, labels, B):
+        """the front of a training step with the previous step's deferred Adam update beside the score pass."""
+        g, ws = self.g, self._ws(B)
+        thr, rhos = ops._host_arrays(g, self.thresholds, self.rho)
+        b1, b2 = self.betas
+        _lib.check(self.lib.pcg_step_front_train(
+            g.desc_ref(), _p(self.theta), _p(self.m), _p(self.v), self.E, _p(self.s0), _p(self.keys) if g.n_pos else None,
+            _p(ids), _p(labels), B, thr, rhos, 0, _p(ws.buf), ws.list_capacity, _p(ws.status), _p(self.slabs),
+            _p(self.step_counter), _p(self.sync), self.lr, b1, b2, self.eps, self.wd, self._stream()), "pcg_step_front_train")
+        return self.keys if g.n_pos else None
+
+    def _enqueue_choose(self, ids, labels, B, keys, train_flag, planned=False, combine=True):
+        """select + gather (+ combine unless the dense kernel will add up the partial sums itself)."""
         g = self.g
         agg = self.agg.view(-1)[:g.R * B * g.feat_dim].view(g.R, B, g.feat_dim)
         cnt = self.cnt.view(-1)[:g.R * B].view(g.R, B)
@@ -123,8 +142,17 @@ class FusedPCGNN:
         if timed:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        ops.choose_aggregate(g, ids, labels if train_flag else None, self.s0, keys, self.thresholds, self.rho,
-                             train_flag, ws=self._ws(B), agg=agg, cnt=cnt, planned=planned)
+        if combine:
+            ops.choose_aggregate(g, ids, labels if train_flag else None, self.s0, keys, self.thresholds, self.rho,
+                                 train_flag, ws=self._ws(B), agg=agg, cnt=cnt, planned=planned)
+        else:
+            assert planned
+            ws = self._ws(B)
+            thr, rhos = ops._host_arrays(g, self.thresholds, self.rho)
+            _lib.check(self.lib.pcg_choose_gather_planned(
+                g.desc_ref(), _p(ids), _p(labels if train_flag else None), B, _p(self.s0), None, _p(keys), thr, rhos,
+                1 if train_flag else 0, 0, _p(agg), agg.stride(-2), _p(cnt), _p(ws.buf), ws.list_capacity, _p(ws.status),
+                self._stream()), "pcg_choose_gather_planned")
         if timed:
             ev[1].record()
             self._prof.append(ev)
@@ -144,6 +172,34 @@ class FusedPCGNN:
             _p(self.row_loss) if labels is not None else None, _p(self.slabs) if train else None,
             _p(self.step_counter) if train else None, self._stream()), "pcg_dense_step")
 
+    def _enqueue_tail(self, ids, labels, B, agg, train: bool, combined=None):
+        """dense tail reading the gather's partial sums (no combine launch); training: + the label classifier's Adam
+        in the same launch, the update of the other parameters left pending (flush() or the next front applies it)."""
+        g, ws = self.g, self._ws(B)
+        cnt = self.cnt.view(-1)[:g.R * B]
+        b1, b2 = self.betas
+        _lib.check(self.lib.pcg_train_dense(
+            g.desc_ref(), _p(self.theta), _p(self.m), _p(self.v), self.E, _p(ids), _p(labels), B, _p(agg), agg.stride(1),
+            _p(cnt), _p(ws.buf), ws.list_capacity, self.lambda_1, 1.0 / (B * self.scale), _p(self.logits), _p(self.center),
+            _p(combined), _p(self.row_loss) if labels is not None else None, _p(self.slabs) if train else None,
+            _p(self.step_counter) if train else None, _p(self.sync), self.lr, b1, b2, self.eps, self.wd, 1 if train else 0,
+            self._stream()), "pcg_train_dense")
+
+    def flush(self):
+        """Apply a deferred Adam update now (no-op on the device if none is pending).  Enqueued, not synchronised."""
+        b1, b2 = self.betas
+        _lib.check(self.lib.pcg_adam_flush(
+            _p(self.theta), _p(self.m), _p(self.v), _p(self.slabs), 0, self.n_params, self.n_rest, _p(self.step_counter),
+            _p(self.sync), self.lr, b1, b2, self.eps, self.wd, self._stream()), "pcg_adam_flush")
+
+    def _enqueue_step(self, ids, labels, B, defer: bool):
+        """the five launches of one training step (+ the flush unless deferred)."""
+        keys = self._enqueue_front_train(ids, labels, B)
+        agg, _ = self._enqueue_choose(ids, labels, B, keys, True, planned=True, combine=False)
+        self._enqueue_tail(ids, labels, B, agg, True)
+        if not defer:
+            self.flush()
+
     def _enqueue_adam(self, B, apply=True, want_grad=False, from_grad=False):
         """from_grad: the (all-reduced) flat gradient in self.grad is the single slab."""
         b1, b2 = self.betas
@@ -154,25 +210,29 @@ class FusedPCGNN:
             1 if apply else 0, self._stream()), "pcg_adam_step")
 
     # ------------------------------------------------------------------
-    def train_step(self, ids: torch.Tensor, labels: torch.Tensor, allreduce=None):
+    def train_step(self, ids: torch.Tensor, labels: torch.Tensor, allreduce=None, defer: bool = False):
         """zero_grad + loss + backward + Adam step for one batch (model_handler.py:149-153).
         ids / labels: int32 device tensors.  Nothing is returned and nothing syncs;
         ``last_loss()`` reads the batch loss afterwards.  ``allreduce(flat_grad)`` (data-parallel
-        ranks) is called between the gradient reduction and the Adam update."""
+        ranks) is called between the gradient reduction and the Adam update.  ``defer``: leave the Adam update of
+        everything but the label classifier to the next step's front (or ``flush()``) - inside an epoch."""
         B = ids.numel()
         if B == 0:
             return
         if B > self.maxB:
+            self.flush()
             self._alloc(B)
         self._lastB = B
+        if allreduce is None:
+            self._enqueue_step(ids, labels, B, defer)
+            return
+        # data-parallel ranks: gradient of the local batch -> all-reduce -> the same Adam on every rank
+        self.flush()
         agg, _ = self._enqueue_sample(ids, labels, B, True)
         self._enqueue_dense(ids, labels, B, agg, True)
-        if allreduce is None:
-            self._enqueue_adam(B, apply=True)
-        else:
-            self._enqueue_adam(B, apply=False, want_grad=True)
-            allreduce(self.grad)
-            self._enqueue_adam(B, apply=True, from_grad=True)
+        self._enqueue_adam(B, apply=False, want_grad=True)
+        allreduce(self.grad)
+        self._enqueue_adam(B, apply=True, from_grad=True)
 
     def train_step_graph(self, ids: torch.Tensor, labels: torch.Tensor, timed: bool = False):
         """Same as train_step through captured hipGraphs (one set per batch size): one graph launch
@@ -182,6 +242,7 @@ class FusedPCGNN:
         if B == 0:
             return
         if B > self.maxB:
+            self.flush()
             self._alloc(B)
         self._lastB = B
         gr = self._graphs.get(B)
@@ -201,6 +262,31 @@ class FusedPCGNN:
         else:
             gr["full"].replay()
 
+    def _capture_graphs(self, fns, warm=None):
+        """Warm up (kernel attributes, per-batch-size workspaces: nothing may allocate inside a capture) on a side
+        stream, capture every fn into a hipGraph of its own, and put the optimizer state back.  A deferred Adam update
+        of real steps is applied first (the saved state then includes it); the warm-up's own is flushed and undone."""
+        self.flush()
+        state = (self.theta.clone(), self.m.clone(), self.v.clone(), self.step_counter.clone())
+        prof, self._prof = self._prof, None
+        s = torch.cuda.Stream(self.dev)
+        s.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(s):
+            for fn in (warm if warm is not None else fns):
+                fn()
+            self.flush()
+        torch.cuda.current_stream(self.dev).wait_stream(s)
+        graphs = []
+        for fn in fns:
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                fn()
+            graphs.append(gr)
+        for dst, src in zip((self.theta, self.m, self.v, self.step_counter), state):
+            dst.copy_(src)
+        self._prof = prof
+        return graphs
+
     def _capture(self, B):
         ids, lab = self.ids_buf[:B], self.lab_buf[:B]
         keys = self.keys if self.g.n_pos else None
@@ -208,37 +294,22 @@ class FusedPCGNN:
         agg = self.agg.view(-1)[:g.R * B * g.feat_dim].view(g.R, B, g.feat_dim)
 
         def pre():
-            self._enqueue_front(ids, lab, B, True)
+            self._enqueue_front_train(ids, lab, B)
 
         def post():
-            self._enqueue_dense(ids, lab, B, agg, True)
-            self._enqueue_adam(B, apply=True)
+            self._enqueue_tail(ids, lab, B, agg, True)
+            self.flush()
 
         def choose():
-            self._enqueue_choose(ids, lab, B, keys, True, planned=True)
+            self._enqueue_choose(ids, lab, B, keys, True, planned=True, combine=False)
 
         def full():
             pre()
             choose()
             post()
 
-        # warm up on a side stream (sets kernel attributes) and put the optimizer state back afterwards
-        state = (self.theta.clone(), self.m.clone(), self.v.clone(), self.step_counter.clone())
-        prof, self._prof = self._prof, None
-        s = torch.cuda.Stream(self.dev)
-        s.wait_stream(torch.cuda.current_stream(self.dev))
-        with torch.cuda.stream(s):
-            full()
-        torch.cuda.current_stream(self.dev).wait_stream(s)
-        graphs = {}
-        for name, fn in (("full", full), ("pre", pre), ("choose", choose), ("post", post)):
-            gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr):
-                fn()
-            graphs[name] = gr
-        for dst, src in zip((self.theta, self.m, self.v, self.step_counter), state):
-            dst.copy_(src)
-        self._prof = prof
+        names = ("full", "pre", "choose", "post")
+        graphs = dict(zip(names, self._capture_graphs([full, pre, choose, post], warm=[full])))
         self._graphs[B] = graphs
         return graphs
 
@@ -261,19 +332,7 @@ class FusedPCGNN:
         gr = self._ep_graphs.get(key)
         if gr is None:
             ids, lab = self._ep_ids[lo:lo + B], self._ep_lab[lo:lo + B]
-            state = (self.theta.clone(), self.m.clone(), self.v.clone(), self.step_counter.clone())
-            prof, self._prof = self._prof, None
-            s = torch.cuda.Stream(self.dev)
-            s.wait_stream(torch.cuda.current_stream(self.dev))
-            with torch.cuda.stream(s):
-                self.train_step(ids, lab)
-            torch.cuda.current_stream(self.dev).wait_stream(s)
-            gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr):
-                self.train_step(ids, lab)
-            for dst, src in zip((self.theta, self.m, self.v, self.step_counter), state):
-                dst.copy_(src)
-            self._prof = prof
+            gr = self._capture_graphs([lambda: self.train_step(ids, lab)])[0]
             self._ep_graphs[key] = gr
         gr.replay()
 
@@ -293,26 +352,11 @@ class FusedPCGNN:
         if grs is None:
             agg = self.agg.view(-1)[:g.R * B * g.feat_dim].view(g.R, B, g.feat_dim)
             keys = self.keys if g.n_pos else None
-            parts = (lambda: self._enqueue_front(ids, lab, B, True),
-                     lambda: self._enqueue_choose(ids, lab, B, keys, True, planned=True),
-                     lambda: (self._enqueue_dense(ids, lab, B, agg, True), self._enqueue_adam(B, apply=True)))
-            state = (self.theta.clone(), self.m.clone(), self.v.clone(), self.step_counter.clone())
-            prof, self._prof = self._prof, None
-            s = torch.cuda.Stream(self.dev)
-            s.wait_stream(torch.cuda.current_stream(self.dev))
-            with torch.cuda.stream(s):
-                for fn in parts:
-                    fn()
-            torch.cuda.current_stream(self.dev).wait_stream(s)
-            grs = []
-            for fn in parts:
-                gr = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gr):
-                    fn()
-                grs.append(gr)
-            for dst, src in zip((self.theta, self.m, self.v, self.step_counter), state):
-                dst.copy_(src)
-            self._prof = prof
+            last = lo + B >= self._ep_n           # the epoch's last batch: nothing follows that would apply the deferred update
+            parts = (lambda: self._enqueue_front_train(ids, lab, B),
+                     lambda: self._enqueue_choose(ids, lab, B, keys, True, planned=True, combine=False),
+                     lambda: (self._enqueue_tail(ids, lab, B, agg, True), self.flush() if last else None))
+            grs = self._capture_graphs(list(parts))
             self._ep_graphs[key] = grs
         grs[0].replay()
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -346,22 +390,13 @@ class FusedPCGNN:
                 for b in range(n_steps):
                     lo = b * self._ep_bs
                     B = min(self._ep_bs, self._ep_n - lo)
-                    self.train_step(self._ep_ids[lo:lo + B], self._ep_lab[lo:lo + B])
-            state = (self.theta.clone(), self.m.clone(), self.v.clone(), self.step_counter.clone())
-            prof, self._prof = self._prof, None
-            s = torch.cuda.Stream(self.dev)
-            s.wait_stream(torch.cuda.current_stream(self.dev))
-            with torch.cuda.stream(s):
-                run()                      # (sets kernel attributes, allocates the per-batch-size workspaces)
-            torch.cuda.current_stream(self.dev).wait_stream(s)
-            gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr):
+                    self.train_step(self._ep_ids[lo:lo + B], self._ep_lab[lo:lo + B], defer=True)
+                self.flush()
+            def sampled_run():
                 if sample is not None:
                     sample()
                 run()
-            for dst, src in zip((self.theta, self.m, self.v, self.step_counter), state):
-                dst.copy_(src)
-            self._prof = prof
+            gr = self._capture_graphs([sampled_run], warm=[run])[0]   # (the warm-up leaves the staged ids as they are)
             self._ep_graphs[key] = gr
         self._lastB = min(self._ep_bs, self._ep_n - (n_steps - 1) * self._ep_bs)
         gr.replay()
@@ -385,6 +420,7 @@ class FusedPCGNN:
     def gradients(self, ids: torch.Tensor, labels: torch.Tensor) -> Dict[str, torch.Tensor]:
         """loss.backward() without the optimizer step: per-parameter gradients (parity tests)."""
         B = ids.numel()
+        self.flush()
         agg, _ = self._enqueue_sample(ids, labels, B, True)
         self._enqueue_dense(ids, labels, B, agg, True)
         self.step_counter -= 1                   # dense_step counted a step that is not taken
@@ -401,10 +437,12 @@ class FusedPCGNN:
         """forward only -> (gnn logits [B,2], label-aware logits [B,2][, combined [B,E]])
         (PCALayer.forward, model.py:34-39; utils.py:305 calls it with train_flag=False)."""
         B = ids.numel()
+        self.flush()
         if B > self.maxB:
             self._alloc(B)
-        agg, _ = self._enqueue_sample(ids, labels, B, train_flag)
+        keys = self._enqueue_front(ids, labels, B, train_flag)
+        agg, _ = self._enqueue_choose(ids, labels, B, keys, train_flag, planned=True, combine=False)
         comb = torch.empty(B, self.E, dtype=torch.float32, device=self.dev) if want_combined else None
-        self._enqueue_dense(ids, None, B, agg, False, combined=comb)
+        self._enqueue_tail(ids, None, B, agg, False, combined=comb)
         res = (self.logits[:B].clone(), self.center[:B].clone())
         return res + (comb,) if want_combined else res
