@@ -77,32 +77,60 @@ __host__ __device__ inline int64_t off_clf(int F, int E, int R) { return off_int
 __host__ __device__ inline int64_t off_bias(int F, int E, int R) { return off_clf(F, E, R) + 2 * (int64_t)F; }
 __host__ __device__ inline int64_t n_params_of(int F, int E, int R) { return off_bias(F, E, R) + 2; }
 
+// One accumulator chain of n_steps v_mfma_f32_16x16x4_f32 (n_steps a multiple of MU: every K dimension is padded with
+// zeros to a multiple of 4 * MU), software-pipelined by hand: the operands of the next MU steps are requested before the
+// MFMAs of the current MU steps issue (two register sets), so that a wave's LDS reads overlap its own matrix work.
+// (hipcc does not unroll these chains by itself; one step at a time every MFMA waits for its own two operand reads.  The
+// fetched values go into the MFMAs untouched - any arithmetic on them would be scheduled, with its wait, ahead of the
+// MFMAs and undo the prefetch.)  fa(s) / fb(s): this lane's A / B operand of step s.
+constexpr int MU = 4;
+constexpr int KPAD = 4 * MU;
+template <class FA, class FB>
+__device__ __forceinline__ void mfma_fetch(float (&av)[MU], float (&bv)[MU], int s, FA &fa, FB &fb) {
+#pragma unroll
+    for (int u = 0; u < MU; ++u) {
+        av[u] = fa(s + u);
+        bv[u] = fb(s + u);
+    }
+}
+template <class FA, class FB>
+__device__ __forceinline__ f32x4 mfma_chain(int n_steps, FA fa, FB fb) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float a0[MU], b0[MU], a1[MU], b1[MU];
+    if (n_steps <= 0) return acc;
+    mfma_fetch(a0, b0, 0, fa, fb);
+    for (int s = 0; s < n_steps; s += 2 * MU) {
+        if (s + MU < n_steps) mfma_fetch(a1, b1, s + MU, fa, fb);          // (wave-uniform)
+#pragma unroll
+        for (int u = 0; u < MU; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u], b0[u], acc, 0, 0, 0);
+        if (s + MU >= n_steps) break;
+        if (s + 2 * MU < n_steps) mfma_fetch(a0, b0, s + 2 * MU, fa, fb);
+#pragma unroll
+        for (int u = 0; u < MU; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u], b1[u], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
 // C[16x16] += A[16 x k-steps] (LDS, row-major, leading dim lda) * B (global, ld ldb, column n0..n0+15), k in [k_lo, k_hi)
 __device__ __forceinline__ f32x4 tile_lds_glob(const float *A, int lda, const float *__restrict__ Bg, int ldb, int n0,
                                                int K, int k_lo, int k_hi, int lane) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const int r = lane & 15, kq = lane >> 4;
-#pragma unroll 4
-    for (int k0 = k_lo; k0 < k_hi; k0 += 4) {
-        const int k = k0 + kq;
-        const float a = A[r * lda + k];
-        const float b = (k < K) ? Bg[(size_t)k * ldb + n0 + r] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
-    }
-    return acc;
+    const float *ap = A + r * lda + k_lo + kq;
+    // rows k >= K of B do not exist: A's pad columns are zero, so any finite value will do there - the last row's
+    return mfma_chain((k_hi - k_lo) >> 2, [&](int s) { return ap[4 * s]; },
+                      [&](int s) {
+                          const int k = k_lo + 4 * s + kq;
+                          return Bg[(size_t)(k < K ? k : K - 1) * ldb + n0 + r];
+                      });
 }
 
 // the same with B an LDS copy of the weight matrix (leading dim ldb; rows beyond K are zero)
 __device__ __forceinline__ f32x4 tile_lds_lds(const float *A, int lda, const float *Bl, int ldb, int n0, int k_lo, int k_hi,
                                               int lane) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const int r = lane & 15, kq = lane >> 4;
-#pragma unroll 8
-    for (int k0 = k_lo; k0 < k_hi; k0 += 4) {
-        const int k = k0 + kq;
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[r * lda + k], Bl[k * ldb + n0 + r], acc, 0, 0, 0);
-    }
-    return acc;
+    const float *ap = A + r * lda + k_lo + kq;
+    const float *bp = Bl + (k_lo + kq) * ldb + n0 + r;
+    return mfma_chain((k_hi - k_lo) >> 2, [&](int s) { return ap[4 * s]; }, [&](int s) { return bp[4 * s * ldb]; });
 }
 
 // C[16x16] = At^T * Bt with both operands row tiles in LDS: C[m][n] = sum_t At[t][m0+m] * Bt[t][n0+n], t < 16
@@ -111,24 +139,33 @@ __device__ __forceinline__ f32x4 tile_ldsT_lds(const float *At, int lda, int m0,
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const int r = lane & 15, kq = lane >> 4;
     const bool mok = m0 + r < M;
+    const int mr = mok ? m0 + r : M - 1;
+    float av[TB / 4], bv[TB / 4];
 #pragma unroll
-    for (int t0 = 0; t0 < TB; t0 += 4) {
-        const int t = t0 + kq;
-        const float a = mok ? At[t * lda + m0 + r] : 0.f;
-        const float b = Bt[t * ldb + n0 + r];
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    for (int j = 0; j < TB / 4; ++j) {
+        const int t = 4 * j + kq;
+        const float x = At[t * lda + mr];
+        av[j] = mok ? x : 0.f;
+        bv[j] = Bt[t * ldb + n0 + r];
     }
+#pragma unroll
+    for (int j = 0; j < TB / 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc, 0, 0, 0);
     return acc;
 }
 
+// two-class cross entropy and its gradient from the logit difference: one v_exp_f32, one v_log_f32, one v_rcp_f32
+// (this runs on a single lane per row, on the critical path between forward and backward: the library expf / logf /
+// division sequences are hundreds of dependent instructions there).  Absolute error ~1e-7: far inside the 1e-4 / 2e-5
+// the parity tests allow for logits / gradients.
 __device__ __forceinline__ void xent2(float a, float b, int y, float &loss, float &da, float &db) {
-    const float mx = fmaxf(a, b);
-    const float ea = expf(a - mx), eb = expf(b - mx);
-    const float s = ea + eb;
-    const float lse = mx + logf(s);
-    loss = lse - (y == 1 ? b : a);
-    da = ea / s - (y == 0 ? 1.f : 0.f);
-    db = eb / s - (y == 1 ? 1.f : 0.f);
+    const float d = b - a;
+    const float e = __expf(-fabsf(d));                   // in (0, 1]
+    const float inv = __frcp_rn(1.f + e);
+    const float p_hi = inv, p_lo = e * inv;              // softmax of the larger / the smaller logit
+    const float pa = d > 0.f ? p_lo : p_hi, pb = d > 0.f ? p_hi : p_lo;
+    loss = fmaxf(a, b) + __logf(1.f + e) - (y == 1 ? b : a);
+    da = pa - (y == 0 ? 1.f : 0.f);
+    db = pb - (y == 1 ? 1.f : 0.f);
 }
 
 // sum over the 16 lanes of a DPP row (every lane gets it): quad permutes, then the half-row / row mirrors
@@ -144,11 +181,15 @@ __device__ __forceinline__ float row16_sum(float p) {
 // is an LDS read; otherwise the B operands stream from global memory / L2.
 // Phases (one barrier between them): stage -> h_r for all relations -> combined (K split over the waves) -> logits + loss
 // grads -> dcomb + small dW -> {dh_r for all r, dW_inter} -> dW_r for all r.
-template <bool WLDS>
+// F_, E_, R_ > 0: the shape is a compile-time constant (the datasets' shapes are instantiated below): every LDS offset is
+// then an immediate and the index arithmetic folds away - with run-time shapes the kernel issues ~1400 vector and ~750
+// scalar instructions per wave, most of them address arithmetic, and that issue time (not the matrix cores, 14 % busy,
+// nor the LDS, 20 % busy) is what it is bound by.  0: run-time shape (any F, E % 16 == 0, R <= 8).
+template <bool WLDS, int F_, int E_, int R_>
 __global__ void __launch_bounds__(DENSE_THREADS) dense_step_kernel(const DenseArgs a) {
     extern __shared__ __align__(16) float sm[];
-    const int F = a.feat_dim, E = a.emb, R = a.n_rel;
-    const int K1 = 2 * F, K1p = (K1 + 3) & ~3, K2 = F + R * E, K2p = (K2 + 3) & ~3;
+    const int F = F_ > 0 ? F_ : a.feat_dim, E = E_ > 0 ? E_ : a.emb, R = R_ > 0 ? R_ : a.n_rel;
+    const int K1 = 2 * F, K1p = (K1 + KPAD - 1) / KPAD * KPAD, K2 = F + R * E, K2p = (K2 + KPAD - 1) / KPAD * KPAD;
     const int ld1 = K1p + 1, ld2 = K2p + 1, ldE = E + 1, ldW = E + 4;   // ldW: rows stay 16-B aligned (ds_write_b128)
     const int ntile_e = E / 16;
     const int kparts = ntile_e <= DENSE_WAVES ? DENSE_WAVES / ntile_e : 1;      // waves sharing one output tile of `combined`
@@ -177,58 +218,67 @@ __global__ void __launch_bounds__(DENSE_THREADS) dense_step_kernel(const DenseAr
             a.pending[1] = (unsigned)(gridDim.x / S);           // ... in this many slabs
         }
     }
+    // wave t's row of the loss phase: its label is requested now, not when the logits are ready
+    const int my_b = row0 + wave;
+    const int my_label = (a.labels && my_b < a.B) ? a.labels[my_b] : 0;
     DENSE_STAMP(0);
+    if (a.stamps && threadIdx.x == 0 && sp == 0) a.stamps[(size_t)tile_id * 16 + 12] = clock64();     // shader cycles (diagnostic)
 
     // ---- stage ----------------------------------------------------------------------------------------------------
     // every global load of the prologue is requested before the first LDS store: weights (<= WSTAGE float4 per thread in
     // flight), the tile's self rows (ids -> rows), its aggregated rows (or their partial sums)
     {
-        // self rows and aggregates: element e of [TB][F] (self) and [R][TB][F] (agg), one or two per thread
+        // self rows and aggregates: element e of [TB][F] (self) and [R][TB][F] (agg), one or two per thread.  Every load is
+        // unconditional (indices clamped, the value discarded afterwards): a load inside a branch makes the compiler wait
+        // for it at the branch's end, which turns the prologue into a chain of L2 round trips
         const int n_self = TB * F, n_agg = R * TB * F;
-        float v_self = 0.f;
-        int self_t = 0, self_f = 0;
         const bool do_self = tid < n_self;                                 // (TB * F <= 1024 for F <= 64; a loop covers the rest)
-        if (do_self) {
-            self_t = tid / F;
-            self_f = tid - self_t * F;
-            const int b = row0 + self_t;
-            if (b < a.B) v_self = a.X[(size_t)a.ids[b] * a.feat_stride + self_f];
-        }
+        const int self_i = do_self ? tid : n_self - 1;
+        const int self_t = self_i / F, self_f = self_i - self_t * F;
+        const int self_b = row0 + self_t;
+        const int self_id = a.ids[self_b < a.B ? self_b : a.B - 1];
         constexpr int NAGG = 2;
         float v_agg[NAGG];
-        int agg_at[NAGG];
+        int agg_at[NAGG], agg_nch[NAGG], agg_cb[NAGG];
+        size_t agg_row[NAGG];
+        int agg_f[NAGG];
+        bool agg_ok[NAGG];
 #pragma unroll
         for (int u = 0; u < NAGG; ++u) {
-            const int i = tid + u * DENSE_THREADS;
-            v_agg[u] = 0.f;
-            agg_at[u] = -1;
-            if (i < n_agg) {
-                const int r = i / (TB * F), j = i - r * TB * F, t = j / F, f = j - t * F;
-                const int b = row0 + t;
-                agg_at[u] = (r * TB + t) * ld1 + F + f;
-                if (b < a.B) {
-                    const size_t row = (size_t)r * a.B + b;
-                    int cb = 0, nch = 1;
-                    if (a.chunk_begin) {
-                        cb = a.chunk_begin[row];
-                        nch = a.chunk_begin[row + 1] - cb;
-                    }
-                    if (nch == 0) v_agg[u] = 0.f / 0.f;      // empty set: 0 / 0 like the reference's mask.div (layers.py:612-614)
-                    else if (nch > 1) {     // sum of the gather's partial sums, in chunk order, / |set|  (== combine_rows)
-                        float acc = 0.f;
-                        const float *pp = a.partial + (size_t)cb * a.partial_stride + f;
-                        int jx = 0;
-                        for (; jx + 4 <= nch; jx += 4) {
-                            const float p0 = pp[(size_t)(jx + 0) * a.partial_stride], p1 = pp[(size_t)(jx + 1) * a.partial_stride];
-                            const float p2 = pp[(size_t)(jx + 2) * a.partial_stride], p3 = pp[(size_t)(jx + 3) * a.partial_stride];
-                            acc += p0; acc += p1; acc += p2; acc += p3;
-                        }
-                        for (; jx < nch; ++jx) acc += pp[(size_t)jx * a.partial_stride];
-                        v_agg[u] = acc / (float)a.cnt[row];
-                    } else {
-                        v_agg[u] = a.agg[row * a.agg_stride + f];
-                    }
+            const int i0 = tid + u * DENSE_THREADS;
+            const int i = i0 < n_agg ? i0 : n_agg - 1;
+            const int r = i / (TB * F), j = i - r * TB * F, t = j / F, f = j - t * F;
+            const int b = row0 + t;
+            agg_at[u] = i0 < n_agg ? (r * TB + t) * ld1 + F + f : -1;
+            agg_ok[u] = i0 < n_agg && b < a.B;
+            agg_row[u] = (size_t)r * a.B + (b < a.B ? b : a.B - 1);
+            agg_f[u] = f;
+            agg_cb[u] = 0;
+            agg_nch[u] = 1;
+            if (a.chunk_begin) {                                           // (uniform: a kernel argument)
+                agg_cb[u] = a.chunk_begin[agg_row[u]];
+                agg_nch[u] = a.chunk_begin[agg_row[u] + 1] - agg_cb[u];
+            }
+            v_agg[u] = a.agg[agg_row[u] * a.agg_stride + f];
+        }
+        float v_self = a.X[(size_t)self_id * a.feat_stride + self_f];
+        if (!do_self || self_b >= a.B) v_self = 0.f;
+#pragma unroll
+        for (int u = 0; u < NAGG; ++u) {
+            if (!agg_ok[u]) v_agg[u] = 0.f;
+            else if (agg_nch[u] == 0) v_agg[u] = 0.f / 0.f;       // empty set: 0 / 0 like the reference's mask.div (layers.py:612-614)
+            else if (agg_nch[u] > 1) {                             // sum of the gather's partial sums, in chunk order, / |set|  (== combine_rows)
+                float acc = 0.f;
+                const float *pp = a.partial + (size_t)agg_cb[u] * a.partial_stride + agg_f[u];
+                const int nch = agg_nch[u];
+                int jx = 0;
+                for (; jx + 4 <= nch; jx += 4) {
+                    const float p0 = pp[(size_t)(jx + 0) * a.partial_stride], p1 = pp[(size_t)(jx + 1) * a.partial_stride];
+                    const float p2 = pp[(size_t)(jx + 2) * a.partial_stride], p3 = pp[(size_t)(jx + 3) * a.partial_stride];
+                    acc += p0; acc += p1; acc += p2; acc += p3;
                 }
+                for (; jx < nch; ++jx) acc += pp[(size_t)jx * a.partial_stride];
+                v_agg[u] = acc / (float)a.cnt[agg_row[u]];
             }
         }
         if constexpr (WLDS) {
@@ -236,18 +286,24 @@ __global__ void __launch_bounds__(DENSE_THREADS) dense_step_kernel(const DenseAr
             const int c4 = E >> 2;
             const int cc = (tid % c4) * 4, r0 = tid / c4, rstep = DENSE_THREADS / c4;   // DENSE_THREADS % c4 == 0 (host-checked)
             const int n_rows = K2 + R * K1;
+            // every workgroup streams the same 100+ KB out of L2 at the same moment: each starts at another row, so that they
+            // do not all queue on the same L2 channels in the same order
+            const int rot = (int)((blockIdx.x * 29u) % (unsigned)n_rows);
             for (int base = r0; base < n_rows; base += WSTAGE * rstep) {
                 float4 wv[WSTAGE];
+                int rows_[WSTAGE];
 #pragma unroll
                 for (int u = 0; u < WSTAGE; ++u) {
-                    const int rr = base + u * rstep;
-                    // (theta is flat: W_inter's K2 rows are followed directly by W_intra[0]'s K1 rows, W_intra[1]'s, ...)
-                    wv[u] = *reinterpret_cast<const float4 *>(a.W_inter + (size_t)(rr < n_rows ? rr : n_rows - 1) * E + cc);
+                    const int rl = base + u * rstep;
+                    int rr = (rl < n_rows ? rl : n_rows - 1) + rot;
+                    rr = rr >= n_rows ? rr - n_rows : rr;
+                    rows_[u] = rl < n_rows ? rr : -1;
+                    wv[u] = *reinterpret_cast<const float4 *>(a.W_inter + (size_t)rr * E + cc);
                 }
 #pragma unroll
                 for (int u = 0; u < WSTAGE; ++u) {
-                    const int rr = base + u * rstep;
-                    if (rr < n_rows) {
+                    const int rr = rows_[u];
+                    if (rr >= 0) {
                         float *dst = rr < K2 ? s_wi + rr * ldW
                                              : s_wr + ((rr - K2) / K1) * K1p * ldW + ((rr - K2) % K1) * ldW;
                         *reinterpret_cast<float4 *>(dst + cc) = wv[u];
@@ -324,7 +380,7 @@ __global__ void __launch_bounds__(DENSE_THREADS) dense_step_kernel(const DenseAr
     //      their partial tiles added in a fixed order ----------------------------------------------------------------
     {
         const int ksteps = K2p / 4;
-        const int per = (ksteps + kparts - 1) / kparts;
+        const int per = ((ksteps + kparts - 1) / kparts + MU - 1) / MU * MU;      // steps per part: a multiple of MU
         for (int item = wave; item < ntile_e * kparts; item += DENSE_WAVES) {
             const int ct = item % ntile_e, kp = item / ntile_e;
             const int k_lo = kp * per * 4, k_hi = (kp + 1) * per * 4 < K2p ? (kp + 1) * per * 4 : K2p;
@@ -335,6 +391,7 @@ __global__ void __launch_bounds__(DENSE_THREADS) dense_step_kernel(const DenseAr
             for (int i = 0; i < 4; ++i) s_part[(kp * TB + rq + i) * E + col] = c[i];
         }
         __syncthreads();
+        DENSE_STAMP(11);
         for (int i = tid; i < TB * E; i += DENSE_THREADS) {
             const int t = i / E, e = i - t * E;
             float acc = s_part[t * E + e];
@@ -374,7 +431,7 @@ __global__ void __launch_bounds__(DENSE_THREADS) dense_step_kernel(const DenseAr
                     a.center[2 * b + 1] = c1;
                 }
                 if (a.labels) {
-                    const int y = a.labels[b];
+                    const int y = my_label;
                     float lg, lc;
                     xent2(g0, g1, y, lg, dg0, dg1);
                     xent2(c0, c1, y, lc, dc0, dc1);
@@ -408,28 +465,26 @@ __global__ void __launch_bounds__(DENSE_THREADS) dense_step_kernel(const DenseAr
         slab[off_cls(F, E, R) + i] = sacc;
     }
     DENSE_STAMP(9);
-    // the label classifier's partial gradient: write-through (sc1) stores when another workgroup of this launch will read it
-    for (int i = tid; i < (sp == 0 ? 2 * F + 2 : 0); i += DENSE_THREADS) {
-        float sacc = 0.f;
-        if (i < 2 * F) {
-            const int cidx = i / F, f = i - cidx * F;
-            for (int t = 0; t < TB; ++t) sacc = fmaf(s_dcl[2 * t + cidx], s_cat[t * ld2 + f], sacc);
-        } else {
-            for (int t = 0; t < TB; ++t) sacc += s_dcl[2 * t + (i - 2 * F)];
+    // the label classifier's partial gradient, by ONE wave: write-through (sc1) stores when another workgroup of this launch
+    // will read it - that wave's own vmcnt wait, a phase later, then covers every one of them.  The wave chosen has no other
+    // global store in between (the last of the waves that only compute a dh_r tile in the next phase), so that wait is free.
+    const int clf_wave = (R * ntile_e - 1) & (DENSE_WAVES - 1);
+    if (wave == clf_wave && sp == 0) {
+        for (int i = lane; i < 2 * F + 2; i += PCG_WAVE) {
+            float sacc = 0.f;
+            if (i < 2 * F) {
+                const int cidx = i / F, f = i - cidx * F;
+                for (int t = 0; t < TB; ++t) sacc = fmaf(s_dcl[2 * t + cidx], s_cat[t * ld2 + f], sacc);
+            } else {
+                for (int t = 0; t < TB; ++t) sacc += s_dcl[2 * t + (i - 2 * F)];
+            }
+            float *dst = slab + off_clf(F, E, R) + i;
+            if (adam_clf) __hip_atomic_store(dst, sacc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else *dst = sacc;
         }
-        float *dst = slab + off_clf(F, E, R) + i;
-        if (adam_clf) __hip_atomic_store(dst, sacc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else *dst = sacc;
     }
-    if (adam_clf) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains before the barrier
     DENSE_STAMP(10);
     __syncthreads();
-    if (adam_clf && tid == 0) {
-        // arrival ticket, taken by EVERY workgroup (the partial gradients above are write-through and drained; and a
-        // workgroup that has arrived has long read the classifier's weights): the last to arrive applies Adam to them
-        const unsigned old = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == (unsigned)gridDim.x - 1u) s_flag[0] = 1;
-    }
     DENSE_STAMP(5);
     // one phase: dh_r = (dcomb W[F+rE.., :]^T) * relu'(h_r) for every r   and   dW_inter = cat^T dcomb
     {
@@ -443,15 +498,12 @@ __global__ void __launch_bounds__(DENSE_THREADS) dense_step_kernel(const DenseAr
             if (tile < n_dh) {
                 const int r = tile / ntile_e, ct = tile - r * ntile_e;
                 const float *Wr = a.W_inter + (size_t)(F + r * E) * E;   // rows of W_inter that multiply h_r
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 const int rr = lane & 15, kq = lane >> 4;
-#pragma unroll 4
-                for (int e0 = 0; e0 < E; e0 += 4) {                       // out[t][j] = sum_e dcomb[t][e] * Wr[j][e]
-                    const float av = s_dcomb[rr * ldE + e0 + kq];
-                    const float bv = WLDS ? s_wi[(F + r * E + ct * 16 + rr) * ldW + e0 + kq]
-                                          : Wr[(size_t)(ct * 16 + rr) * E + e0 + kq];
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
-                }
+                const float *ap = s_dcomb + rr * ldE + kq;                 // out[t][j] = sum_e dcomb[t][e] * Wr[j][e]
+                const float *bl = s_wi + (F + r * E + ct * 16 + rr) * ldW + kq;
+                const float *bg = Wr + (size_t)(ct * 16 + rr) * E + kq;
+                const f32x4 acc = WLDS ? mfma_chain(E >> 2, [&](int s) { return ap[4 * s]; }, [&](int s) { return bl[4 * s]; })
+                                       : mfma_chain(E >> 2, [&](int s) { return ap[4 * s]; }, [&](int s) { return bg[4 * s]; });
                 const int col = ct * 16 + rr, rq = kq * 4;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -469,6 +521,14 @@ __global__ void __launch_bounds__(DENSE_THREADS) dense_step_kernel(const DenseAr
     }
     __syncthreads();
     DENSE_STAMP(6);
+    // arrival ticket, taken by EVERY workgroup (its classifier gradient - wave 0's stores, issued a phase ago - is
+    // write-through and drained; and a workgroup that has arrived has long read the classifier's weights).  The answer
+    // is not needed before the end of the kernel, so nobody waits for it here.
+    unsigned ticket_old = 0u;
+    if (adam_clf && wave == clf_wave) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) ticket_old = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     // dW_r = [self|agg_r]^T dh_r for every r
     {
         const int mt1 = (K1 + 15) / 16, per_r = mt1 * ntile_e;
@@ -484,9 +544,13 @@ __global__ void __launch_bounds__(DENSE_THREADS) dense_step_kernel(const DenseAr
         }
     }
     DENSE_STAMP(7);
-    // ---- the workgroup whose classifier gradient arrived last: sum of every tile's share (tile order), Adam for those
-    //      2F + 2 parameters (model_handler.py:153) - the only ones the next step's score pass reads --------------------
-    if (adam_clf && s_flag[0]) {            // (s_flag was written before the barrier that follows the dh_r phase)
+    if (a.stamps && threadIdx.x == 0 && sp == 0) a.stamps[(size_t)tile_id * 16 + 13] = clock64();
+    // ---- the workgroup whose ticket was the last: sum of every tile's share of the classifier gradient (tile order), Adam
+    //      for those 2F + 2 parameters (model_handler.py:153) - the only ones the next step's score pass reads ----------
+    if (!adam_clf) return;
+    if (wave == clf_wave && lane == 0) s_flag[0] = ticket_old == (unsigned)gridDim.x - 1u;
+    __syncthreads();
+    if (s_flag[0]) {
         if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -528,7 +592,7 @@ __global__ void __launch_bounds__(256) adam_reduce_kernel(float *__restrict__ th
 __global__ void clear_word_kernel(uint32_t *w) { w[0] = 0u; }
 
 static size_t dense_smem_bytes(int F, int E, int R, bool wlds) {
-    const int K1p = (2 * F + 3) & ~3, K2p = (F + R * E + 3) & ~3;
+    const int K1p = (2 * F + KPAD - 1) / KPAD * KPAD, K2p = (F + R * E + KPAD - 1) / KPAD * KPAD;
     const int ntile_e = E / 16, kparts = ntile_e <= DENSE_WAVES ? DENSE_WAVES / ntile_e : 1;
     size_t fl = (size_t)(R * TB * (K1p + 1) + TB * (K2p + 1) + (2 + R) * TB * (E + 1) + 4 * TB + 2 * E + 2 * F + 4 + 4);
     if (wlds) fl += (size_t)(K2p + R * K1p) * (E + 4);
@@ -537,7 +601,7 @@ static size_t dense_smem_bytes(int F, int E, int R, bool wlds) {
 }
 
 static bool dense_wlds(int F, int E, int R) {
-    const int K1p = (2 * F + 3) & ~3;
+    const int K1p = (2 * F + KPAD - 1) / KPAD * KPAD;
     const int ntile_e = E / 16, kparts = ntile_e <= DENSE_WAVES ? DENSE_WAVES / ntile_e : 1;
     // the K-split partial tiles of `combined` live where the W_intra copies were
     return dense_smem_bytes(F, E, R, true) <= 160 * 1024 && DENSE_THREADS % (E / 4) == 0 && (size_t)kparts * TB * E <= (size_t)R * K1p * (E + 4);
@@ -611,18 +675,29 @@ static int launch_dense(const pcg_graph_desc *g, const float *theta, int32_t emb
     int n_split = slabs ? 256 / n_tiles : 1;
     a.n_split = n_split < 1 ? 1 : (n_split > 4 ? 4 : n_split);
     a.stamps = g_dense_stamps;
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(dense_step_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(dense_step_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    // the instantiated shapes: YelpChi (F 32) and Amazon (F 25) at emb 64 and 128, three relations; anything else: run-time shape
+    typedef void (*kern_t)(const DenseArgs);
+    kern_t kern;
+    if (R == 3 && F == 32 && E == 64 && wlds) kern = dense_step_kernel<true, 32, 64, 3>;
+    else if (R == 3 && F == 25 && E == 64 && wlds) kern = dense_step_kernel<true, 25, 64, 3>;
+    else if (R == 3 && F == 32 && E == 128 && !wlds) kern = dense_step_kernel<false, 32, 128, 3>;
+    else if (R == 3 && F == 25 && E == 128 && !wlds) kern = dense_step_kernel<false, 25, 128, 3>;
+    else kern = wlds ? dense_step_kernel<true, 0, 0, 0> : dense_step_kernel<false, 0, 0, 0>;
+    static kern_t attr_done[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool seen = false;
+    for (kern_t k : attr_done) seen = seen || k == kern;
+    if (!seen) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+            hipSuccess)
             return PCG_E_LAUNCH;
-        attr = true;
+        for (kern_t &k : attr_done)
+            if (!k) {
+                k = kern;
+                break;
+            }
     }
     const dim3 grid(n_tiles * a.n_split), block(DENSE_THREADS);
-    if (wlds) hipLaunchKernelGGL(dense_step_kernel<true>, grid, block, smem, static_cast<hipStream_t>(stream), a);
-    else hipLaunchKernelGGL(dense_step_kernel<false>, grid, block, smem, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(kern, grid, block, smem, static_cast<hipStream_t>(stream), a);
     PCG_LAUNCH_CHECK();
     return PCG_OK;
 }
