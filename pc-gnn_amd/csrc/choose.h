@@ -6,13 +6,13 @@
 namespace pcg {
 
 // ---- degree tiers of the select kernel --------------------------------------------------------------------------------
-constexpr int TA_CAP = 16;       // rows of <= 16 neighbours: four per wave, 16 lanes each, ranked with DPP row rotations
+constexpr int TA_CAP = 16;       // rows of <= 16 neighbours WITHOUT minority picks / self union: four per wave, 16 lanes each, DPP ranking
 constexpr int TB_CAP = 64;       // rows of <= 64: one wave, one key per lane, ranked lane against lane
 constexpr int T1_CAP = 512;      // rows of <= 512: one wave, up to 8 keys per lane in registers, 256-bin LDS histogram rounds
 constexpr int T4_CAP = 4096;     // workgroup rows are queued in two classes (> 4096 first) so that the longest start first
 constexpr int WG_KEYCAP = 10240; // workgroup rows up to this length keep their distance keys in LDS; longer ones recompute them
 constexpr int SEL_NW = 8;        // waves per select workgroup
-constexpr int SEL_BLOCKS = 512;  // persistent select workgroups: 2 per CU (96 VGPRs: 5 waves per SIMD)
+constexpr int SEL_BLOCKS = 768;  // persistent select workgroups: 3 per CU (<= 80 VGPRs: 6 waves per SIMD; 49.5 KB of LDS each)
 constexpr int HIST_WG = 2048;    // histogram bins of a workgroup row
 constexpr int HIST_W = 256;      // histogram bins of a single-wave row
 constexpr int WAVE_AREA = WG_KEYCAP / SEL_NW;   // LDS words a wave owns while it works on single-wave rows
@@ -22,7 +22,7 @@ constexpr int PLAN_PER = 4;      // rows per plan thread per tile
 constexpr int FRONT_COUNT_THREADS = 256;
 
 // counters (uint32) at the head of the workspace
-enum { C_N1 = 0, C_N4 = 1, C_N16 = 2, C_NCHUNK = 5, C_N0 = 8, C_NA = 9, C_TICKET = 16 /* .. 16 + 8: gather's arrival shards */ };
+enum { C_N1 = 0, C_N4 = 1, C_N16 = 2, C_NCHUNK = 5, C_N0 = 8, C_NA = 9 };
 
 struct RowRec {            // 32 bytes, written by the plan, read by select: one 32-B load instead of a 3-deep chain
     int64_t start;         // offset of the row in indices[r]
@@ -37,6 +37,7 @@ __host__ __device__ __forceinline__ int rec_cap(const RowRec &p, int add_self) {
 
 struct Workspace {
     uint32_t *counters;    // [64]
+    uint32_t *heads;       // [8 * 16] work-queue heads of the select kernel, one per shard, 64 bytes apart; the plan zeroes them
     int64_t *row_begin;    // [rows + 1] start of every row's region in list
     int32_t *chunk_begin;  // [rows + 1]
     int32_t *len;          // [rows]     entries (holes included) actually written
@@ -63,6 +64,7 @@ static inline int64_t carve(const pcg_graph_desc *g, int32_t B, int64_t list_cap
     };
     unsigned char *p;
     p = take(256);                                 if (w) w->counters = reinterpret_cast<uint32_t *>(p);
+    p = take(4 * 8 * 16);                          if (w) w->heads = reinterpret_cast<uint32_t *>(p);
     p = take(8 * (rows + 1));                      if (w) w->row_begin = reinterpret_cast<int64_t *>(p);
     p = take(4 * (rows + 1));                      if (w) w->chunk_begin = reinterpret_cast<int32_t *>(p);
     p = take(4 * rows);                            if (w) w->len = reinterpret_cast<int32_t *>(p);

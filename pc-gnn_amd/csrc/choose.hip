@@ -38,9 +38,13 @@ __device__ __forceinline__ RowRec row_plan(const ChooseArgs &a, int row) {
 // ---------------------------------------------------------------------------------------------
 // four of the five tier counts of a thread / tile (each <= 4096) share one 64-bit word, 16 bits each: one scan;
 // the fifth (rows of <= 16 neighbours) is scanned on its own
-__device__ __forceinline__ long long tier_word(int d) {
-    return d <= TA_CAP ? 0ll : d <= TB_CAP ? 1ll : d <= T1_CAP ? (1ll << 16) : d <= T4_CAP ? (1ll << 32) : (1ll << 48);
+// tier of a row: 0 = four-per-wave group (<= 16 neighbours and nothing to do after the selection), 1 = one key per lane
+// (<= 64; also the short rows that go on to minority picks / the self union: they get a wave of their own instead of
+// queueing behind each other inside a group), 2 = one wave (<= 512), 3 / 4 = workgroup rows (<= 4096 / longer)
+__device__ __forceinline__ int row_tier(int d, bool tail) {
+    return (d <= TA_CAP && !tail) ? 0 : d <= TB_CAP ? 1 : d <= T1_CAP ? 2 : d <= T4_CAP ? 3 : 4;
 }
+__device__ __forceinline__ long long tier_word(int tier) { return tier == 0 ? 0ll : 1ll << (16 * (tier - 1)); }
 struct TierCounts {
     int na, n0, n1, n4, n16;
 };
@@ -56,11 +60,11 @@ __device__ __forceinline__ TierCounts tier_unpack(long long w, int na) {
 __device__ __forceinline__ void tier_add(TierCounts &a, const TierCounts &b) {
     a.na += b.na; a.n0 += b.n0; a.n1 += b.n1; a.n4 += b.n4; a.n16 += b.n16;
 }
-__device__ __forceinline__ void tier_push(const Workspace &w, int d, int row, TierCounts &o) {
-    if (d <= TA_CAP) w.qa[o.na++] = row;
-    else if (d <= TB_CAP) w.q0[o.n0++] = row;
-    else if (d <= T1_CAP) w.q1[o.n1++] = row;
-    else if (d <= T4_CAP) w.q4[o.n4++] = row;
+__device__ __forceinline__ void tier_push(const Workspace &w, int tier, int row, TierCounts &o) {
+    if (tier == 0) w.qa[o.na++] = row;
+    else if (tier == 1) w.q0[o.n0++] = row;
+    else if (tier == 2) w.q1[o.n1++] = row;
+    else if (tier == 3) w.q4[o.n4++] = row;
     else w.q16[o.n16++] = row;
 }
 __device__ __forceinline__ void tier_finish(const Workspace &w, const TierCounts &t, bool overflow) {
@@ -69,6 +73,7 @@ __device__ __forceinline__ void tier_finish(const Workspace &w, const TierCounts
     w.counters[C_N1] = overflow ? 0 : t.n1;
     w.counters[C_N4] = overflow ? 0 : t.n4;
     w.counters[C_N16] = overflow ? 0 : t.n16;
+    for (int i = 0; i < 8; ++i) w.heads[16 * i] = 0;      // the select kernel's work-queue heads
 }
 // exclusive scan of one value per thread over the block; returns the block total through `total`
 template <typename T>
@@ -168,8 +173,9 @@ __global__ void __launch_bounds__(PLAN_THREADS) plan_kernel(const ChooseArgs a) 
                 cap[i] = rec_cap(p, a.add_self);
                 cap_sum += cap[i];
                 chunk_sum += (cap[i] + CHUNK - 1) / CHUNK;
-                tiers += tier_word(p.d);
-                na_sum += p.d <= TA_CAP;
+                const int tier = row_tier(p.d, p.m > 0 || a.add_self);
+                tiers += tier_word(tier);
+                na_sum += tier == 0;
             }
         }
         PLAN_STAMP(1);
@@ -197,7 +203,7 @@ __global__ void __launch_bounds__(PLAN_THREADS) plan_kernel(const ChooseArgs a) 
             a.w.recs[row] = rec[i];
             if (!overflow) {
                 write_chunk_desc(a.w, row, o_chunk, o_cap, cap[i]);
-                tier_push(a.w, rec[i].d, row, o);
+                tier_push(a.w, row_tier(rec[i].d, rec[i].m > 0 || a.add_self), row, o);
             }
             o_cap += cap[i];
             o_chunk += nch;
@@ -239,8 +245,9 @@ __device__ __forceinline__ void plan_count_body(const ChooseArgs &a, PlanTotals 
         const int cap = rec_cap(p, a.add_self);
         cap_sum = cap;
         chunk_sum = (cap + CHUNK - 1) / CHUNK;
-        tiers = tier_word(p.d);
-        na = p.d <= TA_CAP;
+        const int tier = row_tier(p.d, p.m > 0 || a.add_self);
+        tiers = tier_word(tier);
+        na = tier == 0;
     }
     long long t_cap, t_tiers;
     int t_chunk, t_na;
@@ -294,8 +301,9 @@ __device__ __forceinline__ void plan_write_body(const ChooseArgs &a, const PlanT
     int t_chunk, t_na;
     const long long o_cap = run_cap + block_excl_scan<long long>((long long)cap, lds64, t_cap);
     const int o_chunk = run_chunk + block_excl_scan(nch, lds, t_chunk);
-    const int o_na = block_excl_scan((row < rows && rec.d <= TA_CAP) ? 1 : 0, lds, t_na);
-    TierCounts o = tier_unpack(block_excl_scan<long long>(row < rows ? tier_word(rec.d) : 0ll, lds64, t_tiers), o_na);
+    const int tier = row < rows ? row_tier(rec.d, rec.m > 0 || a.add_self) : -1;
+    const int o_na = block_excl_scan(tier == 0 ? 1 : 0, lds, t_na);
+    TierCounts o = tier_unpack(block_excl_scan<long long>(tier >= 0 ? tier_word(tier) : 0ll, lds64, t_tiers), o_na);
     tier_add(o, run);
     if (row < rows) {
         a.w.row_begin[row] = o_cap;
@@ -304,7 +312,7 @@ __device__ __forceinline__ void plan_write_body(const ChooseArgs &a, const PlanT
         a.w.recs[row].chunk0 = o_chunk;
         if (!overflow) {
             write_chunk_desc(a.w, row, o_chunk, o_cap, cap);
-            tier_push(a.w, rec.d, row, o);
+            tier_push(a.w, tier, row, o);
         }
     }
     if (block == 0 && threadIdx.x == 0) {

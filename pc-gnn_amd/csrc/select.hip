@@ -18,9 +18,10 @@
 // the kept ids by binary search; a duplicate leaves a -1 hole so slots - and sums - keep a fixed order).
 // Nothing fills the unused tail of a row's region: the row writes how many entries each of its gather chunks holds.
 //
-// Rows are assigned statically (no queue atomics): workgroup rows strided over the workgroups from the first one on,
-// longest class first; single-wave rows strided over the waves from the LAST workgroup on.
+// Work is pulled by whole workgroups (one atomic per workgroup row, one per batch of eight single-wave items), longest
+// class first: see select_rows.
 #include <limits.h>
+#include <stdlib.h>
 
 #include "choose.h"
 
@@ -61,26 +62,45 @@ __device__ __forceinline__ void grp_scan(int v, int wave, int lane, int *red, in
     }
 }
 
+// DPP-selected lane value (full-rate VALU, no LDS crossbar round trip as __shfl would make)
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v, uint32_t old = 0u) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, 0xF, 0xF, false);
+}
+// wave-wide min / max of uint32: butterfly inside every 16-lane row (quad permutes, half-row / row mirrors - after them every
+// lane of a row holds the row's result), then the four rows through scalar registers
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-    for (int o = 1; o < PCG_WAVE; o <<= 1) {
-        const uint32_t t = (uint32_t)__shfl_xor((int)v, o);
-        v = t < v ? t : v;
-    }
-    return v;
+    uint32_t t;
+    t = dpp_u32<0xB1>(v); v = t < v ? t : v;
+    t = dpp_u32<0x4E>(v); v = t < v ? t : v;
+    t = dpp_u32<0x141>(v); v = t < v ? t : v;
+    t = dpp_u32<0x140>(v); v = t < v ? t : v;
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    const uint32_t x = r0 < r1 ? r0 : r1, y = r2 < r3 ? r2 : r3;
+    return x < y ? x : y;
 }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-    for (int o = 1; o < PCG_WAVE; o <<= 1) {
-        const uint32_t t = (uint32_t)__shfl_xor((int)v, o);
-        v = t > v ? t : v;
-    }
-    return v;
+    uint32_t t;
+    t = dpp_u32<0xB1>(v); v = t > v ? t : v;
+    t = dpp_u32<0x4E>(v); v = t > v ? t : v;
+    t = dpp_u32<0x141>(v); v = t > v ? t : v;
+    t = dpp_u32<0x140>(v); v = t > v ? t : v;
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    const uint32_t x = r0 > r1 ? r0 : r1, y = r2 > r3 ? r2 : r3;
+    return x > y ? x : y;
 }
+// wave-wide inclusive scan: row_shr 1, 2, 4, 8 inside every 16-lane row (a lane without a source adds 0), then the row
+// totals through scalar registers
 __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
-    for (int o = 1; o < PCG_WAVE; o <<= 1) {
-        const int t = __shfl_up(v, o);
-        if (lane >= o) v += t;
-    }
-    return v;
+    v += (int)dpp_u32<0x111>((uint32_t)v);
+    v += (int)dpp_u32<0x112>((uint32_t)v);
+    v += (int)dpp_u32<0x114>((uint32_t)v);
+    v += (int)dpp_u32<0x118>((uint32_t)v);
+    const int t0 = __builtin_amdgcn_readlane(v, 15), t1 = __builtin_amdgcn_readlane(v, 31), t2 = __builtin_amdgcn_readlane(v, 47);
+    const int row = lane >> 4;
+    return v + (row > 0 ? t0 : 0) + (row > 1 ? t1 : 0) + (row > 2 ? t2 : 0);
 }
 
 __device__ __forceinline__ bool sorted_contains(const uint32_t *list, int n, uint32_t x) {
@@ -263,7 +283,7 @@ __device__ __forceinline__ void finish_row(const ChooseArgs &a, int row, const R
 #pragma unroll
             for (int x = 0; x < KEY_UNROLL; ++x) {
                 const int j = base + x * NT;
-                pos[x] = j < n_strict ? (uint32_t)pk[L + j] : 0u;
+                pos[x] = (uint32_t)pk[L + (j < n_strict ? j : n_strict - 1)];
             }
 #pragma unroll
             for (int x = 0; x < KEY_UNROLL; ++x) u[x] = (uint32_t)a.g.train_pos[pos[x]];
@@ -354,18 +374,22 @@ __device__ __forceinline__ void report_plain_row(const ChooseArgs &a, int row, c
         rank += (ok < key) || (ok == key && op < pos);                                                      \
     } while (0)
 
-// Four rows of <= 16 neighbours, one per 16-lane row of the wave.  area: WAVE_AREA words of LDS.
-__device__ __forceinline__ void select_four_short_rows(const ChooseArgs &a, int q_first, int na, uint32_t *area,
-                                                       const int32_t *const *t_indices, int lane) {
+// Four rows of <= 16 neighbours, one per 16-lane row of the wave.  Only rows that have nothing to do after the selection
+// (no minority picks, no self union) are queued here, so a group runs from its records to its four lists without ever
+// leaving the 16-lane rows; the short rows that do go on have a wave of their own (select_lane_row).
+__device__ __forceinline__ void select_four_short_rows(const ChooseArgs &a, int q_first, int na, const int32_t *const *t_indices,
+                                                       int lane) {
     const int g = lane >> 4, pos = lane & 15;
     const int qi = q_first + g;
     const bool active = qi < na;
     const int row = a.w.qa[active ? qi : na - 1];
     const RowRec p = a.w.recs[row];
     const int r = row / a.B;
-    const int32_t *__restrict__ nbr = t_indices[r] + p.start;
+    // (every load below is unconditional - index clamped, value discarded afterwards: a load inside a branch is waited for
+    //  at the branch's end, one round trip after the other)
+    const int32_t *__restrict__ nbr = t_indices[r] + (p.d > 0 ? p.start : 0);
     const bool have = active && pos < p.d;
-    const uint32_t id = have ? (uint32_t)nbr[pos] : 0u;
+    const uint32_t id = (uint32_t)nbr[pos < p.d ? pos : (p.d > 0 ? p.d - 1 : 0)];
     const float c = a.center_s0 ? a.center_s0[row - r * a.B] : a.s0[p.node];
     const bool keep_all = rec_keep_all(p);
     const float sc = a.s0[id];
@@ -376,32 +400,8 @@ __device__ __forceinline__ void select_four_short_rows(const ChooseArgs &a, int 
     PCG_ROR_STEP(11); PCG_ROR_STEP(12); PCG_ROR_STEP(13); PCG_ROR_STEP(14); PCG_ROR_STEP(15);
     const bool sel = have && (keep_all || rank < p.k);             // stable order: (key, position)
     const uint32_t gm = (uint32_t)(__ballot(sel) >> (16 * g)) & 0xFFFFu;
-    const int at = __popc(gm & ((1u << pos) - 1u)), ns = __popc(gm);
-    const bool tail = active && (p.m > 0 || a.add_self);           // needs the shared tail (minority picks / self union)
-    uint32_t *sel_lds = area + HIST_W + g * TA_CAP;
-    if (sel) {
-        if (tail) sel_lds[at] = id;
-        else a.w.list[p.lbeg + at] = (int32_t)id;
-    }
-    if (active && !tail && pos == 0) report_plain_row(a, row, p, ns);
-    // the rows that go on, one after the other, the whole wave on each
-    const uint64_t tails = __ballot(tail && pos == 0);
-    for (int gg = 0; gg < 4; ++gg) {
-        if (!((tails >> (16 * gg)) & 1ull)) continue;             // wave-uniform
-        const int src = 16 * gg;
-        RowRec q;
-        q.start = 0;
-        q.node = __builtin_amdgcn_readlane(p.node, src);
-        q.d = __builtin_amdgcn_readlane(p.d, src);
-        q.k = __builtin_amdgcn_readlane(p.k, src);
-        q.m = __builtin_amdgcn_readlane(p.m, src);
-        q.lbeg = __builtin_amdgcn_readlane(p.lbeg, src);
-        q.chunk0 = __builtin_amdgcn_readlane(p.chunk0, src);
-        const int qrow = __builtin_amdgcn_readlane(row, src);
-        const int qns = __builtin_amdgcn_readlane(ns, src);
-        const float qc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), src));
-        finish_row<1>(a, qrow, q, qc, area + HIST_W + gg * TA_CAP, qns, false, 0, lane, nullptr);
-    }
+    if (sel) a.w.list[p.lbeg + __popc(gm & ((1u << pos) - 1u))] = (int32_t)id;
+    if (active && pos == 0) report_plain_row(a, row, p, __popc(gm));
 }
 
 // One row of 17 .. 64 neighbours on one wave: one key per lane, ranked lane against lane in the stable (key, position)
@@ -413,21 +413,32 @@ __device__ __forceinline__ void select_lane_row(const ChooseArgs &a, int row, ui
     const int d = p.d, k = p.k;
     const bool keep_all = rec_keep_all(p);
     const int r = row / a.B;
-    const int32_t *__restrict__ nbr = a.g.indices[r] + p.start;
+    const int32_t *__restrict__ nbr = a.g.indices[r] + (d > 0 ? p.start : 0);      // (d == 0: a node without neighbours that joins its own set)
     const float c = a.center_s0 ? a.center_s0[row - r * a.B] : a.s0[p.node];
     uint32_t *sel_lds = area + HIST_W;
     const bool tail = p.m > 0 || a.add_self;
     const bool have = lane < d;
-    const uint32_t id = have ? (uint32_t)nbr[lane] : 0u;
-    const float sc = keep_all ? 0.f : a.s0[id];
+    const uint32_t id = (uint32_t)nbr[have ? lane : (d > 0 ? d - 1 : 0)];   // unconditional load (clamped)
+    const float sc = a.s0[id];
     const uint32_t mine = have ? dist_key(c, sc) : 0xFFFFFFFFu;
     PCG_STAMP(1);
     int rank = 0;
-    if (!keep_all)
-        for (int j = 0; j < d; ++j) {                                            // d is wave-uniform
-            const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)mine, j);
-            rank += (o < mine) || (o == mine && j < lane);
-        }
+    if (!keep_all) {
+        // #keys below mine (two instructions per key); when no two keys are equal - the usual case, recognised by the ranks
+        // adding up to d (d - 1) / 2 - that is the rank in the stable (key, position) order already
+        for (int j = 0; j < d; ++j)                                              // d is wave-uniform
+            rank += (uint32_t)__builtin_amdgcn_readlane((int)mine, j) < mine;
+        int sum = have ? rank : 0;
+        sum += (int)dpp_u32<0xB1>((uint32_t)sum);
+        sum += (int)dpp_u32<0x4E>((uint32_t)sum);
+        sum += (int)dpp_u32<0x141>((uint32_t)sum);
+        sum += (int)dpp_u32<0x140>((uint32_t)sum);
+        const int total = __builtin_amdgcn_readlane(sum, 0) + __builtin_amdgcn_readlane(sum, 16) +
+                          __builtin_amdgcn_readlane(sum, 32) + __builtin_amdgcn_readlane(sum, 48);
+        if (total != d * (d - 1) / 2)                                            // equal keys: + the equal ones at earlier positions
+            for (int j = 0; j < d; ++j)
+                rank += ((uint32_t)__builtin_amdgcn_readlane((int)mine, j) == mine) && j < lane;
+    }
     const bool s = have && (keep_all || rank < k);
     const uint64_t sm = __ballot(s);
     const int ns = __popcll(sm);
@@ -467,10 +478,10 @@ __device__ __forceinline__ void select_wave_row(const ChooseArgs &a, int row, ui
 #pragma unroll
         for (int u = 0; u < KPT; ++u) {
             const int i = u * PCG_WAVE + lane;
-            id[u] = i < d ? (uint32_t)nbr[i] : 0u;
+            id[u] = (uint32_t)nbr[i < d ? i : d - 1];                    // unconditional loads (clamped): all in flight together
         }
 #pragma unroll
-        for (int u = 0; u < KPT; ++u) sc[u] = (keep_all || u * PCG_WAVE >= d) ? 0.f : a.s0[id[u]];
+        for (int u = 0; u < KPT; ++u) sc[u] = a.s0[id[u]];
 #pragma unroll
         for (int u = 0; u < KPT; ++u) key[u] = (u * PCG_WAVE + lane < d) ? dist_key(c, sc[u]) : 0xFFFFFFFFu;
     }
@@ -585,7 +596,7 @@ __device__ __forceinline__ void for_keys(const uint32_t *keys, const int32_t *__
 #pragma unroll
             for (int u = 0; u < KEY_UNROLL; ++u) {
                 const int i = base + u * step;
-                id[u] = i < end ? (uint32_t)nbr[i] : 0u;
+                id[u] = (uint32_t)nbr[i < end ? i : end - 1];
             }
 #pragma unroll
             for (int u = 0; u < KEY_UNROLL; ++u) sc[u] = s0[id[u]];
@@ -627,7 +638,7 @@ __device__ __forceinline__ void select_wg_row(const ChooseArgs &a, int row, uint
 #pragma unroll
             for (int u = 0; u < KEY_UNROLL; ++u) {
                 const int i = base + u * NT;
-                id[u] = i < d ? (uint32_t)nbr[i] : 0u;
+                id[u] = (uint32_t)nbr[i < d ? i : d - 1];
             }
 #pragma unroll
             for (int u = 0; u < KEY_UNROLL; ++u) sc[u] = s0[id[u]];
@@ -762,7 +773,7 @@ __device__ __forceinline__ void select_wg_row(const ChooseArgs &a, int row, uint
 #pragma unroll
             for (int u = 0; u < CU; ++u) {
                 const int i = i0 + u * PCG_WAVE + lane;
-                idv[u] = i < e0 ? (uint32_t)nbr[i] : 0u;
+                idv[u] = (uint32_t)nbr[i < e0 ? i : d - 1];
             }
 #pragma unroll
             for (int u = 0; u < CU; ++u) {
@@ -782,10 +793,10 @@ __device__ __forceinline__ void select_wg_row(const ChooseArgs &a, int row, uint
 #pragma unroll
             for (int u = 0; u < KEY_UNROLL; ++u) {
                 const int i = i0 + u * PCG_WAVE + lane;
-                id[u] = i < e0 ? (uint32_t)nbr[i] : 0u;
+                id[u] = (uint32_t)nbr[i < e0 ? i : d - 1];
             }
 #pragma unroll
-            for (int u = 0; u < KEY_UNROLL; ++u) sc[u] = keep_all ? 0.f : s0[id[u]];
+            for (int u = 0; u < KEY_UNROLL; ++u) sc[u] = s0[id[u]];
 #pragma unroll
             for (int u = 0; u < KEY_UNROLL; ++u) {
                 const int i = i0 + u * PCG_WAVE + lane;
@@ -810,10 +821,10 @@ __device__ __forceinline__ void select_wg_row(const ChooseArgs &a, int row, uint
 #pragma unroll
             for (int u = 0; u < KEY_UNROLL; ++u) {
                 const int i = i0 + u * PCG_WAVE + lane;
-                id[u] = i < e0 ? (uint32_t)nbr[i] : 0u;
+                id[u] = (uint32_t)nbr[i < e0 ? i : d - 1];
             }
 #pragma unroll
-            for (int u = 0; u < KEY_UNROLL; ++u) sc[u] = keep_all ? 0.f : s0[id[u]];
+            for (int u = 0; u < KEY_UNROLL; ++u) sc[u] = s0[id[u]];
 #pragma unroll
             for (int u = 0; u < KEY_UNROLL; ++u) {
                 const int i = i0 + u * PCG_WAVE + lane;
@@ -840,45 +851,81 @@ __device__ __forceinline__ void select_wg_row(const ChooseArgs &a, int row, uint
     finish_row<NW>(a, row, p, c, selbuf, ns, !LDSK, wave, lane, red);
 }
 
-// One persistent launch selects every row of the batch, longest rows first.
-__global__ void __launch_bounds__(SEL_NW *PCG_WAVE) __attribute__((amdgpu_waves_per_eu(5, 8))) select_rows(const ChooseArgs a) {
+// One persistent launch selects every row of the batch, longest rows first.  The work is one queue of workgroup-sized units,
+//   [workgroup rows > 4096 | workgroup rows 513 .. 4096 | batches of eight consecutive single-wave items, one per wave],
+// the single-wave items being [rows 65 .. 512 | rows 17 .. 64 and the short rows with a tail | groups of four short rows].
+// Unit u belongs to shard u % 8.  Workgroup b starts on unit b (no atomic at all for a batch that fits the grid) and then
+// pulls the further units of its shard b % 8 with one returning device-scope atomic per unit, issued a whole unit ahead of
+// its use (its latency hides behind the work).  Eight head words on cache lines of their own keep the pulls of the 768
+// workgroups from serialising on one address (one word serves ~90 atomics per microsecond); per-wave pulls would be
+// thousands.  A workgroup busy with long rows simply pulls fewer units; nothing else is assigned in advance.
+constexpr int SEL_SHARDS = 8;
+__global__ void __launch_bounds__(SEL_NW *PCG_WAVE) __attribute__((amdgpu_waves_per_eu(6, 8))) select_rows(const ChooseArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t *lds = reinterpret_cast<uint32_t *>(smem);
     uint32_t *hist = lds + WG_KEYCAP;
     uint32_t *cand = hist + HIST_WG;
-    int *red = reinterpret_cast<int *>(cand + PCG_WAVE);                   // 2 * SEL_NW + 2 + 4 ints
+    int *red = reinterpret_cast<int *>(cand + PCG_WAVE);                   // 2 * SEL_NW + 2 + 4 ints, then 2 claim slots
+    int *claim = red + 2 * SEL_NW + 6;
     // per-relation neighbour arrays in LDS: a per-lane relation index (four short rows per wave) then costs one ds_read
     // instead of a waterfall over the kernel arguments
     const int32_t **t_indices = reinterpret_cast<const int32_t **>(red + 2 * SEL_NW + 8);
     if (threadIdx.x < PCG_MAX_REL) t_indices[threadIdx.x] = a.g.indices[threadIdx.x < (unsigned)a.g.n_rel ? threadIdx.x : 0];
-    __syncthreads();
     const int wave = threadIdx.x >> 6, lane = lane_id();
-    // workgroup rows: the virtual queue [> 4096 | 513 .. 4096], strided over the workgroups from the first one on
+    const bool leader = threadIdx.x == 0;
     const int n16 = (int)a.w.counters[C_N16], n4 = (int)a.w.counters[C_N4];
-    for (int j = (int)blockIdx.x; j < n16 + n4; j += SEL_BLOCKS) {
-        const int row = __builtin_amdgcn_readfirstlane(j < n16 ? a.w.q16[j] : a.w.q4[j - n16]);     // one row per workgroup: scalar
-        const int d = a.w.recs[row].d;
-        if (d <= WG_KEYCAP) select_wg_row<true>(a, row, lds, hist, cand, red);
-        else select_wg_row<false>(a, row, lds, hist, cand, red);
-    }
-    // single-wave rows: the virtual queue [65 .. 512 | 17 .. 64 | groups of four rows of <= 16], strided over the waves from
-    // the LAST workgroup on, so that with few workgroup rows the workgroups holding those are not the ones holding these too
     const int n1 = (int)a.w.counters[C_N1], n0 = (int)a.w.counters[C_N0], na = (int)a.w.counters[C_NA];
-    const int n_items = n1 + n0 + (na + 3) / 4;
+    const int n_wg = n16 + n4, n_items = n1 + n0 + (na + 3) / 4;
+    // single-wave items per unit: eight (one per wave) when there is plenty of them, fewer when the batch is so small that
+    // the items can be spread over more workgroups (more CUs' load paths) than eight per workgroup would use
+    const int grid = (int)gridDim.x;
+    const int avail = grid - n_wg > grid / 4 ? grid - n_wg : grid / 4;
+    int bs = (n_items + avail - 1) / avail;
+    bs = bs < 1 ? 1 : (bs > SEL_NW ? SEL_NW : bs);
+    const int n_units = n_wg + (n_items + bs - 1) / bs;
+    const bool pull = n_units > grid;                                      // otherwise unit = workgroup: no atomics at all
+    const int shard = (int)blockIdx.x % SEL_SHARDS;
+    uint32_t *head = a.w.heads + 16 * shard;                               // (64 bytes apart)
     uint32_t *area = lds + wave * WAVE_AREA;
-    for (int j = (SEL_BLOCKS - 1 - (int)blockIdx.x) * SEL_NW + wave; j < n_items; j += SEL_BLOCKS * SEL_NW) {
-        if (j < n1) {
-            select_wave_row(a, __builtin_amdgcn_readfirstlane(a.w.q1[j]), area, lane);
-        } else if (j < n1 + n0) {
-            select_lane_row(a, __builtin_amdgcn_readfirstlane(a.w.q0[j - n1]), area, lane);
+    __syncthreads();
+
+    int u = (int)blockIdx.x, pending = 0, slot = 0;
+    while (u < n_units) {
+        // the unit after this one: its claim is in flight while this one runs
+        if (leader && pull) pending = shard + SEL_SHARDS * (grid / SEL_SHARDS + (int)atomicAdd(head, 1u));
+        if (u < n_wg) {
+            const int row = __builtin_amdgcn_readfirstlane(u < n16 ? a.w.q16[u] : a.w.q4[u - n16]);     // one row per workgroup: scalar
+            const int d = a.w.recs[row].d;
+            if (d <= WG_KEYCAP) select_wg_row<true>(a, row, lds, hist, cand, red);
+            else select_wg_row<false>(a, row, lds, hist, cand, red);
         } else {
-            select_four_short_rows(a, 4 * (j - n1 - n0), na, area, t_indices, lane);
+            const int j = wave < bs ? (u - n_wg) * bs + wave : n_items;
+            if (j < n1) {
+                select_wave_row(a, __builtin_amdgcn_readfirstlane(a.w.q1[j]), area, lane);
+            } else if (j < n1 + n0) {
+                select_lane_row(a, __builtin_amdgcn_readfirstlane(a.w.q0[j - n1]), area, lane);
+            } else if (j < n_items) {
+                select_four_short_rows(a, 4 * (j - n1 - n0), na, t_indices, lane);
+            }
+        }
+        if (!pull) break;
+        if (leader) claim[slot] = pending;
+        __syncthreads();
+        u = claim[slot];
+        slot ^= 1;
+    }
+    // the last workgroup out puts the heads back to zero, so that the kernel can be launched again on the same plan
+    if (leader && pull) {
+        const unsigned done = atomicAdd(a.w.heads + 15, 1u);
+        if (done == gridDim.x - 1) {
+            for (int i = 0; i < SEL_SHARDS; ++i) atomicExch(a.w.heads + 16 * i, 0u);
+            atomicExch(a.w.heads + 15, 0u);
         }
     }
 }
 
 static size_t select_smem_bytes() {
-    return sizeof(uint32_t) * (WG_KEYCAP + HIST_WG + PCG_WAVE) + sizeof(int) * (2 * SEL_NW + 8) + sizeof(void *) * PCG_MAX_REL;
+    return sizeof(uint32_t) * (WG_KEYCAP + HIST_WG + PCG_WAVE) + sizeof(int) * (2 * SEL_NW + 8) + sizeof(void *) * PCG_MAX_REL;   // (claim[2] = red[22..23])
 }
 
 int launch_select_rows(const ChooseArgs &a, hipStream_t st) {
@@ -887,7 +934,13 @@ int launch_select_rows(const ChooseArgs &a, hipStream_t st) {
     static_assert(WAVE_AREA >= HIST_W + T1_CAP + PCG_WAVE, "a wave's LDS area: histogram | kept ids | candidates");
     static_assert(((WG_KEYCAP / SEL_NW + PCG_WAVE - 1) / PCG_WAVE) <= 32, "pass A keeps one bit per iteration in a uint32");
     static_assert((2 * SEL_NW + 8) % 2 == 0, "the pointer table behind red stays 8-byte aligned");
-    hipLaunchKernelGGL(select_rows, dim3(SEL_BLOCKS), dim3(SEL_NW * PCG_WAVE), select_smem_bytes(), st, a);
+    static int blocks = 0;
+    if (!blocks) {                      // (tuning knob: PCG_SEL_BLOCKS = persistent workgroups, a multiple of 8, at most 3 per CU)
+        const char *e = getenv("PCG_SEL_BLOCKS");
+        const int v = e ? atoi(e) : 0;
+        blocks = (v >= SEL_SHARDS && v <= SEL_BLOCKS && v % SEL_SHARDS == 0) ? v : SEL_BLOCKS;
+    }
+    hipLaunchKernelGGL(select_rows, dim3(blocks), dim3(SEL_NW * PCG_WAVE), select_smem_bytes(), st, a);
     PCG_LAUNCH_CHECK();
     return PCG_OK;
 }
