@@ -294,17 +294,24 @@ int pcg_adam_flush(float *theta, float *m, float *v, const float *slabs, int32_t
                    double weight_decay, void *stream);
 
 /* ---- multi-GPU halo exchange helpers (no counterpart in the reference) ----------
- * The selection list of a partitioned run holds GLOBAL ids.  `total` is a device int64: the
- * number of list entries in use (row_begin[n_rel*B] of the choose workspace).
- * classify: owned id (lo <= id < hi) -> id - lo; train-pos id (posmap[id] >= 0) -> n_local + posmap[id];
- *           remote id -> -(id + 2) in the list and flag[id] = 1 (flag: int32 [n_nodes], all zero on entry).
- * compact : uniq[slot[v] - 1] = v for every flagged v, slot = inclusive prefix sum of flag (caller-computed).
- * remap   : marked entries -> halo_base + slot[id] - 1; clears the flags it meets. */
-int pcg_halo_classify(int32_t *list, const int64_t *total, int64_t list_capacity, int32_t lo, int32_t hi,
-                      int32_t n_local, const int32_t *posmap, int32_t *flag, void *stream);
-int pcg_halo_compact(const int32_t *flag, const int32_t *slot, int32_t n_nodes, int32_t *uniq, void *stream);
-int pcg_halo_remap(int32_t *list, const int64_t *total, int64_t list_capacity, const int32_t *slot,
-                   int32_t halo_base, int32_t *flag, void *stream);
+ * The selection list of a partitioned run holds GLOBAL ids.  These calls re-index it into the rank's extended feature
+ * table [ owned rows | train-pos rows | halo ]; they walk the list's entries in use (the workspace's chunk table) and a hash
+ * table sized by the halo capacity - nothing is sized by the node-id space.
+ *   bounds   int32 [world + 1]: rank r owns ids [bounds[r], bounds[r + 1])          (device)
+ *   pos_ids / pos_idx  int32 [n_pos]: the train-pos ids ascending / their row in the replicated block   (device)
+ *   table    uint32 [2 * table_slots], table_slots = pcg_halo_table_slots(halo_cap); first half all 0xFFFFFFFF on entry
+ *   counts   uint32 [129], zero on entry; on return [0, world) = unique remote ids per owner, [128] = overflow bits
+ *            (1: table full, 2: more unique remote ids than halo_cap - the caller must not gather then)
+ *   uniq     int32 [halo_cap]: the unique remote ids grouped by owner in rank order (the request list)
+ * classify: owned id -> id - lo; train-pos id -> n_local + its row; remote id -> marked, hashed, counted, given a halo slot.
+ * remap   : marked entries -> halo_base + slot (after the rows were fetched, or before - it only needs the table). */
+int64_t pcg_halo_table_slots(int32_t halo_cap);
+int pcg_halo_classify(const pcg_graph_desc *g, int32_t B, void *workspace, int64_t list_capacity, int32_t lo, int32_t hi,
+                      int32_t n_local, const int32_t *pos_ids, const int32_t *pos_idx, int32_t n_pos, const int32_t *bounds,
+                      int32_t world, uint32_t *table, int64_t table_slots, uint32_t *counts, int32_t *uniq, int32_t halo_cap,
+                      int32_t halo_base, void *stream);
+int pcg_halo_remap(const pcg_graph_desc *g, int32_t B, void *workspace, int64_t list_capacity, uint32_t *table,
+                   int64_t table_slots, int32_t halo_cap, int32_t halo_base, void *stream);
 
 /* gather rows: out[i, :feat_dim] = X[ids[i], :feat_dim]  (self_feats, layers.py:273-277) */
 int pcg_gather_rows(const pcg_graph_desc *g, const int32_t *ids, int32_t n_ids,

@@ -75,9 +75,10 @@ PROTOTYPES = {
     "pcg_pick": (C.c_int, [_P, _P, _I32, _P, _U64, _U64, _I32, _P, _P]),
     "pcg_pick_shuffled": (C.c_int, [_P, _P, _I32, _U64, _U64, _P, _I32, _I32, _P, _P, _P, _P]),
     "pcg_gather_rows": (C.c_int, [_G, _P, _I32, _P, _I32, _P]),
-    "pcg_halo_classify": (C.c_int, [_P, _P, _I64, _I32, _I32, _I32, _P, _P, _P]),
-    "pcg_halo_compact": (C.c_int, [_P, _P, _I32, _P, _P]),
-    "pcg_halo_remap": (C.c_int, [_P, _P, _I64, _P, _I32, _P, _P]),
+    "pcg_halo_table_slots": (_I64, [_I32]),
+    "pcg_halo_classify": (C.c_int, [_G, _I32, _P, _I64, _I32, _I32, _I32, _P, _P, _I32, _P, _I32, _P, _I64, _P, _P, _I32, _I32,
+                                    _P]),
+    "pcg_halo_remap": (C.c_int, [_G, _I32, _P, _I64, _P, _I64, _I32, _I32, _P]),
     "pcg_dense_n_params": (_I64, [_I32, _I32, _I32]),
     "pcg_dense_param_offset": (_I64, [_I32, _I32, _I32, _I32, _I32]),
     "pcg_dense_n_tiles": (_I32, [_I32]),

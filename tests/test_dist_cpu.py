@@ -1,5 +1,6 @@
-"""Multi-process CPU tests (gloo, world size 2) of the N>1 path's host logic: node partition,
-shard construction, and the halo exchange (ids all-to-all -> rows all-to-all -> list re-index).
+"""Multi-process CPU tests (gloo, world size 2) of the N>1 path's host logic: node partition (equal and in-edge
+balanced), shard construction, pick weights with the global label frequencies, and the halo exchange (ids all-to-all ->
+rows all-to-all -> list re-index; capacity errors raised by every rank together).
 The HIP kernels are not involved (they have no CPU path); GPU coverage is tests/test_dist_gpu.py."""
 import os
 import socket
@@ -26,38 +27,51 @@ def _worker(rank, world, port, q):
     try:
         import pcgnn_amd  # noqa: F401
         from pcgnn_amd import synth
-        from pcgnn_amd.dist import HaloExchange, Partition, shard_workload
+        from pcgnn_amd.dist import HaloExchange, Partition, shard_pick_weights, shard_workload, total_degree
         w = synth.make_workload("t", 601, 25, (900, 4000), 0.2, seed=3)      # odd N: last shard is shorter
-        part = Partition(w.n, world, rank)
-        assert part.n_per == 301 and part.n_local == (301 if rank == 0 else 300)
-        sh = shard_workload(w, part)
-        # shard CSR rows == the global rows, neighbour ids stay global
-        for (ip, ix), (gip, gix) in zip(sh["csr"], w.csr):
-            for v in (part.lo, part.lo + 7, part.hi - 1):
-                assert np.array_equal(ix[ip[v - part.lo]:ip[v - part.lo + 1]], gix[gip[v]:gip[v + 1]])
-        assert np.array_equal(sh["X_local"], w.X[part.lo:part.hi])
-        P = len(sh["train_pos"])
-        halo_rows = 400
-        X_ext = torch.zeros(part.n_local + P + halo_rows, 28)
-        X_ext[:part.n_local, :25] = torch.from_numpy(sh["X_local"])
-        X_ext[part.n_local:part.n_local + P, :25] = torch.from_numpy(sh["X_pos"])
-        posmap = torch.full((w.n,), -1, dtype=torch.int32)
-        posmap[torch.as_tensor(sh["train_pos"])] = torch.arange(P, dtype=torch.int32)
-        hx = HaloExchange(part, X_ext, P, posmap)
-        rs = np.random.RandomState(10 + rank)
-        for trial in range(3):
-            n_list = [500, 37, 0][trial] if rank == 0 else [300, 0, 5][trial]   # uneven, incl. an empty list
-            orig = rs.randint(0, w.n, size=n_list).astype(np.int32)
-            orig[rs.rand(n_list) < 0.1] = -1                                    # holes
-            lst = torch.from_numpy(orig.copy())
-            n_halo = hx.fetch_and_remap(lst)
-            new = lst.numpy()
-            keep = orig >= 0
-            assert np.array_equal(new[~keep], orig[~keep])                       # holes untouched
-            got = X_ext[torch.from_numpy(new[keep]).long(), :25].numpy()
-            assert np.array_equal(got, w.X[orig[keep]]), "re-indexed rows must be the requested global rows"
-            rem = keep & ~((orig >= part.lo) & (orig < part.hi)) & (posmap.numpy()[np.clip(orig, 0, None)] < 0)
-            assert n_halo == len(np.unique(orig[rem])) and hx.last_stats["remote_entries"] == int(rem.sum())
+        for balanced in (False, True):
+            part = Partition.balanced(total_degree(w.csr), world, rank) if balanced else Partition(w.n, world, rank)
+            if not balanced:
+                assert part.n_max == 301 and part.n_local == (301 if rank == 0 else 300)
+            sh = shard_workload(w, part)
+            # shard CSR rows == the global rows, neighbour ids stay global
+            for (ip, ix), (gip, gix) in zip(sh["csr"], w.csr):
+                for v in (part.lo, part.lo + 7, part.hi - 1):
+                    assert np.array_equal(ix[ip[v - part.lo]:ip[v - part.lo + 1]], gix[gip[v]:gip[v + 1]])
+            assert np.array_equal(sh["X_local"], w.X[part.lo:part.hi])
+            # pick weights: every rank uses the GLOBAL label frequencies (utils.py:276), so the ranks' weights are the
+            # single-GPU sampler's weights restricted to their nodes
+            y_all = w.labels[w.idx_train]
+            mine = shard_pick_weights(w.labels[sh["idx_train_local"]], sh["homo_deg_train"], len(y_all), int(y_all.sum()))
+            glob = np.diff(np.concatenate([[0.0], synth.pick_cum_weights(w)]))
+            sel = (w.idx_train >= part.lo) & (w.idx_train < part.hi)
+            np.testing.assert_allclose(mine, glob[sel], rtol=1e-12)
+            P = len(sh["train_pos"])
+            halo_rows = 400
+            X_ext = torch.zeros(part.n_local + P + halo_rows, 28)
+            X_ext[:part.n_local, :25] = torch.from_numpy(sh["X_local"])
+            X_ext[part.n_local:part.n_local + P, :25] = torch.from_numpy(sh["X_pos"])
+            hx = HaloExchange(part, X_ext, sh["train_pos"])
+            tp = np.asarray(sh["train_pos"])
+            rs = np.random.RandomState(10 + rank)
+            for trial in range(3):
+                n_list = [500, 37, 0][trial] if rank == 0 else [300, 0, 5][trial]   # uneven, incl. an empty list
+                orig = rs.randint(0, w.n, size=n_list).astype(np.int32)
+                orig[rs.rand(n_list) < 0.1] = -1                                    # holes
+                lst = torch.from_numpy(orig.copy())
+                n_halo = hx.fetch_and_remap(lst)
+                new = lst.numpy()
+                keep = orig >= 0
+                assert np.array_equal(new[~keep], orig[~keep])                       # holes untouched
+                got = X_ext[torch.from_numpy(new[keep]).long(), :25].numpy()
+                assert np.array_equal(got, w.X[orig[keep]]), "re-indexed rows must be the requested global rows"
+                rem = keep & ~((orig >= part.lo) & (orig < part.hi)) & ~np.isin(orig, tp)
+                assert n_halo == len(np.unique(orig[rem])) and hx.last_stats["remote_entries"] == int(rem.sum())
+            # a halo too small on ONE rank: every rank raises (same count matrix, same verdict) - nobody is left in a collective
+            small = HaloExchange(part, X_ext[:part.n_local + P + (3 if rank == 0 else 400)], sh["train_pos"])
+            lst = torch.from_numpy(rs.randint(0, w.n, size=200).astype(np.int32))
+            with pytest.raises(RuntimeError, match="rank 0 needs"):
+                small.fetch_and_remap(lst)
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         import traceback
@@ -88,3 +102,31 @@ def test_partition_covers_every_node_once():
         assert np.array_equal(owned, np.arange(n))
         ids = np.arange(n)
         assert all(parts[int(o)].lo <= v < parts[int(o)].hi for v, o in zip(ids, parts[0].owner(ids)))
+
+
+def test_balanced_partition_equalises_edges():
+    """Partition.balanced: contiguous ranges whose CSR entry counts are nearly equal (SURVEY 8e), covering every node once;
+    owner() agrees with the ranges on numpy and torch inputs."""
+    from pcgnn_amd import synth
+    from pcgnn_amd.dist import Partition, expected_halo_rows, total_degree
+    w = synth.make_workload("t", 5000, 8, (3000, 40000), 0.1, seed=1, skew=1.2)
+    deg = total_degree(w.csr)
+    for world in (2, 3, 8):
+        parts = [Partition.balanced(deg, world, r) for r in range(world)]
+        owned = np.concatenate([np.arange(p.lo, p.hi) for p in parts])
+        assert np.array_equal(owned, np.arange(w.n))
+        loads = np.array([deg[p.lo:p.hi].sum() + p.n_local for p in parts], dtype=np.float64)
+        assert loads.max() <= loads.mean() * 1.05 + deg.max() + 1, loads
+        eq = [Partition(w.n, world, r) for r in range(world)]
+        eq_loads = np.array([deg[p.lo:p.hi].sum() for p in eq], dtype=np.float64)
+        assert loads.max() - loads.min() <= eq_loads.max() - eq_loads.min() + deg.max()
+        ids = np.arange(w.n)
+        own = parts[0].owner(ids)
+        assert all(parts[int(o)].lo <= v < parts[int(o)].hi for v, o in zip(ids[::37], own[::37]))
+        assert np.array_equal(parts[0].owner(torch.from_numpy(ids)).numpy(), own)
+    # halo capacity: from the batch's demand, never more than the remote nodes, a single row at world size 1
+    d = [np.full(100, 40), np.full(100, 10)]
+    wts = np.ones(100)
+    assert expected_halo_rows(d, wts, 64, 1, 1000) == 1
+    assert expected_halo_rows(d, wts, 64, 2, 10 ** 9) == int(np.ceil(25 * 64 * 0.5 * 1.5 + 1024))
+    assert expected_halo_rows(d, wts, 64, 8, 300) == 300

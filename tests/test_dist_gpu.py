@@ -1,5 +1,9 @@
 """Two ranks of the node-partitioned path on ONE GPU (collectives staged through the host over gloo)
-against the single-GPU path on the same global batch.  -m gpu."""
+against the single-GPU path on the same global batch.  -m gpu.
+
+Shape: BASELINE configs[2]'s model (emb 128: the dense kernel variant that streams its weights) at batch 1024 per rank,
+in-edge-balanced partition, a halo region much smaller than the node count (n_ext < N), and a third scenario whose halo is
+too small on purpose: every rank must raise together."""
 import os
 import socket
 
@@ -10,6 +14,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
+EMB, BATCH, NODES = 128, 1024, 120000
 
 
 def _free_port():
@@ -29,20 +34,23 @@ def _worker(rank, world, port, q):
         from pcgnn_amd import ops, synth
         from pcgnn_amd.dist import DistributedPCGNN
         dev = torch.device("cuda", 0)
-        w = synth.make_workload("t", 3001, 32, (4000, 30000, 90000), 0.15, seed=5)
-        B = 96
-        cfg = dict(emb_size=32, rho=0.5, alpha=2.0, lr=0.01, weight_decay=0.001, batch_size=B, seed=11)
-        d = DistributedPCGNN(w, cfg, dev, stage_host=True)
+        w = synth.make_workload("t", NODES, 32, (20000, 100000, 400000), 0.15, seed=5, skew=1.5)
+        B, E, F = BATCH, EMB, 32
+        cfg = dict(emb_size=E, rho=0.5, alpha=2.0, lr=0.01, weight_decay=0.001, batch_size=B, seed=11)
+        d = DistributedPCGNN(w, cfg, dev, stage_host=True)           # default: halo sized from the batch's demand
         part = d.part
+        rows = d.feature_rows
+        assert rows["owned"] + rows["train_pos"] + rows["halo"] < w.n, "the extended table must be smaller than the full one"
+        assert abs(part.n_local - w.n / world) < 0.25 * w.n          # (in-edge balanced: not the equal split, not degenerate)
         ids_local = d.pick_epoch(B, 0)                       # duplicates included
         labels = d.labels_of(ids_local)
         theta0 = d.theta.clone()
 
         # ---- single-GPU reference on the full graph, same parameters ----
         g = pcgnn_amd.DeviceGraph(w.X, w.csr, w.train_pos, dev)
-        o3 = d.lib.pcg_dense_param_offset(32, 32, 3, 3, 0)
-        o4 = d.lib.pcg_dense_param_offset(32, 32, 3, 4, 0)
-        Wc, bc = theta0[o3:o3 + 64].view(2, 32), theta0[o4:o4 + 2]
+        o3 = d.lib.pcg_dense_param_offset(F, E, 3, 3, 0)
+        o4 = d.lib.pcg_dense_param_offset(F, E, 3, 4, 0)
+        Wc, bc = theta0[o3:o3 + 2 * F].view(2, F), theta0[o4:o4 + 2]
         s0 = ops.score_table(g, Wc, bc)
         keys = ops.pos_sort(g, s0)
         gids = (ids_local.long() + part.lo).to(torch.int32)
@@ -56,9 +64,10 @@ def _worker(rank, world, port, q):
         assert torch.equal(agg, agg_ref), "same lists, same order of summation: bitwise equal"
         stats = d.halo.last_stats
         assert stats["halo_rows"] > 0 and stats["rows_served"] > 0
+        assert stats["halo_rows"] <= rows["halo"] and stats["rows_served"] <= rows["serve_buffer"]
 
         # ---- one train step: gradient = all-reduced; compare with the single-GPU gradient on the global batch ----
-        d.train_step(ids_local, labels, use_graphs=(rank == 0))     # one rank through the captured graphs, one eagerly
+        d.train_step(ids_local, labels, use_graphs=False)           # (every rank in the same mode: a rank's first graph step runs a whole warm-up step, collectives included)
         torch.cuda.synchronize()
         all_ids = [torch.empty(B, dtype=torch.int32) for _ in range(world)]
         dist.all_gather(all_ids, gids.cpu())
@@ -72,7 +81,7 @@ def _worker(rank, world, port, q):
         lg, ce, rl = torch.empty(world * B, 2, device=dev), torch.empty(world * B, 2, device=dev), torch.empty(world * B, device=dev)
         st = ops._stream(dev)
         P_ = ops._p
-        assert d.lib.pcg_dense_step(g.desc_ref(), P_(theta0), 32, P_(gb_ids), P_(gb_lab), world * B, P_(agg_g), 32, 2.0,
+        assert d.lib.pcg_dense_step(g.desc_ref(), P_(theta0), E, P_(gb_ids), P_(gb_lab), world * B, P_(agg_g), F, 2.0,
                                     1.0 / (world * B), P_(lg), P_(ce), None, P_(rl), P_(slabs), None, st) == 0
         assert d.lib.pcg_adam_step(None, None, None, P_(slabs), n_tiles, d.n_params, None, 0.01, 0.9, 0.999, 1e-8, 0.001,
                                    P_(grad), 0, st) == 0
@@ -85,6 +94,20 @@ def _worker(rank, world, port, q):
         dist.all_gather(th, d.theta.cpu())
         assert torch.equal(th[0], th[1])
         assert not torch.equal(th[0], theta0.cpu())
+        # a second and third step through the captured segments on both ranks (fresh batches): the first of them warms up and
+        # captures, the second replays
+        for ep in (1, 2):
+            ids2 = d.pick_epoch(B, ep)
+            d.train_step(ids2, d.labels_of(ids2))
+        torch.cuda.synchronize()
+        dist.all_gather(th, d.theta.cpu())
+        assert torch.equal(th[0], th[1]) and torch.isfinite(th[0]).all()
+
+        # ---- a halo that is too small on one rank only: both ranks raise (nobody is left inside a collective) ----
+        small = DistributedPCGNN(w, dict(cfg, batch_size=256), dev, stage_host=True, halo_rows=(16 if rank == 1 else 20000))
+        ids3 = small.pick_epoch(256, 0)
+        with pytest.raises(RuntimeError, match="rank 1 needs"):
+            small.train_step(ids3, small.labels_of(ids3), use_graphs=False)
         q.put((rank, "ok"))
     except Exception:  # pragma: no cover
         import traceback
@@ -100,7 +123,7 @@ def test_two_ranks_match_single_gpu():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=600) for _ in procs]
+    res = [q.get(timeout=900) for _ in procs]
     for p in procs:
         p.join(timeout=60)
     for rank, msg in res:
