@@ -117,6 +117,7 @@ def run_partitioned(args, w, B, lr, wd, dev, dist, world, rank):
     from pcgnn_amd.dist import DistributedPCGNN
     cfg = dict(emb_size=args.emb, rho=args.rho, alpha=2.0, lr=lr, weight_decay=wd, batch_size=B, seed=args.seed)
     d = DistributedPCGNN(w, cfg, dev)
+    n_nodes, feat, n_rel = w.n, d.F, d.R
 
     def one_step(k):
         ids = d.pick_epoch(B, k)
@@ -140,8 +141,12 @@ def run_partitioned(args, w, B, lr, wd, dev, dist, world, rank):
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     stats = torch.tensor([halo_rows, remote, entries], dtype=torch.float64, device=dev)
+    fr = d.feature_rows
+    mem = torch.tensor([fr["owned"] + fr["train_pos"] + fr["halo"], d.halo.max_seen["halo_rows"], fr["halo"]],
+                       dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(stats)
+    dist.all_reduce(mem, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     nodes_total = args.steps * B * world
     if rank == 0:
@@ -166,13 +171,15 @@ def run_partitioned(args, w, B, lr, wd, dev, dist, world, rank):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{w.name} N={w.n} F={w.X.shape[1]} R={len(w.csr)} "
+            "config": {"workload": f"{w.name} N={n_nodes} F={feat} R={n_rel} "
                                    f"edges={'/'.join(str(e) for e in w.meta['rel_edges'])}, PCGNN emb={args.emb} "
                                    f"batch={B}/GPU rho={args.rho}",
-                       "global_batch": B * world, "parallelism": f"node-partition x{world}: score all-gather, "
-                       "id + feature-row all-to-all, grad all-reduce (RCCL)", "engine": "fused-eager",
+                       "global_batch": B * world, "parallelism": f"node-partition x{world} (in-edge balanced): score "
+                       "all-gather, id + feature-row all-to-all, grad all-reduce (RCCL)", "engine": "graph segments + eager collectives",
                        "nodes_processed": int(nodes_total),
-                       "per_rank_per_step": {"halo_rows_fetched": hr, "rows_served_to_others": rm, "halo_bytes_in": en}},
+                       "per_rank_per_step": {"halo_rows_fetched": hr, "rows_served_to_others": rm, "halo_bytes_in": en},
+                       "feature_rows_per_rank_max": {"owned+train_pos+halo": int(mem[0].item()), "halo_capacity": int(mem[2].item()),
+                                                     "halo_rows_max_seen": int(mem[1].item()), "unpartitioned_table": int(n_nodes)}},
             "roofline": roofline,
         }
         print(json.dumps(out))
@@ -200,9 +207,15 @@ def main():
     import pcgnn_amd  # noqa: F401  (raises if libpcgnn_hip.so is missing - no fallback)
     from pcgnn_amd.handler import PCGNNTrainer
 
+    partitioned = (world > 1 or args.force_partitioned) and args.engine != "dp"
+    if partitioned and args.workload == "powerlaw":
+        # every rank generates ITS shard of the graph (pure functions of the seed): no rank ever holds the whole graph
+        from pcgnn_amd import synth
+        w = synth.power_law_shard(args.nodes, args.edges, args.seed, world, rank)
+        return run_partitioned(args, w, args.batch_size or 4096, 0.01, 0.001, dev, dist, world, rank)
     w, default_b, lr, wd = make_workload(args)
     B = args.batch_size or default_b
-    if (world > 1 or args.force_partitioned) and args.engine != "dp":
+    if partitioned:
         return run_partitioned(args, w, B, lr, wd, dev, dist, world, rank)
     engine = args.engine or ("graph" if world == 1 else "fused")
     if engine == "dp":          # N>1 only: replicated graph, data-parallel batches (not the default)

@@ -304,19 +304,27 @@ class DistributedPCGNN:
         cfg = dict(emb_size=64, rho=0.5, alpha=2.0, lr=0.01, weight_decay=0.001, batch_size=1024, seed=0)
         cfg.update(model_cfg or {})
         self.cfg = cfg
-        if balanced:
-            part = self.part = Partition.balanced(total_degree(w.csr), self.world, self.rank)
+        if hasattr(w, "X_local"):                   # a synth.ShardedWorkload: this rank's shard, generated in place (no rank ever held the whole graph)
+            assert w.rank == self.rank and len(w.bounds) == self.world + 1
+            part = self.part = Partition(w.n, self.world, self.rank, w.bounds)
+            sh = dict(X_local=w.X_local, csr=w.csr, labels_local=w.labels_local, idx_train_local=w.idx_train_local,
+                      homo_deg_train=w.homo_deg_train, train_pos=list(w.train_pos), X_pos=w.X_pos)
+            n_train, n_train_pos, y_loc = w.n_train, w.n_train_pos, w.labels_train_local
+            F = w.X_local.shape[1]
         else:
-            part = self.part = Partition(w.n, self.world, self.rank)
-        sh = shard_workload(w, part)
-        F = w.X.shape[1]
+            if balanced:
+                part = self.part = Partition.balanced(total_degree(w.csr), self.world, self.rank)
+            else:
+                part = self.part = Partition(w.n, self.world, self.rank)
+            sh = shard_workload(w, part)
+            y_all = w.labels[w.idx_train]
+            n_train, n_train_pos, y_loc = len(y_all), int(y_all.sum()), w.labels[sh["idx_train_local"]]
+            F = w.X.shape[1]
         P = len(sh["train_pos"])
         B = cfg["batch_size"]
         n_local = part.n_local
         # pick weights with the GLOBAL label frequencies (utils.py:276), not this shard's
-        y_all = w.labels[w.idx_train]
-        y_loc = w.labels[sh["idx_train_local"]]
-        weights = shard_pick_weights(y_loc, sh["homo_deg_train"], len(y_all), int(y_all.sum()))
+        weights = shard_pick_weights(y_loc, sh["homo_deg_train"], n_train, n_train_pos)
         n_remote = max(w.n - n_local, 0)
         if halo_rows is None:       # from the batch's expected demand, not from the node count
             deg_rel = [np.diff(ip)[sh["idx_train_local"] - part.lo] for ip, _ in sh["csr"]]

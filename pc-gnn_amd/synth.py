@@ -124,3 +124,109 @@ def pick_cum_weights(w: Workload) -> np.ndarray:
     y = w.labels[w.idx_train]
     lf = (y.sum() - len(y)) * y + len(y)
     return np.cumsum(w.homo_deg[w.idx_train] / lf)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Sharded generation (multi-GPU runs at BASELINE config 4 scale): every rank builds ITS rows of one global power-law graph
+# without any rank ever holding the whole graph.  Everything is a pure function of (seed, node id) or of (seed, relation,
+# edge chunk), so the ranks agree on the graph without communicating:
+#   features / labels / train split : counter-based (a 64-bit mix of the node id), any subset of nodes on demand
+#   edges : chunks of `chunk` (src, dst) pairs from Philox streams keyed by (relation, chunk); a rank walks all chunks and
+#           keeps the pairs that touch its id range (transient memory: one chunk; kept: ~2 m / world pairs)
+# (A different generator than power_law() above - same shape parameters, not the same graph.)
+# ---------------------------------------------------------------------------------------------------------------------
+def _mix64(x: np.ndarray) -> np.ndarray:
+    """splitmix64 finaliser on uint64 arrays."""
+    x = (x + np.uint64(0x9E3779B97F4A7C15)).astype(np.uint64)
+    x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return x ^ (x >> np.uint64(31))
+
+
+def _unit(seed: int, stream: int, idx: np.ndarray) -> np.ndarray:
+    """uniform (0, 1) doubles, a pure function of (seed, stream, idx)."""
+    with np.errstate(over="ignore"):
+        h = _mix64(idx.astype(np.uint64) * np.uint64(0xD1342543DE82EF95) + np.uint64((seed * 1000003 + stream) & 0xFFFFFFFFFFFFFFFF))
+    return ((h >> np.uint64(11)).astype(np.float64) + 0.5) / float(1 << 53)
+
+
+def node_features(seed: int, ids: np.ndarray, feat: int) -> np.ndarray:
+    """N(0, 1) feature rows of the given nodes (Box-Muller on counter-based uniforms)."""
+    ids = np.asarray(ids, dtype=np.int64)
+    flat = (ids[:, None] * feat + np.arange(feat, dtype=np.int64)[None, :]).reshape(-1)
+    u1, u2 = _unit(seed, 11, flat), _unit(seed, 12, flat)
+    return (np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)).astype(np.float32).reshape(len(ids), feat)
+
+
+@dataclass
+class ShardedWorkload:
+    name: str
+    n: int                              # nodes of the whole graph
+    bounds: np.ndarray                  # [world + 1] partition
+    rank: int
+    X_local: np.ndarray                 # [n_local, F]
+    labels_local: np.ndarray            # [n_local]
+    csr: List[Tuple[np.ndarray, np.ndarray]]   # this rank's rows, neighbour ids GLOBAL
+    idx_train_local: np.ndarray         # global ids of this rank's training nodes (sorted)
+    labels_train_local: np.ndarray
+    homo_deg_train: np.ndarray
+    train_pos: List[int]                # global ids of ALL training positives (replicated)
+    X_pos: np.ndarray                   # their feature rows (replicated)
+    n_train: int                        # global counts (the pick weights' LF, utils.py:276)
+    n_train_pos: int
+    meta: dict = field(default_factory=dict)
+
+
+def power_law_shard(n: int, n_edges: int, seed: int, world: int, rank: int, feat: int = 32, pos_rate: float = 0.01,
+                    split=(0.05, 0.25, 0.70), skew: float = 1.1, max_share: float = 1e-4, train_ratio: float = 0.4,
+                    chunk: int = 1 << 22, balanced: bool = True) -> ShardedWorkload:
+    """Rank `rank`'s shard of a heavy-tailed graph with BASELINE config 4's shape parameters."""
+    ids_all = np.arange(n, dtype=np.int64)
+    pop = np.random.Generator(np.random.Philox(key=seed)).pareto(skew, n) + 0.02
+    pop = np.minimum(pop, max_share * pop.sum())
+    cdf = np.cumsum(pop)
+    cdf /= cdf[-1]
+    rel_edges = [int(n_edges * s) for s in split]
+    # partition: equal expected CSR entries (popularity endpoints + the uniform ones + the self-loop), no pass over the edges
+    if balanced and world > 1:
+        m = float(sum(rel_edges))
+        exp_deg = m * pop / pop.sum() + m / n + len(rel_edges)
+        cum = np.cumsum(exp_deg)
+        cuts = np.searchsorted(cum, cum[-1] * np.arange(1, world) / world) + 1
+        bounds = np.maximum.accumulate(np.concatenate([[0], np.minimum(cuts, n), [n]])).astype(np.int64)
+    else:
+        n_per = (n + world - 1) // world
+        bounds = np.array([min(r * n_per, n) for r in range(world)] + [n], dtype=np.int64)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    n_local = hi - lo
+    labels = (_unit(seed, 1, ids_all) < pos_rate).astype(np.int64)
+    in_train = _unit(seed, 2, ids_all) < train_ratio            # (independent 40 % per node: both classes ~40 %)
+    idx_train = ids_all[in_train]
+    train_pos = idx_train[labels[idx_train] == 1]
+    csr = []
+    for r, m_r in enumerate(rel_edges):
+        keys = [np.arange(lo, hi, dtype=np.int64) * n + np.arange(lo, hi, dtype=np.int64)]       # self-loops
+        for c in range((m_r + chunk - 1) // chunk):
+            cnt = min(chunk, m_r - c * chunk)
+            gen = np.random.Generator(np.random.Philox(key=seed + 1, counter=[r, c, 0, 0]))
+            src = np.searchsorted(cdf, gen.random(cnt)).clip(0, n - 1).astype(np.int64)
+            dst = gen.integers(0, n, cnt, dtype=np.int64)
+            a = (src >= lo) & (src < hi)
+            b = (dst >= lo) & (dst < hi)
+            keys.append(src[a] * n + dst[a])
+            keys.append(dst[b] * n + src[b])
+            if m_r >= 20_000_000 and c % 8 == 7:
+                print(f"[synth] rank {rank}: relation {r} chunk {c + 1}/{(m_r + chunk - 1) // chunk}", file=sys.stderr, flush=True)
+        key = np.unique(np.concatenate(keys))
+        rows = key // n - lo
+        indptr = np.zeros(n_local + 1, dtype=np.int64)
+        np.cumsum(np.bincount(rows, minlength=n_local), out=indptr[1:])
+        csr.append((indptr, (key % n).astype(np.int32)))
+    tr_local = idx_train[(idx_train >= lo) & (idx_train < hi)]
+    homo = (sum(np.diff(ip) for ip, _ in csr) - (len(csr) - 1)).astype(np.int64)      # (duplicate edges across relations are negligible here)
+    return ShardedWorkload(
+        f"powerlaw-sharded-{n}n-{n_edges}e", n, bounds, rank, node_features(seed, np.arange(lo, hi), feat), labels[lo:hi], csr,
+        tr_local, labels[tr_local], homo[tr_local - lo], [int(v) for v in train_pos], node_features(seed, train_pos, feat),
+        int(len(idx_train)), int(len(train_pos)),
+        {"n": n, "feat": feat, "rel_edges": rel_edges, "pos_rate": pos_rate, "seed": seed,
+         "endpoints": f"pareto({skew}) x uniform, generated per rank"})

@@ -130,3 +130,28 @@ def test_balanced_partition_equalises_edges():
     assert expected_halo_rows(d, wts, 64, 1, 1000) == 1
     assert expected_halo_rows(d, wts, 64, 2, 10 ** 9) == int(np.ceil(25 * 64 * 0.5 * 1.5 + 1024))
     assert expected_halo_rows(d, wts, 64, 8, 300) == 300
+
+
+def test_sharded_generator_agrees_across_ranks():
+    """synth.power_law_shard: every rank builds its own rows of one global graph from pure functions of the seed - the shards
+    of a 3-rank run are exactly the corresponding rows of the 1-rank run (CSR rows, features, labels, replicated train-pos
+    block), the partition is in-edge balanced, and the ranks' pick weights use the same global label counts."""
+    from pcgnn_amd import synth
+    full = synth.power_law_shard(20000, 300000, 3, 1, 0, chunk=1 << 16)
+    parts = [synth.power_law_shard(20000, 300000, 3, 3, r, chunk=1 << 16) for r in range(3)]
+    assert full.bounds.tolist() == [0, 20000]
+    for r, p in enumerate(parts):
+        assert np.array_equal(p.bounds, parts[0].bounds) and p.rank == r
+        lo, hi = int(p.bounds[r]), int(p.bounds[r + 1])
+        for (ip, ix), (fip, fix) in zip(p.csr, full.csr):
+            assert np.array_equal(ix, fix[fip[lo]:fip[hi]]) and np.array_equal(ip, fip[lo:hi + 1] - fip[lo])
+            rows = np.repeat(np.arange(lo, hi), np.diff(ip))
+            assert np.all(np.diff(ix)[np.diff(rows) == 0] > 0), "neighbour ids ascending inside a row"
+            assert np.all(np.isin(np.arange(lo, hi), ix)), "self-loops kept"
+        assert np.array_equal(p.X_local, full.X_local[lo:hi]) and np.array_equal(p.labels_local, full.labels_local[lo:hi])
+        assert p.train_pos == full.train_pos and np.array_equal(p.X_pos, full.X_pos)
+        assert (p.n_train, p.n_train_pos) == (full.n_train, full.n_train_pos)
+        assert np.array_equal(p.idx_train_local, full.idx_train_local[(full.idx_train_local >= lo) & (full.idx_train_local < hi)])
+    loads = np.array([sum(len(ix) for _, ix in p.csr) for p in parts], dtype=np.float64)
+    assert loads.max() < 1.05 * loads.mean()
+    assert abs(full.X_local.std() - 1.0) < 0.02 and 0.005 < full.labels_local.mean() < 0.02
