@@ -106,9 +106,21 @@ def cpu_baseline(w, trainer, cfg, batches, n_batches):
         O.train_step(om, opt, ids.tolist(), w.labels[ids])
         spent += time.perf_counter() - t0
         nodes += len(ids)
-    return {"value": nodes / spent, "unit": "nodes/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n_batches} batches ({nodes} nodes) of the same workload, same picked ids, "
-                      f"oracle/pcgnn_oracle.py train_step (dense-mask formulation as in the reference), {spent:.1f} s"}
+    out = {"value": nodes / spent, "unit": "nodes/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"{n_batches} batches ({nodes} nodes) of the same workload, same picked ids, "
+                     f"oracle/pcgnn_oracle.py train_step (dense-mask formulation as in the reference), {spent:.1f} s"}
+    # calibration against the reference itself (tests/golden/make_cpu_calibration.py, run where the reference can be imported:
+    # the build container, 8 cores): the port's speed relative to the reference on the same graph shape and batches
+    cpath = os.path.join(ROOT, "tests", "golden", "cpu_calibration.json")
+    key = {"yelp": "yelp", "amazon": "amazon"}.get(cfg.get("workload_key", ""), None)
+    if key and os.path.exists(cpath):
+        cal = json.load(open(cpath)).get(key)
+        if cal:
+            out["port_over_reference"] = cal["port_over_reference"]
+            out["reference_equivalent"] = out["value"] / cal["port_over_reference"]
+            out["calibration"] = (f"reference {cal['reference_nodes_per_s']:.0f} vs port {cal['oracle_nodes_per_s']:.0f} nodes/s on "
+                                  f"{cal['workload']}, {cal['threads']} threads, build container")
+    return out
 
 
 def run_partitioned(args, w, B, lr, wd, dev, dist, world, rank):
@@ -221,7 +233,8 @@ def main():
     if engine == "dp":          # N>1 only: replicated graph, data-parallel batches (not the default)
         engine = "fused"
     cfg = dict(emb_size=args.emb, rho=args.rho, alpha=2.0, lr=lr, weight_decay=wd, batch_size=B,
-               seed=args.seed + 1000 * rank, engine=engine, world_size=world)
+               seed=args.seed + 1000 * rank, engine=engine, world_size=world,
+               workload_key=args.workload if (B == default_b and args.emb == 64) else "")
     tr = PCGNNTrainer(w, cfg, dev)
     torch.manual_seed(args.seed)                     # identical initial weights on every rank
     with torch.no_grad():
@@ -356,9 +369,13 @@ def main():
                 traffic = None
         out = {
             "metric": "sampled-nodes/sec", "value": nodes_total / elapsed, "unit": "nodes/s",
-            "n_gpus": world, "steps": args.steps, "warmup": warmup,
+            "n_gpus": world, "steps": args.steps, "warmup": warmup, "warmup_requested": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "timed_window": "every step = the reference's per-batch window (src/model_handler.py:143-155); the sampler - pick + "
+                            "shuffle + label lookup (:130-133), one launch per epoch - runs INSIDE the timed region at every "
+                            "epoch start, so `value` is the pick-inclusive figure (there is no separate pick-exclusive one); "
+                            "warm-up extended beyond --warmup so that every hipGraph is captured before the clock starts",
             "config": {"workload": f"{w.name} N={w.n} F={w.X.shape[1]} R={len(w.csr)} "
                                    f"edges={'/'.join(str(e) for e in w.meta['rel_edges'])} "
                                    f"endpoints={w.meta['endpoints']}, PCGNN emb={args.emb} batch={B} rho={args.rho}, "
