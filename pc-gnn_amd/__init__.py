@@ -20,7 +20,8 @@ def __getattr__(name):
     table = {
         "DeviceGraph": ".graph", "adj_to_csr": ".graph",
         "IntraAgg": ".layers", "InterAgg": ".layers", "InterAgg1": ".layers", "InterAgg3": ".layers",
-        "InterAgg5": ".layers", "PCALayer": ".model", "ops": None, "layers": None, "model": None, "graph": None,
+        "InterAgg5": ".layers", "PCALayer": ".model", "ModelHandler": ".handler", "PCGNNTrainer": ".handler",
+        "ResultManager": ".result_manager", "result_manager": None, "utils": None, "synth": None, "fused": None, "ops": None, "layers": None, "model": None, "graph": None,
         "sampler": None, "handler": None, "graphsage": None, "dist": None,
     }
     if name in table:

@@ -38,6 +38,46 @@ def adj_to_csr(adj: AdjList, n_nodes: int) -> Tuple[np.ndarray, np.ndarray]:
     return indptr, indices
 
 
+def csr_from_pairs_device(n_nodes: int, src: torch.Tensor, dst: torch.Tensor, symmetrise: bool = True,
+                          self_loops: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+    """CSR of an edge list, built ON THE DEVICE: what ``sparse_to_adjlist_for_train`` builds on the host with Python sets
+    (src/utils.py:243-254: both directions, one self-loop per node, duplicates dropped) as one sort + unique of 64-bit
+    (row, column) keys.  src / dst: integer device tensors of equal length.  Returns (indptr int64 [N + 1], indices int32
+    ascending inside a row), both on the device of `src`."""
+    dev = src.device
+    a, b = src.to(torch.int64), dst.to(torch.int64)
+    if a.numel() and (int(torch.min(torch.minimum(a, b))) < 0 or int(torch.max(torch.maximum(a, b))) >= n_nodes):
+        raise ValueError("edge endpoint out of range")
+    rows, cols = [a], [b]
+    if symmetrise:
+        rows.append(b)
+        cols.append(a)
+    if self_loops:
+        loop = torch.arange(n_nodes, dtype=torch.int64, device=dev)
+        rows.append(loop)
+        cols.append(loop)
+    key = torch.unique(torch.cat(rows) * n_nodes + torch.cat(cols))          # sorted: by row, then by column
+    r = torch.div(key, n_nodes, rounding_mode="floor")
+    indptr = torch.zeros(n_nodes + 1, dtype=torch.int64, device=dev)
+    indptr[1:] = torch.cumsum(torch.bincount(r, minlength=n_nodes), 0)
+    return indptr, (key - r * n_nodes).to(torch.int32)
+
+
+def adj_to_pairs(adj: AdjList) -> Tuple[np.ndarray, np.ndarray]:
+    """dict-of-sets -> (src, dst) int64 arrays (one pass over the dict; the sort / de-duplication happens on the device)."""
+    n_entries = sum(len(s) for s in adj.values())
+    src = np.empty(n_entries, dtype=np.int64)
+    dst = np.empty(n_entries, dtype=np.int64)
+    at = 0
+    for v, s in adj.items():
+        k = len(s)
+        if k:
+            src[at:at + k] = int(v)
+            dst[at:at + k] = np.fromiter(s, dtype=np.int64, count=k)
+            at += k
+    return src, dst
+
+
 class DeviceGraph:
     def __init__(self, X, csr: Sequence[Tuple[np.ndarray, np.ndarray]], train_pos: Sequence[int],
                  device: Optional[torch.device] = None, id_space: Optional[int] = None):
@@ -90,10 +130,40 @@ class DeviceGraph:
 
     # -- constructors ---------------------------------------------------------
     @classmethod
-    def from_adj_lists(cls, features_weight, adj_lists: Sequence[AdjList], train_pos, device=None):
+    def from_adj_lists(cls, features_weight, adj_lists: Sequence[AdjList], train_pos, device=None, build_on_device: bool = True):
+        """From the reference's input format (list of dict[int -> set[int]] incl. self-loops, src/utils.py:226-239).  The
+        dicts are flattened in one host pass; sorting / de-duplicating the rows happens on the device
+        (``csr_from_pairs_device``) unless ``build_on_device=False`` (per-row host sort, ``adj_to_csr``)."""
         n = int(features_weight.shape[0])
-        return cls(features_weight.detach().cpu() if torch.is_tensor(features_weight) else features_weight,
-                   [adj_to_csr(a, n) for a in adj_lists], train_pos, device)
+        X = features_weight.detach().cpu() if torch.is_tensor(features_weight) else features_weight
+        if not build_on_device:
+            return cls(X, [adj_to_csr(a, n) for a in adj_lists], train_pos, device)
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if dev.type != "cuda":
+            raise _lib.PcgnnLibraryError("DeviceGraph needs a GPU device: the PC-GNN hot path has no CPU fallback")
+        csr = []
+        for a in adj_lists:
+            src, dst = adj_to_pairs(a)
+            ip, ix = csr_from_pairs_device(n, torch.from_numpy(src).to(dev), torch.from_numpy(dst).to(dev),
+                                           symmetrise=False, self_loops=False)       # the reference's dicts are complete already
+            csr.append((ip.cpu().numpy(), ix.cpu().numpy()))
+        return cls(X, csr, train_pos, dev)
+
+    @classmethod
+    def from_scipy(cls, features_weight, matrices, train_pos, device=None):
+        """From scipy sparse adjacency matrices (what data_process.py reads from the .mat files): symmetrised, self-loops
+        added, duplicates dropped on the device (src/utils.py:243-254 semantics)."""
+        import scipy.sparse as sp
+        n = int(features_weight.shape[0])
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        csr = []
+        for m in matrices:
+            coo = sp.coo_matrix(m)
+            ip, ix = csr_from_pairs_device(n, torch.from_numpy(coo.row.astype(np.int64)).to(dev),
+                                           torch.from_numpy(coo.col.astype(np.int64)).to(dev))
+            csr.append((ip.cpu().numpy(), ix.cpu().numpy()))
+        X = features_weight.detach().cpu() if torch.is_tensor(features_weight) else features_weight
+        return cls(X, csr, train_pos, dev)
 
     # -- C ABI view -------------------------------------------------------------
     @property

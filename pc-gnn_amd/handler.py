@@ -121,3 +121,175 @@ class PCGNNTrainer:
         torch.cuda.synchronize(self.device)
         t1 = time.perf_counter()
         return self.pick_size, t1 - t0, t1 - t_all
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ModelHandler: the reference's experiment driver (src/model_handler.py:24-178) over the HIP path
+# ---------------------------------------------------------------------------------------------------------------------
+FIRST_LABELED = {"amazon": 3305, "amazon_new": 2013}      # model_handler.py:38-40: the unlabeled Amazon users come first
+
+
+def _csr_of(adj, n):
+    """one relation in any of the accepted forms -> (indptr, indices): a (indptr, indices) pair, or the reference's
+    dict[int -> set[int]] (src/utils.py:226-239)"""
+    if isinstance(adj, (tuple, list)) and len(adj) == 2 and hasattr(adj[0], "shape"):
+        return np.asarray(adj[0], dtype=np.int64), np.asarray(adj[1], dtype=np.int32)
+    from .graph import adj_to_csr
+    return adj_to_csr(adj, n)
+
+
+class ModelHandler(object):
+    """``ModelHandler(config).train() -> (auc_test, recall_test, f1_macro_test)`` with the reference's config keys
+    (generate_exp_config.ipynb:50-66): data_name, model (PCGNN | SAGE | GCN), seed, train_ratio, test_ratio, emb_size, rho,
+    alpha, lr, weight_decay, batch_size, epochs, valid_epochs, patience (+ exp_num, kept for bookkeeping).
+
+    The reference reads its datasets from files that exist nowhere offline (``load_data``, src/utils.py:66-207), so the
+    graph is handed in: ``dataset = (homo, relation_list, feat_data, labels)`` - exactly what ``load_data`` returns
+    (dict-of-sets adjacencies, or (indptr, indices) pairs) - or a ``synth.Workload``.  Everything after that follows the
+    reference: seeded stratified train / valid / test split (:36-48, ``utils.split_dataset``), ``pos_neg_split`` (:56),
+    Amazon feature normalisation (:59-60), model construction (:85-122), Adam (:124), the epoch loop with the pick sampler
+    (:128-156), validation every ``valid_epochs`` with the gain rule and the best checkpoint (:158-169), patience (:170-173),
+    restore + final test (:175-178), ``ResultManager`` logs.  One difference: pick and shuffle draw from the device
+    generator (Philox), not from Python's ``random`` - the same distribution, not the same draws."""
+
+    def __init__(self, config, dataset=None, device=None):
+        import argparse
+        import random
+        from .result_manager import EXP_RES_DIR, ResultManager
+        from . import utils as U
+        self.result = ResultManager(args=config, root=config.get("result_dir", EXP_RES_DIR))
+        args = argparse.Namespace(**config)
+        if dataset is None:
+            raise FileNotFoundError(
+                f"dataset '{args.data_name}': the reference loads ./data/pyg/... files (src/utils.py:66-207) that are not part of "
+                f"either tree; pass dataset=(homo, relation_list, feat_data, labels) or a synth.Workload")
+        if hasattr(dataset, "csr"):                 # synth.Workload
+            w = dataset
+            homo_deg = np.asarray(w.homo_deg, dtype=np.int64)
+            relation_list, feat_data, labels = list(w.csr), np.asarray(w.X), np.asarray(w.labels)
+            homo = None
+        else:
+            homo, relation_list, feat_data, labels = dataset
+            feat_data, labels = np.asarray(feat_data), np.asarray(labels)
+            homo_deg = None
+        n = feat_data.shape[0]
+        np.random.seed(args.seed)                                                                    # :35-36
+        random.seed(args.seed)
+        first = FIRST_LABELED.get(args.data_name, 3305 if str(args.data_name).startswith("amazon") else 0)
+        idx_train, y_train, idx_valid, y_valid, idx_test, y_test = U.split_dataset(labels, args.train_ratio, args.test_ratio,
+                                                                                    args.seed, first)   # :36-48
+        print(f"Run on {args.data_name}, postive/total num: {np.sum(labels)}/{len(labels)}, train num {len(y_train)},"
+              f"valid num {len(y_valid)}, test num {len(y_test)}, test positive num {np.sum(y_test)}")       # :50-51
+        print(f"Feature dimension: {feat_data.shape[1]}")
+        train_pos, train_neg = U.pos_neg_split(idx_train, y_train)                                    # :56
+        if str(args.data_name).startswith("amazon"):                                                   # :59-60
+            feat_data = np.asarray(U.normalize(feat_data), dtype=np.float32)
+        self.relations = [_csr_of(a, n) for a in relation_list]
+        if homo is not None:
+            self.homo = _csr_of(homo, n)
+            homo_deg = np.diff(self.homo[0])
+        else:                                       # union of the relations (what the reference's homo pickle holds)
+            keys = np.unique(np.concatenate([np.repeat(np.arange(n, dtype=np.int64), np.diff(ip)) * n + ix for ip, ix in self.relations]))
+            rows = keys // n
+            hp = np.zeros(n + 1, dtype=np.int64)
+            np.cumsum(np.bincount(rows, minlength=n), out=hp[1:])
+            self.homo = (hp, (keys - rows * n).astype(np.int32))
+        print(f"Model: {args.model}, emb_size: {args.emb_size}.")                                       # :68
+        self.args = args
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.dataset = {"feat_data": feat_data.astype(np.float32), "labels": labels, "homo_deg": homo_deg,
+                        "idx_train": idx_train, "idx_valid": idx_valid, "idx_test": idx_test,
+                        "y_train": y_train, "y_valid": y_valid, "y_test": y_test,
+                        "train_pos": train_pos, "train_neg": train_neg}
+
+    def _build(self):
+        """model construction (:85-122)"""
+        from . import graphsage as GS
+        from .fused import FusedPCGNN
+        from .layers import InterAgg1, InterAgg3, InterAgg5
+        args, ds, dev = self.args, self.dataset, self.device
+        feat_data = ds["feat_data"]
+        n, f = feat_data.shape
+        features = nn.Embedding(n, f)
+        features.weight = nn.Parameter(torch.from_numpy(feat_data), requires_grad=False)                # :85-86
+        if args.model == "PCGNN":
+            graph = DeviceGraph(feat_data, self.relations, ds["train_pos"], dev)
+            intras = [IntraAgg(features, f, args.emb_size, ds["train_pos"], args.rho, cuda=True) for _ in self.relations]
+            cls = {1: InterAgg1, 3: InterAgg3, 5: InterAgg5}.get(len(intras), InterAgg)                 # :103-113
+            inter = cls(features, f, args.emb_size, ds["train_pos"], graph, intras, cuda=True)
+            model = PCALayer(2, inter, args.alpha).to(dev)                                              # :114, :122
+            engine = FusedPCGNN(model, args.lr, args.weight_decay, max_batch=args.batch_size)          # :124 (Adam, fused)
+            return model, engine, None
+        graph = DeviceGraph(feat_data, [self.homo], [], dev)
+        if args.model == "SAGE":                                                                        # :96-98, :115-118
+            enc = GS.Encoder(features, f, args.emb_size, graph, GS.MeanAggregator(features, cuda=True), gcn=True, cuda=True)
+            model = GS.GraphSage(2, enc)
+        elif args.model == "GCN":                                                                       # :99-101, :119-120
+            enc = GS.GCNEncoder(features, f, args.emb_size, graph, GS.GCNAggregator(features, cuda=True), cuda=True)
+            model = GS.GCN(2, enc)
+        else:
+            raise ValueError(f"model {args.model!r}: PCGNN, SAGE or GCN")
+        model = model.to(dev)
+        opt = torch.optim.Adam(filter(lambda p: p.requires_grad, model.parameters()), lr=args.lr, weight_decay=args.weight_decay)
+        return model, None, opt
+
+    def train(self):
+        import random
+        from . import utils as U
+        args, ds, dev = self.args, self.dataset, self.device
+        idx_train, y_train = ds["idx_train"], ds["y_train"]
+        model, engine, opt = self._build()
+        labels_dev = torch.from_numpy(np.asarray(ds["labels"]).astype(np.int32)).to(dev)
+        auc_best, f1_mac_best, epoch_best = 1e-10, 1e-10, 0                                              # :125
+        saved = False
+        if engine is not None:
+            sampler = PickSampler(idx_train, y_train, ds["homo_deg"][np.asarray(idx_train)], dev, seed=args.seed)
+            pick_size = 2 * len(ds["train_pos"])                                                        # :130
+            epoch_dev = torch.zeros(2, dtype=torch.int64, device=dev)
+        self.epoch_time = []
+        epoch = -1
+        for epoch in range(args.epochs):                                                                 # :128
+            t0 = time.perf_counter()
+            if engine is not None:
+                # pick + shuffle + label lookup on the device, then every batch of the epoch (the last one partial; the
+                # empty batch the reference's int(len / B) + 1 can produce is not run): one graph launch
+                engine.stage_epoch(pick_size, args.batch_size)
+                engine.epoch_run(sample=lambda: sampler.pick_shuffled(pick_size, engine._ep_ids[:pick_size], labels_dev,
+                                                                       engine._ep_lab[:pick_size], epoch_counter=epoch_dev,
+                                                                       bump=True))
+            else:
+                sampled = list(idx_train)                                                                # :132-133
+                random.shuffle(sampled)
+                for b0 in range(0, len(sampled), args.batch_size):
+                    batch_nodes = sampled[b0:b0 + args.batch_size]
+                    opt.zero_grad()
+                    loss = model.loss(batch_nodes, labels_dev[torch.as_tensor(batch_nodes, device=dev)].long())
+                    loss.backward()
+                    opt.step()
+            self.epoch_time.append(time.perf_counter() - t0)                                              # (:155; enqueue time only)
+            if (epoch + 1) % args.valid_epochs == 0:                                                      # :158-169
+                print("Valid at epoch {}".format(epoch))
+                auc_val, recall_val, f1_mac_val, precision_val = U.test(ds["idx_valid"], ds["y_valid"], engine or model,
+                                                                        args.batch_size, self.result, epoch, epoch_best, flag="val")
+                gain_auc = (auc_val - auc_best) / auc_best
+                gain_f1_mac = (f1_mac_val - f1_mac_best) / f1_mac_best
+                if (gain_auc + gain_f1_mac) > 0:
+                    f1_mac_best, auc_best, epoch_best = f1_mac_val, auc_val, epoch
+                    if engine is not None:
+                        engine.flush()
+                    torch.save(model.state_dict(), self.result.model_path)
+                    saved = True
+            if (epoch - epoch_best) > args.patience:                                                      # :170-173
+                print(f"Early stopping at epoch {epoch}")
+                break
+        if engine is not None:
+            engine.check()
+        print("Restore model from epoch {}".format(epoch_best))                                          # :175-177
+        if saved:
+            if engine is not None:
+                engine.flush()
+            model.load_state_dict(torch.load(self.result.model_path, weights_only=True))
+        auc_test, recall_test, f1_mac_test, precision_test = U.test(ds["idx_test"], ds["y_test"], engine or model, args.batch_size,
+                                                                    self.result, epoch_best=epoch_best, flag="test")
+        self.model, self.engine, self.epoch_best, self.last_epoch = model, engine, epoch_best, epoch
+        return auc_test, recall_test, f1_mac_test

@@ -182,3 +182,76 @@ def set_seeds(seed):
     torch.manual_seed(seed)
     if torch.cuda.is_available():
         torch.cuda.manual_seed_all(seed)
+
+
+# ---- stratified train / valid / test split (src/model_handler.py:36-48) ------------------------------------------------------
+def _approximate_mode(class_counts: np.ndarray, n_draws: int, rng: np.random.RandomState) -> np.ndarray:
+    """How many of n_draws go to every class: proportional, the remainders settled largest first with random tie-breaks
+    (scikit-learn 1.7 ``utils/_approximate_mode``; consumes the generator exactly as it does)."""
+    continuous = class_counts / class_counts.sum() * n_draws
+    floored = np.floor(continuous)
+    need = int(n_draws - floored.sum())
+    if need > 0:
+        remainder = continuous - floored
+        for value in np.sort(np.unique(remainder))[::-1]:
+            (inds,) = np.where(remainder == value)
+            add_now = min(len(inds), need)
+            inds = rng.choice(inds, size=add_now, replace=False)
+            floored[inds] += 1
+            need -= add_now
+            if need == 0:
+                break
+    return floored.astype(int)
+
+
+def train_test_split(index, labels, stratify, train_size: Optional[float] = None, test_size: Optional[float] = None,
+                     random_state: int = 0, shuffle: bool = True):
+    """``sklearn.model_selection.train_test_split(index, labels, stratify=labels, train_size=... | test_size=...,
+    random_state=seed, shuffle=True)`` restated (scikit-learn 1.7: one StratifiedShuffleSplit draw) so that the splits
+    the reference makes (model_handler.py:42-43, 47-48) can be reproduced without scikit-learn: same generator
+    (``np.random.RandomState(seed)``), same order of draws, same outputs - checked against scikit-learn in the tests.
+    Returns (idx_train, idx_test, y_train, y_test) as lists / arrays like the reference consumes them."""
+    assert shuffle and stratify is not None
+    index, labels, y = list(index), np.asarray(labels), np.asarray(stratify)
+    n = len(index)
+    if test_size is None and train_size is None:
+        test_size = 0.25
+    # scikit-learn's _validate_shuffle_split for float sizes
+    n_test = int(np.ceil(test_size * n)) if test_size is not None else None
+    n_train = int(np.floor(train_size * n)) if train_size is not None else None
+    if n_train is None:
+        n_train = n - n_test
+    elif n_test is None:
+        n_test = n - n_train
+    if n_train + n_test > n or n_train <= 0:
+        raise ValueError("train_size / test_size do not fit the number of samples")
+    rng = np.random.RandomState(random_state)
+    classes, y_indices = np.unique(y, return_inverse=True)
+    class_counts = np.bincount(y_indices)
+    if class_counts.min() < 2:
+        raise ValueError("The least populated class in y has only 1 member, which is too few.")
+    if n_train < len(classes) or n_test < len(classes):
+        raise ValueError("fewer samples than classes in one side of the split")
+    class_indices = np.split(np.argsort(y_indices, kind="mergesort"), np.cumsum(class_counts)[:-1])
+    n_i = _approximate_mode(class_counts, n_train, rng)
+    t_i = _approximate_mode(class_counts - n_i, n_test, rng)
+    train, test = [], []
+    for i in range(len(classes)):
+        perm = class_indices[i].take(rng.permutation(class_counts[i]), mode="clip")
+        train.extend(perm[:n_i[i]])
+        test.extend(perm[n_i[i]:n_i[i] + t_i[i]])
+    train, test = rng.permutation(train), rng.permutation(test)
+    pick = lambda seq, ids: [seq[i] for i in ids]
+    return pick(index, train), pick(index, test), labels[train], labels[test]
+
+
+def split_dataset(labels, train_ratio: float, test_ratio: float, seed: int, first_labeled: int = 0):
+    """The reference's train / valid / test split (model_handler.py:36-48): nodes [first_labeled, N) (Amazon: the first 3305 -
+    amazon_new: 2013 - are unlabeled), ``train_ratio`` of them for training, ``test_ratio`` of the rest for testing, both
+    stratified, both seeded with ``seed``.  Returns idx_train, y_train, idx_valid, y_valid, idx_test, y_test."""
+    labels = np.asarray(labels)
+    index = list(range(first_labeled, len(labels)))
+    lab = labels[first_labeled:]
+    idx_train, idx_rest, y_train, y_rest = train_test_split(index, lab, stratify=lab, train_size=train_ratio, random_state=seed)
+    idx_valid, idx_test, y_valid, y_test = train_test_split(idx_rest, y_rest, stratify=y_rest, test_size=test_ratio, random_state=seed)
+    return idx_train, y_train, idx_valid, y_valid, idx_test, y_test

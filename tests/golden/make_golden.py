@@ -313,8 +313,28 @@ def kat_case():
     print("kat:", {k: (v if not hasattr(v, "shape") else v.tolist()) for k, v in out.items() if "out" in k or "kept" in k})
 
 
+def split_case():
+    """The reference's train / valid / test split (src/model_handler.py:36-48): two stratified
+    ``sklearn.model_selection.train_test_split`` calls, run here with scikit-learn itself."""
+    from sklearn.model_selection import train_test_split
+    out = {}
+    rs = np.random.RandomState(4)
+    for tag, n, rate, first, train_ratio, seed in (("yelp", 4000, 0.1453, 0, 0.4, 2), ("amazon", 1500, 0.0687, 300, 0.1, 7),
+                                                   ("tiny", 90, 0.3, 0, 0.05, 11)):
+        labels = (rs.rand(n) < rate).astype(np.int64)
+        index = list(range(first, n))
+        a = train_test_split(index, labels[first:], stratify=labels[first:], train_size=train_ratio, random_state=seed, shuffle=True)
+        b = train_test_split(a[1], a[3], stratify=a[3], test_size=0.67, random_state=seed, shuffle=True)
+        out[f"{tag}_labels"], out[f"{tag}_first"], out[f"{tag}_train_ratio"], out[f"{tag}_seed"] = labels, first, train_ratio, seed
+        out[f"{tag}_idx_train"], out[f"{tag}_idx_valid"], out[f"{tag}_idx_test"] = np.array(a[0]), np.array(b[0]), np.array(b[1])
+        out[f"{tag}_y_train"], out[f"{tag}_y_valid"], out[f"{tag}_y_test"] = a[2], b[2], b[3]
+    np.savez_compressed(os.path.join(HERE, "split.npz"), **out)
+    print("split:", {k: len(v) for k, v in out.items() if k.endswith("idx_train")})
+
+
 if __name__ == "__main__":
     kat_case()
+    split_case()
     pcgnn_case("yelp_small", seed=3, n=1500, f=32, rel_deg=(2.5, 9, 28), pos_rate=0.145, emb=64, batch=256,
                rhos=(0.5, 0.2, 0.8, 2.0))
     pcgnn_case("amazon_small", seed=5, n=900, f=25, rel_deg=(8, 40, 20), pos_rate=0.09, emb=64, batch=128,

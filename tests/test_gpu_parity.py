@@ -874,3 +874,78 @@ def test_realloc_between_epoch_graphs(P):
     torch.cuda.synchronize()
     for name in ("theta", "m", "v", "step_counter"):
         assert torch.equal(getattr(a.fused, name), getattr(b.fused, name)), name
+
+
+# ---------------------------------------------------------------------------
+# ingestion on the device, the reference's experiment driver
+# ---------------------------------------------------------------------------
+def test_device_csr_build_matches_oracle(P):
+    """csr_from_pairs_device (sort + unique of (row, column) keys on the GPU) == oracle.adj_to_csr of the dict-of-sets the
+    reference's sparse_to_adjlist_for_train builds (src/utils.py:243-254: symmetric, self-loops, no duplicates);
+    DeviceGraph.from_adj_lists / from_scipy give the graph the host build gives."""
+    import scipy.sparse as sp
+    from pcgnn_amd.graph import adj_to_pairs, csr_from_pairs_device
+    from pcgnn_amd import utils as U
+    rs = np.random.RandomState(0)
+    for n, m in ((1, 0), (300, 900), (5000, 60000)):
+        src, dst = rs.randint(0, n, m), rs.randint(0, n, m)
+        adj = {v: {v} for v in range(n)}
+        for a, b in zip(src.tolist(), dst.tolist()):
+            adj[a].add(b)
+            adj[b].add(a)
+        want_ip, want_ix = O.adj_to_csr(adj, n)
+        ip, ix = csr_from_pairs_device(n, torch.from_numpy(src).cuda(), torch.from_numpy(dst).cuda())
+        assert ip.is_cuda and np.array_equal(ip.cpu().numpy(), want_ip) and np.array_equal(ix.cpu().numpy(), want_ix)
+        # the reference's dicts (already symmetric, with self-loops) through the DeviceGraph constructors
+        X = rs.randn(n, 8).astype(np.float32)
+        g_dev = P.DeviceGraph.from_adj_lists(torch.from_numpy(X), [adj], [], dev())
+        g_host = P.DeviceGraph.from_adj_lists(torch.from_numpy(X), [adj], [], dev(), build_on_device=False)
+        assert torch.equal(g_dev.indptr[0], g_host.indptr[0]) and torch.equal(g_dev.indices[0], g_host.indices[0])
+        if m:
+            mat = sp.csr_matrix((np.ones(m), (src, dst)), shape=(n, n))
+            g_sp = P.DeviceGraph.from_scipy(torch.from_numpy(X), [mat], [], dev())
+            hip, hix = U.sparse_to_csr(mat)
+            assert np.array_equal(g_sp.indptr[0].cpu().numpy(), hip) and np.array_equal(g_sp.indices[0].cpu().numpy(), hix)
+            assert np.array_equal(hip, want_ip) and np.array_equal(hix, want_ix)
+
+
+@pytest.mark.parametrize("model_name", ["PCGNN", "SAGE", "GCN"])
+def test_model_handler_train_loop(P, model_name, tmp_path):
+    """ModelHandler(config).train() (src/model_handler.py:24-178): split, epochs with the pick sampler, validation every
+    valid_epochs with the gain rule, best checkpoint, patience, restore, final test, ResultManager logs - on a synthetic
+    dataset handed over in load_data's return format."""
+    import pandas as pd
+    from pcgnn_amd import synth
+    from pcgnn_amd.handler import ModelHandler
+    w = synth.make_workload("mini", 3000, 32, (2500, 12000, 30000), 0.15, seed=4)
+    # features that carry the label: the loop has something to learn
+    w.X[:, 0] += 2.0 * w.labels
+    adj = [csr_to_adj(c, w.n) for c in w.csr]
+    homo = {v: set().union(*[a[v] for a in adj]) for v in range(w.n)}
+    cfg = dict(data_name="yelp", model=model_name, seed=3, train_ratio=0.4, test_ratio=0.67, emb_size=32, lr=0.01, weight_decay=0.001,
+               alpha=2, rho=0.5, epochs=12, valid_epochs=2, batch_size=256, patience=3, exp_num="0000",
+               result_dir=str(tmp_path / "experimental_results"))
+    h = ModelHandler(cfg, dataset=(homo, adj, w.X, w.labels), device=dev())
+    ds = h.dataset
+    assert len(ds["idx_train"]) == int(0.4 * w.n) and len(set(ds["idx_train"]) & set(ds["idx_test"])) == 0
+    assert len(ds["idx_valid"]) + len(ds["idx_test"]) + len(ds["idx_train"]) == w.n
+    assert ds["train_pos"] == [v for v, l in zip(ds["idx_train"], ds["y_train"]) if l == 1]
+    auc, recall, f1m = h.train()
+    assert 0.0 <= auc <= 1.0 and 0.0 <= recall <= 1.0 and 0.0 < f1m <= 1.0
+    if model_name == "PCGNN":            # (its self features carry the label; the baselines see them only averaged over ~30 neighbours)
+        assert auc > 0.7
+    assert h.epoch_best % 2 == 1 and h.last_epoch <= 11                      # validated at epochs 1, 3, 5, ...
+    assert h.last_epoch == 11 or h.last_epoch - h.epoch_best > 3               # ran out of epochs, or stopped by patience
+    # best checkpoint: saved with the reference's state-dict keys, and what the model holds after train()
+    sd = torch.load(h.result.model_path, weights_only=True)
+    for k, v in h.model.state_dict().items():
+        assert torch.equal(v.cpu(), sd[k].cpu()), k
+    if model_name == "PCGNN":
+        assert {"weight", "inter1.weight", "inter1.label_clf.weight", "inter1.intra_agg3.weight", "inter1.features.weight"} <= set(sd)
+    val = open(h.result.log_val_path).read()
+    assert val.count("Validation performance") == (h.last_epoch + 1) // 2 and "[Epoch-001] Validation performance" in val
+    assert "Test performance: - Epoch_Best: %d\t- F1:" % h.epoch_best in open(h.result.log_test_path).read()
+    dt = pd.read_pickle(h.result.df_test_path)
+    assert len(dt) == 1 and abs(dt["auc"].iloc[0] - auc) < 1e-9 and dt["model"].iloc[0] == model_name
+    with pytest.raises(FileNotFoundError):
+        ModelHandler(cfg)                                                     # (no dataset files exist offline)
