@@ -383,7 +383,7 @@ def main():
                        "global_batch": B * world, "parallelism": "single" if world == 1 else f"dp{world}-replicated-graph",
                        "engine": engine,
                        "nodes_processed": int(nodes_total)},
-            "roofline": {"bound": "hbm", "kernel": "pcg_choose_aggregate_planned (select_rows + gather_chunks + combine_rows; the plan rides along the score pass and the sort in pcg_step_front)", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "pcg_choose_gather_planned (select_rows + gather_chunks; the plan rides along the score pass and the sort in pcg_step_front_train, multi-chunk sums are finished in the dense kernel's prologue)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": float(np.mean(abytes)),
                          "launches_timed": len(kern_ms)},

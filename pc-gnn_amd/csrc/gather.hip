@@ -68,7 +68,8 @@ __global__ void __launch_bounds__(256) gather_chunks(const AggArgs a) {
     // four (count -> row -> offsets -> list).  n = the entries of the chunk the select kernel filled (it overwrites the
     // capacity share the plan put there; nothing fills a region's unused tail).
     int4 desc = a.chunk_desc[ch0 < (uint32_t)a.chunk_cap ? ch0 : 0u];
-    const uint32_t total = *a.n_chunks;
+    uint32_t total = *a.n_chunks;
+    total = total < (uint32_t)a.chunk_cap ? total : (uint32_t)a.chunk_cap;      // (a device-side counter never indexes unchecked)
     for (uint32_t ch = ch0; ch < total; ch += nwaves) {
         if (ch != ch0) desc = a.chunk_desc[ch];
         const int row = desc.x, n = desc.z, nch_row = desc.w;

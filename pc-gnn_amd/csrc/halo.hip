@@ -21,6 +21,7 @@ struct HaloArgs {
     int32_t *list;
     const int4 *chunk_desc;
     const uint32_t *n_chunks;        // device word (the plan's chunk count)
+    uint32_t chunk_cap;              // entries of chunk_desc (a device-side counter never indexes unchecked)
     int32_t lo, hi, n_local;
     const int32_t *pos_ids;          // [n_pos] train-pos ids ascending
     const int32_t *pos_idx;          // [n_pos] their row in the replicated train-pos block
@@ -62,7 +63,7 @@ __global__ void __launch_bounds__(256) halo_classify_kernel(const HaloArgs a) {
     __syncthreads();
     const int lane = lane_id();
     const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
-    const uint32_t total = *a.n_chunks;
+    const uint32_t total = *a.n_chunks < a.chunk_cap ? *a.n_chunks : a.chunk_cap;
     for (uint32_t ch = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); ch < total; ch += nwaves) {
         const int4 desc = a.chunk_desc[ch];
         for (int i = lane; i < desc.z; i += PCG_WAVE) {
@@ -126,14 +127,14 @@ __global__ void __launch_bounds__(256) halo_assign_kernel(const HaloArgs a) {
         const int o = owner_of(s_bounds, a.world, (int32_t)key);
         const uint32_t slot = s_off[o] + atomicAdd(&a.owner_fill[o], 1u);
         a.vals[h] = slot;
-        if (fits) a.uniq[slot] = (int32_t)key;
+        if (fits && slot < (uint32_t)a.halo_cap) a.uniq[slot] = (int32_t)key;     // (a device-side counter never indexes unchecked)
     }
 }
 
 __global__ void __launch_bounds__(256) halo_remap_kernel(const HaloArgs a) {
     const int lane = lane_id();
     const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
-    const uint32_t total = *a.n_chunks;
+    const uint32_t total = *a.n_chunks < a.chunk_cap ? *a.n_chunks : a.chunk_cap;
     for (uint32_t ch = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); ch < total; ch += nwaves) {
         const int4 desc = a.chunk_desc[ch];
         for (int i = lane; i < desc.z; i += PCG_WAVE) {
@@ -182,6 +183,7 @@ static int halo_args(pcg::HaloArgs &a, const pcg_graph_desc *g, int32_t B, void 
     a.list = w.list;
     a.chunk_desc = w.chunk_desc;
     a.n_chunks = w.counters + pcg::C_NCHUNK;
+    a.chunk_cap = (uint32_t)w.chunk_cap;
     a.lo = lo;
     a.hi = hi;
     a.n_local = n_local;
@@ -231,6 +233,7 @@ int pcg_halo_remap(const pcg_graph_desc *g, int32_t B, void *workspace, int64_t 
     a.list = w.list;
     a.chunk_desc = w.chunk_desc;
     a.n_chunks = w.counters + pcg::C_NCHUNK;
+    a.chunk_cap = (uint32_t)w.chunk_cap;
     a.keys = table;
     a.vals = table + table_slots;
     a.mask = (uint32_t)(table_slots - 1);

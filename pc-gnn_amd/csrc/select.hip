@@ -718,7 +718,10 @@ __device__ __forceinline__ void select_wg_row(const ChooseArgs &a, int row, uint
             if (tid == 0) res[3] = 0;
             __syncthreads();
             for_keys<LDSK>(keys, nbr, s0, c, tid, d, NT, [&](int, uint32_t key) {
-                if (key >= lo && key <= hi) cand[atomicAdd(&res[3], 1)] = key;
+                if (key >= lo && key <= hi) {
+                    const int at = atomicAdd(&res[3], 1);
+                    if (at < PCG_WAVE) cand[at] = key;          // (cnt <= 64 by construction; a counter never indexes unchecked)
+                }
             });
             __syncthreads();
             const bool hv = lane < cnt;

@@ -9,7 +9,7 @@ import json
 import sys
 from collections import defaultdict
 
-CALL_KERNELS = ("select_rows", "gather_chunks", "combine_rows")      # the launches of pcg_choose_aggregate_planned
+CALL_KERNELS = ("select_rows", "gather_chunks", "combine_rows")      # the launches of the select + aggregate call (the training engine's pcg_choose_gather_planned has no combine_rows: its sums are finished in the dense kernel)
 WIDE_READERS = ("gather_chunks",)                                     # 16 B per lane: FETCH_SIZE x 2
 
 
