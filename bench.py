@@ -57,6 +57,8 @@ def parse():
                     "instead of staging the whole epoch (A/B switch)")
     ap.add_argument("--force-partitioned", action="store_true",
                     help="run the node-partitioned RCCL path even at world size 1 (rehearsal of the N>1 code)")
+    ap.add_argument("--window", type=int, default=8, help="partitioned path: steps per halo prefetch (feature rows never change, "
+                    "so the remote rows of a window's centres are fetched once)")
     ap.add_argument("--event-every", type=int, default=10,
                     help="graph engine: bracket the select+aggregate launch with HIP events on every step of every Nth epoch")
     ap.add_argument("--engine", default=None, choices=["graph", "fused", "torch", "dp"],
@@ -124,57 +126,66 @@ def cpu_baseline(w, trainer, cfg, batches, n_batches):
 
 
 def run_partitioned(args, w, B, lr, wd, dev, dist, world, rank):
-    """N > 1: destination-node partition, RCCL all-gather of scores + all-to-all of remote neighbour rows +
+    """N > 1: destination-node partition, RCCL all-to-all of remote neighbour rows (once per window of steps) +
     gradient all-reduce (pc-gnn_amd/dist.py).  Weak scaling: every rank trains batches of B centres it owns."""
     from pcgnn_amd.dist import DistributedPCGNN
     cfg = dict(emb_size=args.emb, rho=args.rho, alpha=2.0, lr=lr, weight_decay=wd, batch_size=B, seed=args.seed)
-    d = DistributedPCGNN(w, cfg, dev)
+    W = max(1, args.window)
+    d = DistributedPCGNN(w, cfg, dev, window=W)
     n_nodes, feat, n_rel = w.n, d.F, d.R
 
-    def one_step(k):
-        ids = d.pick_epoch(B, k)
-        d.train_step(ids, d.labels_of(ids))
+    def run_steps(first, n):
+        """n steps in windows of W: one pick + one halo prefetch (two all-to-alls) per window, then per step one graph
+        replay + the gradient all-reduce + Adam.  No host synchronisation anywhere."""
+        k = 0
+        while k < n:
+            m = min(W, n - k)
+            ids = d.pick_epoch(m * B, first + k)
+            lab = d.labels_of(ids)
+            d.begin_window(ids)
+            for i in range(m):
+                d.train_step(ids[i * B:(i + 1) * B], lab[i * B:(i + 1) * B])
+            k += m
 
     def barrier():
         dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for k in range(args.warmup):
-        one_step(k)
+    run_steps(0, args.warmup)
     prof = d.profile_select(args.event_every) if rank == 0 else None
     barrier()
     t0 = time.perf_counter()
-    halo_rows = remote = entries = 0
-    for k in range(args.steps):
-        one_step(args.warmup + k)
-        st = d.halo.last_stats
-        halo_rows += st["halo_rows"]; remote += st.get("rows_served", 0); entries += st["bytes_in"]
+    run_steps(args.warmup, args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
+    d.check()                               # raises on every rank if any rank's exchange / lists went over capacity
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    stats = torch.tensor([halo_rows, remote, entries], dtype=torch.float64, device=dev)
-    fr = d.feature_rows
-    mem = torch.tensor([fr["owned"] + fr["train_pos"] + fr["halo"], d.halo.max_seen["halo_rows"], fr["halo"]],
-                       dtype=torch.float64, device=dev)
+    fr, seen = d.feature_rows, d.halo.max_seen
+    # rows a step's exchange moves per rank: the fixed-pitch buffers (what the all-to-alls carry) and the rows really asked for
+    stats = torch.tensor([seen["halo_rows"], int((d.halo.req_in >= 0).sum().item()), fr["halo"] * d.g.X.shape[1] * 4],
+                         dtype=torch.float64, device=dev)
+    mem = torch.tensor([fr["owned"] + fr["train_pos"] + fr["halo"], seen["halo_rows"], fr["halo"], seen["rows_from_one_owner"],
+                        fr["halo_pitch"]], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(stats)
     dist.all_reduce(mem, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     nodes_total = args.steps * B * world
     if rank == 0:
-        hr, rm, en = (float(x) / (args.steps * world) for x in stats.tolist())
-        # roofline of the dominant launch of this path: the select segment (train-pos sort + plan + select_rows), rank 0
+        hr, rm, en = (float(x) / world for x in stats.tolist())
+        # roofline of this path's one launch per step - the captured graph (score pass over the rank's table, plan, train-pos
+        # sort, select, look-up, gather, dense step, slab sum) - on rank 0: the select + gather bytes of algorithmic_bytes()
+        # plus the score pass's table stream
         ms, ab = [], []
         g = d.g
         for e0, e1, ids_l, cnt in prof:
             ms.append(e0.elapsed_time(e1))
             ids_h = ids_l.cpu().numpy().astype(np.int64)
-            deg = [g.deg_host[r][ids_h].astype(np.int64).sum() for r in range(g.R)]
-            ab.append(sum(4 * (2 * len(ids_h) + int(x)) + 4 * int(x) for x in deg) + 4 * int(cnt.sum().item()) + 8 * g.n_pos)
+            ab.append(algorithmic_bytes(g, ids_h, cnt.view(g.R, -1).cpu().numpy()) + 4 * g.X.shape[0] * g.feat_dim)
         avg_ms = float(np.mean(ms)) if ms else float("nan")
         achieved = float(np.mean(ab)) / (avg_ms * 1e-3) / 1e9 if ms else float("nan")
-        roofline = {"bound": "hbm", "kernel": "select segment of the partitioned step on rank 0 (pos_sort + plan + select_rows: CSR rows, "
-                                              "neighbour scores, lists); the feature-row gather follows the halo exchange",
+        roofline = {"bound": "hbm", "kernel": "the step graph of rank 0 (score pass over owned + train-pos + halo rows, plan, train-pos "
+                                              "sort, select_rows, halo look-up, gather_chunks, dense_step, slab sum): one launch per step",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                     "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": float(np.mean(ab)) if ab else None,
                     "launches_timed": len(ms)}
@@ -186,11 +197,15 @@ def run_partitioned(args, w, B, lr, wd, dev, dist, world, rank):
             "config": {"workload": f"{w.name} N={n_nodes} F={feat} R={n_rel} "
                                    f"edges={'/'.join(str(e) for e in w.meta['rel_edges'])}, PCGNN emb={args.emb} "
                                    f"batch={B}/GPU rho={args.rho}",
-                       "global_batch": B * world, "parallelism": f"node-partition x{world} (in-edge balanced): score "
-                       "all-gather, id + feature-row all-to-all, grad all-reduce (RCCL)", "engine": "graph segments + eager collectives",
+                       "global_batch": B * world, "parallelism": f"node-partition x{world} (in-edge balanced): id + feature-row "
+                       f"all-to-all once per window of {W} steps (feature rows are immutable), every rank scores the rows it holds, "
+                       "grad all-reduce per step (RCCL)", "engine": "one graph replay + one all-reduce + Adam per step; no host "
+                       "synchronisation", "window_steps": W,
                        "nodes_processed": int(nodes_total),
-                       "per_rank_per_step": {"halo_rows_fetched": hr, "rows_served_to_others": rm, "halo_bytes_in": en},
+                       "per_rank_per_window": {"halo_rows_needed_max_seen": hr, "rows_served_last_window": rm,
+                                               "all_to_all_row_bytes_fixed_pitch": en},
                        "feature_rows_per_rank_max": {"owned+train_pos+halo": int(mem[0].item()), "halo_capacity": int(mem[2].item()),
+                                                     "halo_pitch": int(mem[4].item()), "rows_from_one_owner_max_seen": int(mem[3].item()),
                                                      "halo_rows_max_seen": int(mem[1].item()), "unpartitioned_table": int(n_nodes)}},
             "roofline": roofline,
         }

@@ -159,13 +159,16 @@ int pcg_step_front(const pcg_graph_desc *g, const float *W, const float *b, floa
 /* The two halves of pcg_step_front on their own, for callers that need something between them (the partitioned
  * path all-gathers the scores): _a = scores of rows [row_begin, row_end) into s0_out[row] (as pcg_score_table) || plan
  * pass 1;  _b = train-pos sort by s0 || plan pass 2.  Same plan arguments in both.
+ * _a with row_ids != NULL (int32 [n_nodes] on the device; pos_keys must be NULL then): row r's score goes to s0_out[row_ids[r]],
+ * rows with row_ids[r] < 0 are skipped - the partitioned path, whose table rows are owned / train-pos / halo rows while scores
+ * are looked up by global node id (every rank scores the rows it holds; no score all-gather).
  * _a with pos_keys != NULL (training, 0 < n_pos <= 16384, every train-pos row present in g->X) also forms the unsorted keys
  * from the feature rows in the scratch half of pos_keys (a third group of workgroups); pass raw_keys_ready = 1 to _b then,
  * and its sort stages them with coalesced loads instead of gathering n_pos scores in every sort workgroup. */
 int pcg_step_front_a(const pcg_graph_desc *g, const float *W, const float *b, int64_t row_begin, int64_t row_end,
-                     float *s0_out, uint64_t *pos_keys, const int32_t *nodes, const int32_t *labels, int32_t B,
-                     const double *thresholds, const double *rho, int32_t train_flag, int32_t add_self,
-                     void *workspace, int64_t list_capacity, uint32_t *status, void *stream);
+                     float *s0_out, const int32_t *row_ids, uint64_t *pos_keys, const int32_t *nodes,
+                     const int32_t *labels, int32_t B, const double *thresholds, const double *rho, int32_t train_flag,
+                     int32_t add_self, void *workspace, int64_t list_capacity, uint32_t *status, void *stream);
 int pcg_step_front_b(const pcg_graph_desc *g, const float *s0, uint64_t *pos_keys, int32_t raw_keys_ready,
                      const int32_t *nodes, const int32_t *labels, int32_t B, const double *thresholds,
                      const double *rho, int32_t train_flag, int32_t add_self, void *workspace, int64_t list_capacity,
@@ -294,24 +297,40 @@ int pcg_adam_flush(float *theta, float *m, float *v, const float *slabs, int32_t
                    double weight_decay, void *stream);
 
 /* ---- multi-GPU halo exchange helpers (no counterpart in the reference) ----------
- * The selection list of a partitioned run holds GLOBAL ids.  These calls re-index it into the rank's extended feature
- * table [ owned rows | train-pos rows | halo ]; they walk the list's entries in use (the workspace's chunk table) and a hash
- * table sized by the halo capacity - nothing is sized by the node-id space.
+ * A rank of a partitioned run holds the table [ owned rows | train-pos rows | halo ]; CSR rows and selection lists hold
+ * GLOBAL ids.  Feature rows never change, so a fetched row stays valid: the exchange runs once per WINDOW of steps over every
+ * neighbour the window's centres have; a step only looks rows up.  Nothing here is sized by the node-id space.
  *   bounds   int32 [world + 1]: rank r owns ids [bounds[r], bounds[r + 1])          (device)
  *   pos_ids / pos_idx  int32 [n_pos]: the train-pos ids ascending / their row in the replicated block   (device)
- *   table    uint32 [2 * table_slots], table_slots = pcg_halo_table_slots(halo_cap); first half all 0xFFFFFFFF on entry
- *   counts   uint32 [129], zero on entry; on return [0, world) = unique remote ids per owner, [128] = overflow bits
- *            (1: table full, 2: more unique remote ids than halo_cap - the caller must not gather then)
- *   uniq     int32 [halo_cap]: the unique remote ids grouped by owner in rank order (the request list)
- * classify: owned id -> id - lo; train-pos id -> n_local + its row; remote id -> marked, hashed, counted, given a halo slot.
- * remap   : marked entries -> halo_base + slot (after the rows were fetched, or before - it only needs the table). */
+ *   table    uint32 [2 * table_slots], table_slots = pcg_halo_table_slots(halo_cap)
+ *   counts   uint32 [131], zeroed ONCE by the caller; after a collect [0, world) = unique remote ids per owner, [128] =
+ *            overflow bits (1: table full, 2: more unique remote ids than halo_cap / than an owner's pitch, 4: a lookup
+ *            missed; STICKY across calls - the caller clears them after looking, so one look per epoch sees every step),
+ *            [129] / [130] = the largest number of unique remote ids a window needed so far / needed from one owner
+ *   uniq     int32 [halo_cap]: the request list - the unique remote ids grouped by owner in rank order; it doubles as the
+ *            halo rows' id column (row halo_base + i holds node uniq[i], -1 = unused)
+ *   owner_pitch  0: packed (owner o's ids start where owner o - 1's end; the all-to-all's split sizes are the counts)
+ *                > 0 (halo_cap == max(world - 1, 1) * owner_pitch): the j-th OTHER rank's ids (ranks in order, self_rank left
+ *                out) sit at [j * pitch, (j + 1) * pitch), unused entries are -1 - the all-to-alls' split sizes are known in
+ *                advance, and no count has to reach the host before they are issued
+ * pcg_halo_collect: reset (table, per-window counts, request list) + walk the CSR rows (all relations) of `centres` (local
+ *   row numbers [n_centres], duplicates allowed) inserting their remote non-train-pos neighbours + assign slots / fill the
+ *   request list (an id that does not fit gets no slot: the overflow bit).  Then all-to-all #1 (ids), pcg_halo_serve on the
+ *   owner: out[i, :] = X[req[i] - lo, :] (whole padded rows; req[i] < 0 or not owned: row i untouched), all-to-all #2 (rows).
+ * pcg_halo_lookup: per step - the list's global ids -> rows of the table: owned id -> id - lo; train-pos id -> n_local + its
+ *   row; remote id -> halo_base + slot; an id the window did not collect becomes a hole (-1) and sets bit 4.
+ * A rank then holds the feature row of every node its window can touch and scores them itself (pcg_step_front_a with
+ * row_ids): the step needs no score exchange - its only collective is the gradient all-reduce. */
 int64_t pcg_halo_table_slots(int32_t halo_cap);
-int pcg_halo_classify(const pcg_graph_desc *g, int32_t B, void *workspace, int64_t list_capacity, int32_t lo, int32_t hi,
-                      int32_t n_local, const int32_t *pos_ids, const int32_t *pos_idx, int32_t n_pos, const int32_t *bounds,
-                      int32_t world, uint32_t *table, int64_t table_slots, uint32_t *counts, int32_t *uniq, int32_t halo_cap,
-                      int32_t halo_base, void *stream);
-int pcg_halo_remap(const pcg_graph_desc *g, int32_t B, void *workspace, int64_t list_capacity, uint32_t *table,
-                   int64_t table_slots, int32_t halo_cap, int32_t halo_base, void *stream);
+int pcg_halo_collect(const pcg_graph_desc *g, const int32_t *centres, int32_t n_centres, int32_t lo, int32_t hi,
+                     int32_t n_local, const int32_t *pos_ids, int32_t n_pos, const int32_t *bounds, int32_t world,
+                     uint32_t *table, int64_t table_slots, uint32_t *counts, int32_t *uniq, int32_t halo_cap,
+                     int32_t halo_base, int32_t owner_pitch, int32_t self_rank, void *stream);
+int pcg_halo_serve(const pcg_graph_desc *g, const int32_t *req, int32_t n_req, int32_t lo, int32_t n_local, float *out,
+                   int32_t out_stride, void *stream);
+int pcg_halo_lookup(const pcg_graph_desc *g, int32_t B, void *workspace, int64_t list_capacity, int32_t lo, int32_t hi,
+                    int32_t n_local, const int32_t *pos_ids, const int32_t *pos_idx, int32_t n_pos, uint32_t *table,
+                    int64_t table_slots, uint32_t *counts, int32_t halo_cap, int32_t halo_base, void *stream);
 
 /* gather rows: out[i, :feat_dim] = X[ids[i], :feat_dim]  (self_feats, layers.py:273-277) */
 int pcg_gather_rows(const pcg_graph_desc *g, const int32_t *ids, int32_t n_ids,

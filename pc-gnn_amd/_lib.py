@@ -52,7 +52,7 @@ PROTOTYPES = {
                                        _I32, _P, _I32, _P, _P, _I64, _P, _P]),
     "pcg_step_front": (C.c_int, [_G, _P, _P, _P, _P, _P, _P, _I32, C.POINTER(_F64), C.POINTER(_F64), _I32, _I32, _P, _I64,
                                  _P, _P]),
-    "pcg_step_front_a": (C.c_int, [_G, _P, _P, _I64, _I64, _P, _P, _P, _P, _I32, C.POINTER(_F64), C.POINTER(_F64), _I32, _I32,
+    "pcg_step_front_a": (C.c_int, [_G, _P, _P, _I64, _I64, _P, _P, _P, _P, _P, _I32, C.POINTER(_F64), C.POINTER(_F64), _I32, _I32,
                                    _P, _I64, _P, _P]),
     "pcg_step_front_b": (C.c_int, [_G, _P, _P, _I32, _P, _P, _I32, C.POINTER(_F64), C.POINTER(_F64), _I32, _I32, _P, _I64, _P,
                                    _P]),
@@ -76,9 +76,10 @@ PROTOTYPES = {
     "pcg_pick_shuffled": (C.c_int, [_P, _P, _I32, _U64, _U64, _P, _I32, _I32, _P, _P, _P, _P]),
     "pcg_gather_rows": (C.c_int, [_G, _P, _I32, _P, _I32, _P]),
     "pcg_halo_table_slots": (_I64, [_I32]),
-    "pcg_halo_classify": (C.c_int, [_G, _I32, _P, _I64, _I32, _I32, _I32, _P, _P, _I32, _P, _I32, _P, _I64, _P, _P, _I32, _I32,
-                                    _P]),
-    "pcg_halo_remap": (C.c_int, [_G, _I32, _P, _I64, _P, _I64, _I32, _I32, _P]),
+    "pcg_halo_serve": (C.c_int, [_G, _P, _I32, _I32, _I32, _P, _I32, _P]),
+    "pcg_halo_collect": (C.c_int, [_G, _P, _I32, _I32, _I32, _I32, _P, _I32, _P, _I32, _P, _I64, _P, _P, _I32, _I32, _I32, _I32,
+                                   _P]),
+    "pcg_halo_lookup": (C.c_int, [_G, _I32, _P, _I64, _I32, _I32, _I32, _P, _P, _I32, _P, _I64, _P, _I32, _I32, _P]),
     "pcg_dense_n_params": (_I64, [_I32, _I32, _I32]),
     "pcg_dense_param_offset": (_I64, [_I32, _I32, _I32, _I32, _I32]),
     "pcg_dense_n_tiles": (_I32, [_I32]),

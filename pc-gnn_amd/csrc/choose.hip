@@ -341,7 +341,8 @@ __global__ void __launch_bounds__(FRONT_COUNT_THREADS) front_a_kernel(const Choo
                                                                       int n_key_blocks, uint64_t *__restrict__ raw_keys,
                                                                       const float *__restrict__ W, const float *__restrict__ bias,
                                                                       int64_t row_begin, int64_t row_end, float *__restrict__ s0,
-                                                                      const DeferredAdam ad, int n_adam_blocks) {
+                                                                      const DeferredAdam ad, int n_adam_blocks,
+                                                                      const int32_t *__restrict__ row_ids) {
     __shared__ float part[4][PCG_WAVE];
     const int b = (int)blockIdx.x;
     if (b < n_plan_blocks)
@@ -356,7 +357,7 @@ __global__ void __launch_bounds__(FRONT_COUNT_THREADS) front_a_kernel(const Choo
     } else
         score_table_body(a.g.X, a.g.feat_dim, a.g.feat_stride, W, bias, row_begin, row_end, s0,
                          b - n_plan_blocks - n_key_blocks - n_adam_blocks,
-                         (int)gridDim.x - n_plan_blocks - n_key_blocks - n_adam_blocks);
+                         (int)gridDim.x - n_plan_blocks - n_key_blocks - n_adam_blocks, row_ids);
 }
 
 __global__ void __launch_bounds__(PLAN_THREADS) front_b_kernel(const ChooseArgs a, const PlanTotals *totals, int n_write_blocks,
@@ -497,13 +498,14 @@ int pcg_choose_select_planned(const pcg_graph_desc *g, const int32_t *nodes, con
 
 /* first half: class-0 logits of rows [row_begin, row_end) -> s0_out[row]  ||  plan pass 1  (|| a deferred Adam update) */
 static int front_a(const pcg_graph_desc *g, const float *W, const float *b, int64_t row_begin, int64_t row_end,
-                   float *s0_out, uint64_t *pos_keys, const int32_t *nodes, const int32_t *labels, int32_t B,
+                   float *s0_out, const int32_t *row_ids, uint64_t *pos_keys, const int32_t *nodes, const int32_t *labels, int32_t B,
                    const double *thresholds, const double *rho, int32_t train_flag, int32_t add_self, void *workspace,
                    int64_t list_capacity, uint32_t *status, const pcg::DeferredAdam *ad, void *stream) {
     if (!g || !g->X || !W || !b || !s0_out || B < 0) return PCG_E_ARG;
     if (g->feat_dim < 1 || g->feat_stride < g->feat_dim || g->feat_stride % 4 != 0) return PCG_E_ARG;
     if ((reinterpret_cast<uintptr_t>(g->X) & 15u) != 0) return PCG_E_ARG;
     if (row_begin < 0 || row_end > g->n_nodes || row_begin > row_end) return PCG_E_ARG;
+    if (B == 0 && row_ids) return PCG_E_ARG;
     if (B == 0) return pcg_score_table(g, W, b, row_begin, row_end, s0_out, stream);   // (then _b gathers its keys itself)
     pcg::ChooseArgs a;
     const int rc = choose_args(a, g, nodes, labels, B, nullptr, nullptr, nullptr, thresholds, rho, train_flag, add_self, nullptr,
@@ -523,16 +525,17 @@ static int front_a(const pcg_graph_desc *g, const float *W, const float *b, int6
     const int n_adam = ad ? (int)((ad->p_end + PCG_WAVE - 1) / PCG_WAVE) : 0;
     hipLaunchKernelGGL(pcg::front_a_kernel, dim3(n_count + n_key + n_adam + n_score), dim3(pcg::FRONT_COUNT_THREADS), 0,
                        static_cast<hipStream_t>(stream), a, tot, n_count, n_key, raw_keys, W, b, row_begin, row_end, s0_out,
-                       ad ? *ad : none, n_adam);
+                       ad ? *ad : none, n_adam, row_ids);
     PCG_LAUNCH_CHECK();
     return PCG_OK;
 }
 
 int pcg_step_front_a(const pcg_graph_desc *g, const float *W, const float *b, int64_t row_begin, int64_t row_end,
-                     float *s0_out, uint64_t *pos_keys, const int32_t *nodes, const int32_t *labels, int32_t B,
-                     const double *thresholds, const double *rho, int32_t train_flag, int32_t add_self, void *workspace,
-                     int64_t list_capacity, uint32_t *status, void *stream) {
-    return front_a(g, W, b, row_begin, row_end, s0_out, pos_keys, nodes, labels, B, thresholds, rho, train_flag, add_self,
+                     float *s0_out, const int32_t *row_ids, uint64_t *pos_keys, const int32_t *nodes, const int32_t *labels,
+                     int32_t B, const double *thresholds, const double *rho, int32_t train_flag, int32_t add_self,
+                     void *workspace, int64_t list_capacity, uint32_t *status, void *stream) {
+    if (row_ids && pos_keys) return PCG_E_ARG;       // (the keys-from-feature-rows group indexes X by node id)
+    return front_a(g, W, b, row_begin, row_end, s0_out, row_ids, pos_keys, nodes, labels, B, thresholds, rho, train_flag, add_self,
                    workspace, list_capacity, status, nullptr, stream);
 }
 
@@ -590,7 +593,7 @@ int pcg_step_front_train(const pcg_graph_desc *g, float *theta, float *m, float 
     ad.step_counter = step_counter;
     ad.pending = sync_words + 1;
     ad.h = {(float)lr, (float)beta1, (float)beta2, (float)eps, (float)weight_decay};
-    const int rc = front_a(g, theta + o_clf, theta + o_b, 0, g->n_nodes, s0, pos_keys, nodes, labels, B, thresholds, rho, 1, add_self,
+    const int rc = front_a(g, theta + o_clf, theta + o_b, 0, g->n_nodes, s0, nullptr, pos_keys, nodes, labels, B, thresholds, rho, 1, add_self,
                            workspace, list_capacity, status, &ad, stream);
     if (rc != PCG_OK) return rc;
     return front_b(g, s0, pos_keys, 1, nodes, labels, B, thresholds, rho, 1, add_self, workspace, list_capacity, status,
@@ -602,7 +605,7 @@ int pcg_step_front(const pcg_graph_desc *g, const float *W, const float *b, floa
                    int32_t train_flag, int32_t add_self, void *workspace, int64_t list_capacity, uint32_t *status,
                    void *stream) {
     if (!g) return PCG_E_ARG;
-    const int rc = pcg_step_front_a(g, W, b, 0, g->n_nodes, s0, pos_keys, nodes, labels, B, thresholds, rho, train_flag, add_self,
+    const int rc = pcg_step_front_a(g, W, b, 0, g->n_nodes, s0, nullptr, pos_keys, nodes, labels, B, thresholds, rho, train_flag, add_self,
                                     workspace, list_capacity, status, stream);
     if (rc != PCG_OK) return rc;
     return pcg_step_front_b(g, s0, pos_keys, B > 0 ? 1 : 0, nodes, labels, B, thresholds, rho, train_flag, add_self, workspace,

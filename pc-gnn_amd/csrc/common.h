@@ -101,11 +101,13 @@ __device__ __forceinline__ float score_reduce(float p, int lpr) {
 #endif
 constexpr int SCORE_UNROLL = PCG_SCORE_UNROLL;
 
-// class-0 logit of rows [row_begin, row_end): workgroup `block` of `n_blocks` (256 threads each), grid-stride
+// class-0 logit of rows [row_begin, row_end): workgroup `block` of `n_blocks` (256 threads each), grid-stride.
+// row_ids == nullptr: s0[row] = score(row);  else: s0[row_ids[row]] = score(row), rows with row_ids[row] < 0 skipped (the
+// partitioned path: a rank's table rows are owned / train-pos / halo rows, scores are looked up by global node id)
 __device__ __forceinline__ void score_table_body(const float *__restrict__ X, int feat_dim, int stride,
                                                  const float *__restrict__ W, const float *__restrict__ bias,
                                                  int64_t row_begin, int64_t row_end, float *__restrict__ s0, int block,
-                                                 int n_blocks) {
+                                                 int n_blocks, const int32_t *__restrict__ row_ids = nullptr) {
     const int lane = lane_id();
     const int lpr = lanes_per_row(stride);
     const int rpw = PCG_WAVE / lpr;
@@ -131,7 +133,14 @@ __device__ __forceinline__ void score_table_body(const float *__restrict__ X, in
         }
         if (sub < SCORE_UNROLL) {
             const int64_t row = base + (int64_t)sub * rpw + slot;
-            if (row < row_end) s0[row] = mine + b0;
+            if (row < row_end) {
+                if (row_ids) {
+                    const int32_t id = row_ids[row];
+                    if (id >= 0) s0[id] = mine + b0;
+                } else {
+                    s0[row] = mine + b0;
+                }
+            }
         }
     }
 }

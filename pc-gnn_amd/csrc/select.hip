@@ -612,9 +612,9 @@ __device__ __forceinline__ void for_keys(const uint32_t *keys, const int32_t *__
 // lds: WG_KEYCAP words (keys, later the kept ids) | hist HIST_WG | cand 64 | red
 template <bool LDSK>
 __device__ __forceinline__ void select_wg_row(const ChooseArgs &a, int row, uint32_t *keys, uint32_t *hist, uint32_t *cand,
-                                              int *red) {
+                                              int *red, int tid) {
     constexpr int NW = SEL_NW, NT = SEL_NW * PCG_WAVE;
-    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6), tid = (int)threadIdx.x;
+    const int lane = tid & (PCG_WAVE - 1), wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (a.stamps && tid == 0) a.stamps[(size_t)row * 8] = wall_clock64() | ((unsigned long long)blockIdx.x << 54);
     const RowRec p = a.w.recs[row];
     const int d = p.d, k = p.k;
@@ -874,7 +874,6 @@ __global__ void __launch_bounds__(SEL_NW *PCG_WAVE) __attribute__((amdgpu_waves_
     // instead of a waterfall over the kernel arguments
     const int32_t **t_indices = reinterpret_cast<const int32_t **>(red + 2 * SEL_NW + 8);
     if (threadIdx.x < PCG_MAX_REL) t_indices[threadIdx.x] = a.g.indices[threadIdx.x < (unsigned)a.g.n_rel ? threadIdx.x : 0];
-    const int wave = threadIdx.x >> 6, lane = lane_id();
     const bool leader = threadIdx.x == 0;
     const int n16 = (int)a.w.counters[C_N16], n4 = (int)a.w.counters[C_N4];
     const int n1 = (int)a.w.counters[C_N1], n0 = (int)a.w.counters[C_N0], na = (int)a.w.counters[C_NA];
@@ -889,18 +888,24 @@ __global__ void __launch_bounds__(SEL_NW *PCG_WAVE) __attribute__((amdgpu_waves_
     const bool pull = n_units > grid;                                      // otherwise unit = workgroup: no atomics at all
     const int shard = (int)blockIdx.x % SEL_SHARDS;
     uint32_t *head = a.w.heads + 16 * shard;                               // (64 bytes apart)
-    uint32_t *area = lds + wave * WAVE_AREA;
     __syncthreads();
 
     int u = (int)blockIdx.x, pending = 0, slot = 0;
     while (u < n_units) {
         // the unit after this one: its claim is in flight while this one runs
         if (leader && pull) pending = shard + SEL_SHARDS * (grid / SEL_SHARDS + (int)atomicAdd(head, 1u));
+        // the thread index goes through an opaque move once per unit: everything the row paths derive from it (lane masks,
+        // quarter-wave indices, LDS offsets) is then recomputed per unit - a few VALU ops - instead of being hoisted out of
+        // this loop and kept alive across every path, which costs more registers than the 80 the occupancy allows (spills)
+        int tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & (PCG_WAVE - 1), wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        uint32_t *area = lds + wave * WAVE_AREA;
         if (u < n_wg) {
             const int row = __builtin_amdgcn_readfirstlane(u < n16 ? a.w.q16[u] : a.w.q4[u - n16]);     // one row per workgroup: scalar
             const int d = a.w.recs[row].d;
-            if (d <= WG_KEYCAP) select_wg_row<true>(a, row, lds, hist, cand, red);
-            else select_wg_row<false>(a, row, lds, hist, cand, red);
+            if (d <= WG_KEYCAP) select_wg_row<true>(a, row, lds, hist, cand, red, tid);
+            else select_wg_row<false>(a, row, lds, hist, cand, red, tid);
         } else {
             const int j = wave < bs ? (u - n_wg) * bs + wave : n_items;
             if (j < n1) {

@@ -8,30 +8,32 @@ reference has no distributed code at all; this is new des
   holds ``X[v]``, the CSR rows of ``v`` for every relation (neighbour ids stay GLOBAL) and ``v``'s
   label.  Replicated on every rank: all parameters, the train-pos ids and their feature rows (so
   minority over-sampling never needs a fetch).
-* **Per step** (each rank works on centres it owns):
-    1. class-0 scores of the owned rows (``pcg_step_front_a``) -> ``all_gather`` -> every rank has
-       ``s0[N]``  (4 N bytes; 0.18 MB for YelpChi, 40 MB at 10 M nodes);
-    2. train-pos sort + choose (``pcg_choose_select_planned``) on local rows -> selection lists of
-       global ids;
-    3. halo exchange: the list's entries are classified, the remote ids de-duplicated in a hash table
-       sized by the halo capacity (``pcg_halo_classify`` - work and memory proportional to the list,
-       not to the node count), the per-owner request counts of every rank all-gathered (the step's
-       one host synchronisation: it sizes both all-to-alls, and every rank derives the SAME overflow
-       verdict from it), ``all_to_all`` #1 sends the ids, the owners gather those rows,
-       ``all_to_all`` #2 returns them into the halo region of the extended feature table; the lists
-       are re-indexed into that table (``pcg_halo_remap``);
-    4. ``pcg_aggregate_lists`` over the extended table, ``pcg_dense_step`` on the local batch
-       with the loss scaled by 1 / global batch, gradient ``all_reduce`` (~107 KB), identical
-       Adam on every rank.
-  xGMI is point-to-point, so the all-to-all uses all 7 links of a GPU at once; the gradient
-  all-reduce is latency-bound at this size.
-* **Memory per rank**: owned rows + train-pos rows + a halo region sized from the batch's expected
-  demand (``halo_rows``: pick-weighted mean list length x batch x a margin, never more than the remote
-  nodes there are) - not from the node count; no per-node flag / slot / position tables.
+* **Per window of steps** (``begin_window``; feature rows never change, so a fetched row stays valid):
+  every rank walks the CSR rows of the centres it will train on in the next steps, de-duplicates their
+  remote neighbours in a hash table sized by the halo capacity (``pcg_halo_collect``), ``all_to_all`` #1
+  sends the ids to their owners, the owners gather those rows (``pcg_halo_serve``), ``all_to_all`` #2
+  returns them into the halo region of the extended table ``[owned | train-pos | halo]``.  Owner o's
+  requests sit in a fixed range of the request list, so both all-to-alls have equal splits and nothing
+  waits for the host.  xGMI is point-to-point: the all-to-alls use all 7 links of a GPU at once.
+* **Per step** (each rank works on centres it owns), one hipGraph replay + ONE collective:
+    1. class-0 scores of every row the rank holds (owned, train-pos, halo - every node a list of this
+       window can name), stored by global node id (``pcg_step_front_a`` with ``row_ids``): no score
+       exchange - a row's score is the same arithmetic on whichever rank computes it;
+    2. train-pos sort + choose (``pcg_choose_select_planned``) -> selection lists of global ids ->
+       rows of the extended table (``pcg_halo_lookup``);
+    3. ``pcg_gather_lists`` over the extended table, ``pcg_train_dense`` on the local batch with the
+       loss scaled by 1 / global batch;
+    4. gradient ``all_reduce`` (~107 KB, latency-bound), identical Adam on every rank.
+* **Memory per rank**: owned rows + train-pos rows + a halo region sized from the window's expected
+  demand (``halo_rows``: distinct remote neighbours of window x batch picked centres, x a margin,
+  never more than the remote nodes there are) - not from the node count; no per-node flag / slot /
+  position tables (the one per-node array is the score vector, 4 bytes a node).
+* **Capacity errors** are device flags (an owner asked for more than its range, a list over capacity,
+  a step outside its window); ``check()`` all-reduces them so that every rank raises, or none.
 
 The exchange layer (`HaloExchange`) is plain ``torch`` + ``torch.distributed`` and therefore also
-runs on CPU tensors over ``gloo`` - that is what the world-size-2 CPU tests drive.  The kernels
-themselves have no CPU path.
+runs on CPU tensors over ``gloo`` - that is what the world-size-2 CPU tests drive; `HaloExchangeHip`
+replaces its list work by kernels.  The kernels themselves have no CPU path.
 """
 import math
 from typing import List, Optional, Sequence
@@ -110,91 +112,77 @@ def shard_pick_weights(labels_train_local: np.ndarray, homo_deg_train_local: np.
 
 
 def expected_halo_rows(deg_rel_train_local: Sequence[np.ndarray], weights: np.ndarray, batch: int, world: int, n_remote: int,
-                       margin: float = 1.5) -> int:
-    """Halo capacity from the batch's expected demand: a picked centre has, per relation, ~ceil(deg / 2) chosen
-    neighbours (its minority picks are local: the train-pos block); a fraction (world - 1) / world of them is remote;
-    distinct ones are at most that many.  Pick-weighted mean over the rank's training nodes x batch x margin, never more
-    than the remote nodes there are."""
+                       margin: float = 1.5, kept: float = 0.5) -> int:
+    """Halo capacity from the expected demand of `batch` picked centres: a centre contributes, per relation,
+    ~ceil(kept * deg) neighbours (kept = 0.5: the chosen ones of one step; 1.0: all of them - what a window prefetch
+    fetches; minority picks are local: the train-pos block); a fraction (world - 1) / world of them is remote:
+    e entries (pick-weighted mean over the rank's training nodes x batch).  e draws from n_remote nodes hit at most
+    n_remote * (1 - exp(-e / n_remote)) distinct ones (uniform draws; skewed ones hit fewer).  x margin + 1024, never
+    more than the remote nodes there are."""
     if world == 1 or n_remote <= 0:
         return 1
     if weights.size == 0 or weights.sum() <= 0:
         return min(n_remote, 1024)
     p = weights / weights.sum()
-    per_centre = sum(float((np.ceil(d / 2.0) * p).sum()) for d in deg_rel_train_local)
-    est = per_centre * batch * (world - 1) / world * margin + 1024
-    return int(min(n_remote, math.ceil(est)))
+    per_centre = sum(float((np.ceil(d * kept) * p).sum()) for d in deg_rel_train_local)
+    entries = per_centre * batch * (world - 1) / world
+    distinct = n_remote * -math.expm1(-entries / n_remote)
+    return int(min(n_remote, math.ceil(distinct * margin + 1024)))
 
 
 class HaloExchange:
-    """Fetch the feature rows of remote ids and re-index a selection list into the extended table
+    """The halo exchange of a WINDOW of steps, on any device / backend (plain ``torch`` + ``torch.distributed``).
 
-        X_ext = [ owned rows (n_local) | train-pos rows (P) | halo (per step) ]
+        X_ext = [ owned rows (n_local) | train-pos rows (P) | halo ((world - 1) x pitch rows) ]
 
-    `lst` holds global ids (-1 = hole).  After `fetch_and_remap(lst)`, `lst` holds row numbers of
-    X_ext and the halo region holds the rows fetched this step.  Works on any device / backend;
-    `stage_host=True` stages the collectives through CPU tensors (gloo with device tensors).
-    Work and memory are proportional to the list (sort-unique of its remote entries, binary search in the
-    sorted train-pos ids), not to the node count.
-    """
+    Feature rows never change, so a fetched row stays valid: `prefetch(csr, centres)` requests every remote, non-train-pos
+    neighbour the centres have (de-duplicated; the j-th other rank's requests sit in slots [j * pitch, (j + 1) * pitch) of
+    the request list, unused slots = -1, and the halo region has the same layout - the split sizes of both all-to-alls are
+    known in advance and nothing has to reach the host before they are issued); `lookup(lst)` then turns a list of global ids (-1 = hole) into row numbers
+    of X_ext.  An owner asked for more than `pitch` rows, or a lookup of an id outside the window, sets bits in the sticky
+    device word `overflow_word` (2 / 4; those ids become holes).  Work and memory are proportional to the window's CSR
+    rows and the lists, not to the node count.  `stage_host=True` stages the collectives through CPU tensors (gloo with
+    device tensors)."""
 
-    def __init__(self, part: Partition, X_ext: torch.Tensor, train_pos: Sequence[int], group=None, stage_host: bool = False):
+    def __init__(self, part: Partition, X_ext: torch.Tensor, train_pos: Sequence[int], pitch: Optional[int] = None, group=None,
+                 stage_host: bool = False, req_out: Optional[torch.Tensor] = None):
         self.part, self.X_ext, self.P = part, X_ext, len(train_pos)
         self.group, self.stage_host = group, stage_host
-        tp = torch.as_tensor(np.asarray(list(train_pos), dtype=np.int64), device=X_ext.device)
+        dev = X_ext.device
+        tp = torch.as_tensor(np.asarray(list(train_pos), dtype=np.int64), device=dev)
         self.pos_ids, self.pos_idx = torch.sort(tp) if self.P else (tp, tp)
         self.halo_base = part.n_local + self.P
         self.halo_cap = X_ext.shape[0] - self.halo_base
-        self._all_caps = None
-        self.last_stats = {}
+        self.peers = max(part.world - 1, 1)
+        self.pitch = int(pitch) if pitch is not None else self.halo_cap // self.peers
+        assert self.pitch >= 1 and self.halo_cap == self.peers * self.pitch, "the halo region is (world - 1) x pitch rows"
+        # split sizes of both all-to-alls: `pitch` with every other rank, nothing with oneself (world 1: one dummy range)
+        self.splits = [self.pitch if (r != part.rank or part.world == 1) else 0 for r in range(part.world)]
+        self.counts = torch.zeros(131, dtype=torch.int32, device=dev)
+        self.overflow_word = self.counts[128:129]
+        # the request list doubles as the halo rows' id column (the caller may pass that slice of its row -> id array)
+        self.req_out = req_out if req_out is not None else torch.empty(self.halo_cap, dtype=torch.int32, device=dev)
+        assert self.req_out.numel() == self.halo_cap and self.req_out.dtype == torch.int32 and self.req_out.is_contiguous()
+        self.req_out.fill_(-1)
+        self.req_in = torch.full((self.halo_cap,), -1, dtype=torch.int32, device=dev)
+        self.rows_out = torch.zeros(self.halo_cap, X_ext.shape[1], dtype=torch.float32, device=dev)
+        self.halo_rows = X_ext[self.halo_base:self.halo_base + self.halo_cap]
+        self._uniq = torch.zeros(0, dtype=torch.int64, device=dev)
+        self._slot = torch.zeros(0, dtype=torch.int64, device=dev)
 
     # -- collectives (optionally staged through the host) -------------------------------------
-    def _a2a(self, out: torch.Tensor, inp: torch.Tensor, out_splits: Optional[List[int]], in_splits: Optional[List[int]]):
+    def _a2a(self, out: torch.Tensor, inp: torch.Tensor):
+        """fixed splits: the j-th range of `inp` goes to the j-th other rank, the j-th range of `out` comes from it"""
         if self.stage_host and inp.device.type != "cpu":
             o, i = torch.empty(out.shape, dtype=out.dtype), inp.cpu()
-            dist.all_to_all_single(o, i, out_splits, in_splits, group=self.group)
+            dist.all_to_all_single(o, i, self.splits, self.splits, group=self.group)
             out.copy_(o)
         else:
-            dist.all_to_all_single(out, inp.contiguous(), out_splits, in_splits, group=self.group)
+            dist.all_to_all_single(out, inp.contiguous(), self.splits, self.splits, group=self.group)
 
-    def _gather_counts(self, out, inp):
-        if self.stage_host and inp.device.type != "cpu":
-            o = torch.empty(out.shape, dtype=out.dtype)
-            dist.all_gather_into_tensor(o, inp.cpu(), group=self.group)
-            out.copy_(o)
-        else:
-            dist.all_gather_into_tensor(out, inp.contiguous(), group=self.group)
-
-    def _share_caps(self, halo_cap: int, serve_cap: int):
-        """every rank's capacities on every rank (one collective at construction), so that every rank can judge every rank"""
-        w = self.part.world
-        caps = torch.tensor([halo_cap, serve_cap], dtype=torch.int64, device=self.X_ext.device)
-        allc = torch.empty(2 * w, dtype=torch.int64, device=self.X_ext.device)
-        self._gather_counts(allc, caps)
-        self._all_caps = allc.view(w, 2).cpu().tolist()
-
-    def _check(self, mat: torch.Tensor, flags: Optional[torch.Tensor] = None):
-        """Every rank holds the same count matrix (and the same capacities), so every rank reaches the same verdict:
-        all raise, or none does - a rank raising on its own would leave the others blocked in the next collective."""
-        need = mat.sum(1)                       # rows each rank fetches
-        serve = mat.sum(0)                      # rows each rank serves
-        bad = []
-        for r in range(self.part.world):
-            cap_r, srv_r = self._all_caps[r] if self._all_caps is not None else (self.halo_cap, None)
-            if int(need[r]) > int(cap_r):
-                bad.append(f"rank {r} needs {int(need[r])} halo rows, capacity {int(cap_r)}")
-            if srv_r is not None and int(serve[r]) > int(srv_r):
-                bad.append(f"rank {r} has to serve {int(serve[r])} rows, capacity {int(srv_r)}")
-            if flags is not None and int(flags[r]):
-                bad.append(f"rank {r}: request table full (flags {int(flags[r])})")
-        if bad:
-            raise RuntimeError("halo exchange over capacity - raise halo_rows / serve_rows: " + "; ".join(bad))
-
-    def fetch_and_remap(self, lst: torch.Tensor) -> int:
-        part, dev = self.part, lst.device
-        w = part.world
-        if self._all_caps is None:
-            self._share_caps(self.halo_cap, (w - 1) * part.n_local)
-        ids = lst.long()
+    def _classify(self, ids: torch.Tensor):
+        """(valid & owned, valid & train-pos, train-pos row, valid & remote) of a tensor of global ids (int64)"""
+        part = self.part
         valid = ids >= 0
         is_local = valid & (ids >= part.lo) & (ids < part.hi)
         if self.P:
@@ -203,96 +191,128 @@ class HaloExchange:
             pm = self.pos_idx[at]
         else:
             is_pos, pm = torch.zeros_like(valid), torch.zeros_like(ids)
-        is_rem = valid & ~is_local & ~is_pos
-        uniq, inv = torch.unique(ids[is_rem], return_inverse=True)         # sorted ascending = grouped by owner
+        return is_local, is_pos, pm, valid & ~is_local & ~is_pos
+
+    # -- the window's exchange ---------------------------------------------------------------------
+    def collect(self, csr, centres: torch.Tensor):
+        """(1) the request list: the remote, non-train-pos neighbours of `centres` (local rows; duplicates allowed) over all
+        relations of `csr` = [(indptr, indices)] (tensors on this device, global neighbour ids), once each."""
+        part, dev = self.part, self.X_ext.device
+        c = centres.long()
+        c = c[(c >= 0) & (c < part.n_local)]
+        parts = []
+        for indptr, indices in csr:
+            beg, deg = indptr[c], indptr[c + 1] - indptr[c]
+            if int(deg.sum()) == 0:
+                continue
+            off = torch.arange(int(deg.sum()), device=dev) - torch.repeat_interleave(torch.cumsum(deg, 0) - deg, deg)
+            parts.append(indices[torch.repeat_interleave(beg, deg) + off].long())
+        ids = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.int64, device=dev)
+        uniq = torch.unique(ids[self._classify(ids)[3]])                     # sorted ascending = grouped by owner
+        owner = part.owner(uniq)
         cuts = torch.searchsorted(uniq, part.bounds(dev))
-        send_counts = (cuts[1:] - cuts[:-1]).to(torch.int64)
-        mat = torch.empty(w * w, dtype=torch.int64, device=dev)
-        self._gather_counts(mat, send_counts)
-        mat = mat.view(w, w).cpu()                                          # host needs the split sizes
-        self._check(mat)
-        sc, rc = mat[part.rank].tolist(), mat[:, part.rank].tolist()
-        n_halo = int(uniq.numel())
-        req = torch.empty(sum(rc), dtype=torch.int64, device=dev)
-        self._a2a(req, uniq, rc, sc)                                        # all-to-all #1: requested ids
-        rows = self.X_ext.index_select(0, req - part.lo)                    # the owner gathers its rows
-        halo = self.X_ext[self.halo_base:self.halo_base + n_halo]
-        self._a2a(halo, rows, sc, rc)                                       # all-to-all #2: feature rows
-        new = torch.where(is_local, ids - part.lo, torch.where(is_pos, part.n_local + pm, ids))
-        new[is_rem] = self.halo_base + inv
+        nth = torch.arange(uniq.numel(), device=dev) - cuts[owner]
+        ok = nth < self.pitch
+        self._uniq = uniq
+        self._slot = torch.where(ok, (owner - (owner > part.rank).long()) * self.pitch + nth, torch.full_like(nth, -1))
+        self.req_out.fill_(-1)
+        self.req_out[self._slot[ok]] = uniq[ok].to(torch.int32)
+        per_owner = (cuts[1:] - cuts[:-1]).to(torch.int32)
+        self.counts[:part.world] = per_owner
+        self.counts[128] |= (~ok).any().to(torch.int32) * 2
+        self.counts[129] = torch.maximum(self.counts[129], per_owner.sum())
+        self.counts[130] = torch.maximum(self.counts[130], per_owner.max() if part.world else per_owner.sum())
+
+    def exchange_ids(self):
+        """(2) all-to-all #1: slice o of req_out goes to owner o; slice r of req_in = what rank r asks of this rank"""
+        self._a2a(self.req_in, self.req_out)
+
+    def serve(self, graph=None):
+        """(3) the owner gathers the rows it was asked for (unused slots and ids it does not own: left alone)"""
+        row = self.req_in.long() - self.part.lo
+        ok = (self.req_in >= 0) & (row >= 0) & (row < self.part.n_local)
+        self.rows_out[ok] = self.X_ext[row[ok]]
+
+    def exchange_rows(self):
+        """(4) all-to-all #2: the rows come back into the halo region, in the request list's layout"""
+        self._a2a(self.halo_rows, self.rows_out)
+
+    def prefetch(self, csr, centres: torch.Tensor) -> None:
+        """COLLECTIVE: afterwards the halo region holds every remote row the centres' lists can name"""
+        self.collect(csr, centres)
+        self.exchange_ids()
+        self.serve(csr)
+        self.exchange_rows()
+
+    def lookup(self, lst: torch.Tensor) -> None:
+        """per step: `lst` (global ids, -1 = hole) -> rows of X_ext, in place"""
+        ids = lst.long()
+        is_local, is_pos, pm, is_rem = self._classify(ids)
+        new = torch.where(is_local, ids - self.part.lo, torch.where(is_pos, self.part.n_local + pm, ids))
+        if self._uniq.numel():
+            at = torch.searchsorted(self._uniq, ids.clamp(min=0)).clamp(max=self._uniq.numel() - 1)
+            hit = is_rem & (self._uniq[at] == ids) & (self._slot[at] >= 0)
+            row = self.halo_base + self._slot[at]
+        else:
+            hit, row = torch.zeros_like(is_rem), ids
+        new = torch.where(is_rem, torch.where(hit, row, torch.full_like(ids, -1)), new)
+        self.counts[128] |= (is_rem & ~hit).any().to(torch.int32) * 4
         lst.copy_(new.to(lst.dtype))
-        self.last_stats = {"entries": int(valid.sum()), "remote_entries": int(is_rem.sum()), "halo_rows": n_halo,
-                           "bytes_in": n_halo * self.X_ext.shape[1] * 4, "bytes_out": sum(rc) * self.X_ext.shape[1] * 4}
-        return n_halo
+
+    @property
+    def max_seen(self):
+        """largest demand of a window so far (one device read: not for the step loop)"""
+        c = self.counts[129:131].cpu().tolist()
+        return {"halo_rows": int(c[0]), "rows_from_one_owner": int(c[1]), "pitch": self.pitch}
 
 
 class HaloExchangeHip(HaloExchange):
-    """Same exchange with the list work done by HIP kernels (pcg_halo_classify / pcg_halo_remap: hash-table
-    de-duplication of the list's remote entries) and ONE host synchronisation per step: the per-owner request counts
-    (+ a table-overflow word) of every rank are all-gathered as a world x (world + 1) matrix, which gives a rank its send
-    and receive split sizes and gives every rank the same overflow verdict."""
+    """The same exchange with the list / CSR work done by HIP kernels (pcg_halo_collect: hash-table de-duplication sized by
+    the halo capacity; pcg_halo_serve; pcg_halo_lookup).  No host synchronisation anywhere."""
 
-    def __init__(self, part, X_ext, train_pos, serve_cap: int, group=None, stage_host=False):
-        super().__init__(part, X_ext, train_pos, group, stage_host)
+    def __init__(self, part, X_ext, train_pos, pitch: int, group=None, stage_host=False, req_out: Optional[torch.Tensor] = None):
+        super().__init__(part, X_ext, train_pos, pitch, group, stage_host, req_out)
         from . import _lib, ops
         self._lib, self._ops = _lib, ops
         dev = X_ext.device
-        lib = _lib.load()
-        w = part.world
-        self.slots = int(lib.pcg_halo_table_slots(self.halo_cap))
+        self.slots = int(_lib.load().pcg_halo_table_slots(self.halo_cap))
         self.table = torch.empty(2 * self.slots, dtype=torch.int32, device=dev)
-        self.counts = torch.zeros(129, dtype=torch.int32, device=dev)
-        self.uniq = torch.empty(max(self.halo_cap, 1), dtype=torch.int32, device=dev)
         self.bounds_dev = part.bounds(dev).to(torch.int32)
         self.pos_ids32, self.pos_idx32 = self.pos_ids.to(torch.int32), self.pos_idx.to(torch.int32)
-        self.serve_cap = max(1, int(serve_cap))
-        self._req = torch.empty(self.serve_cap, dtype=torch.int32, device=dev)
-        self._rows = torch.zeros(self.serve_cap, X_ext.shape[1], dtype=torch.float32, device=dev)
-        self._vec = torch.zeros(w + 1, dtype=torch.int32, device=dev)
-        self._mat = torch.zeros(w * (w + 1), dtype=torch.int32, device=dev)
-        self._share_caps(self.halo_cap, self.serve_cap)
-        self.max_seen = {"halo_rows": 0, "rows_served": 0}
 
-    def fetch_and_remap_device(self, ws, B: int, graph) -> int:
-        """ws: the step's ChooseWorkspace (its list holds global ids, its chunk table says which entries are in use)."""
+    def collect(self, graph, centres: torch.Tensor):
         lib, ops, part = self._lib.load(), self._ops, self.part
-        _p, st = ops._p, ops._stream(self.X_ext.device)
-        w, rank = part.world, part.rank
-        self.table[:self.slots].fill_(-1)
-        self.counts.zero_()
-        self._lib.check(lib.pcg_halo_classify(
+        _p = ops._p
+        centres = centres.to(torch.int32).contiguous()
+        self._lib.check(lib.pcg_halo_collect(
+            graph.desc_ref(), _p(centres), centres.numel(), part.lo, part.hi, part.n_local, _p(self.pos_ids32), self.P,
+            _p(self.bounds_dev), part.world, _p(self.table), self.slots, _p(self.counts), _p(self.req_out), self.halo_cap,
+            self.halo_base, self.pitch, part.rank, ops._stream(self.X_ext.device)), "pcg_halo_collect")
+
+    def serve(self, graph):
+        ops, part = self._ops, self.part
+        self._lib.check(self._lib.load().pcg_halo_serve(
+            graph.desc_ref(), ops._p(self.req_in), self.halo_cap, part.lo, part.n_local, ops._p(self.rows_out),
+            self.rows_out.stride(0), ops._stream(self.X_ext.device)), "pcg_halo_serve")
+
+    def lookup(self, ws, B: int, graph):
+        """per step: ws.list (global ids; the chunk table says which entries are in use) -> rows of X_ext"""
+        ops, part = self._ops, self.part
+        _p = ops._p
+        self._lib.check(self._lib.load().pcg_halo_lookup(
             graph.desc_ref(), B, _p(ws.buf), ws.list_capacity, part.lo, part.hi, part.n_local, _p(self.pos_ids32),
-            _p(self.pos_idx32), self.P, _p(self.bounds_dev), w, _p(self.table), self.slots, _p(self.counts), _p(self.uniq),
-            self.halo_cap, self.halo_base, st), "pcg_halo_classify")
-        self._vec[:w].copy_(self.counts[:w])
-        self._vec[w:].copy_(self.counts[128:129])
-        self._gather_counts(self._mat, self._vec)
-        full = self._mat.view(w, w + 1).cpu()                              # the step's single host sync
-        mat, flags = full[:, :w].long(), full[:, w]
-        self._check(mat, flags=flags)
-        sc, rc = mat[rank].tolist(), mat[:, rank].tolist()
-        n_halo, n_req = sum(sc), sum(rc)
-        req = self._req[:n_req]
-        self._a2a(req, self.uniq[:n_halo], rc, sc)                         # all-to-all #1: requested ids
-        rows = self._rows[:n_req]
-        if n_req:
-            ops.gather_rows(graph, req - part.lo, out=rows)                # the owner gathers its rows (pad columns stay 0)
-        halo = self.X_ext[self.halo_base:self.halo_base + n_halo]
-        self._a2a(halo, rows, sc, rc)                                      # all-to-all #2: feature rows
-        self._lib.check(lib.pcg_halo_remap(graph.desc_ref(), B, _p(ws.buf), ws.list_capacity, _p(self.table), self.slots,
-                                           self.halo_cap, self.halo_base, st), "pcg_halo_remap")
-        self.last_stats = {"halo_rows": n_halo, "rows_served": n_req, "bytes_in": n_halo * self.X_ext.shape[1] * 4,
-                           "bytes_out": n_req * self.X_ext.shape[1] * 4}
-        self.max_seen["halo_rows"] = max(self.max_seen["halo_rows"], n_halo)
-        self.max_seen["rows_served"] = max(self.max_seen["rows_served"], n_req)
-        return n_halo
+            _p(self.pos_idx32), self.P, _p(self.table), self.slots, _p(self.counts), self.halo_cap, self.halo_base,
+            ops._stream(self.X_ext.device)), "pcg_halo_lookup")
 
 
 class DistributedPCGNN:
     """The step driver of one rank of a node-partitioned run (HIP kernels + RCCL)."""
 
     def __init__(self, w, model_cfg: dict, device, group=None, stage_host: bool = False, halo_rows: Optional[int] = None,
-                 serve_rows: Optional[int] = None, balanced: bool = True):
+                 halo_pitch: Optional[int] = None, balanced: bool = True, window: int = 8):
+        """window: steps per halo prefetch (begin_window) the default capacities are sized for;
+        halo_rows: distinct remote rows a window is expected to need (default: from window x batch centres' neighbourhoods);
+        halo_pitch: rows reserved per owner (default: from halo_rows); the halo region is (world - 1) x halo_pitch rows."""
         from . import _lib, ops
         from .graph import DeviceGraph
         from .sampler import PickSampler
@@ -328,11 +348,14 @@ class DistributedPCGNN:
         n_remote = max(w.n - n_local, 0)
         if halo_rows is None:       # from the batch's expected demand, not from the node count
             deg_rel = [np.diff(ip)[sh["idx_train_local"] - part.lo] for ip, _ in sh["csr"]]
-            halo_rows = expected_halo_rows(deg_rel, weights, B, self.world, n_remote)
+            halo_rows = expected_halo_rows(deg_rel, weights, B * max(int(window), 1), self.world, n_remote, kept=1.0)
         halo_rows = max(int(halo_rows), 1)
-        if serve_rows is None:      # what the others may ask of this rank: about what it asks of them; at most every owned row once per rank
-            serve_rows = min((self.world - 1) * n_local, 2 * halo_rows + 1024) if self.world > 1 else 1
-        serve_rows = max(int(serve_rows), 1)
+        # one owner's share of it (+ 25 % for the owners' imbalance), never more than the longest shard has rows; every rank
+        # must arrive at the same pitch (equal-split all-to-alls): the largest any rank computed
+        if halo_pitch is None:
+            halo_pitch = min(part.n_max, -(-halo_rows * 5 // (4 * max(self.world - 1, 1))) + 64) if self.world > 1 else 64
+        halo_pitch = self._agree_max(max(int(halo_pitch), 1))
+        halo_rows = max(self.world - 1, 1) * halo_pitch
         n_ext = n_local + P + halo_rows
         X_ext = np.zeros((n_ext, F), np.float32)
         X_ext[:n_local] = sh["X_local"]
@@ -343,10 +366,15 @@ class DistributedPCGNN:
             csr_ext.append((ip, idx))
         self.g = DeviceGraph(X_ext, csr_ext, sh["train_pos"], self.dev, id_space=w.n)
         g = self.g
-        self.halo = HaloExchangeHip(part, g.X, sh["train_pos"], serve_rows, group, stage_host)
+        # node id of every table row: owned | train-pos | halo (= the exchange's request list, -1 = unused slot)
+        self.row_gid = torch.cat([torch.arange(part.lo, part.hi, dtype=torch.int32),
+                                  torch.as_tensor(np.asarray(sh["train_pos"], dtype=np.int32).reshape(-1)),
+                                  torch.full((halo_rows,), -1, dtype=torch.int32)]).to(self.dev)
+        self.halo = HaloExchangeHip(part, g.X, sh["train_pos"], halo_pitch, group, stage_host, req_out=self.row_gid[n_local + P:])
         self.labels_local = torch.from_numpy(sh["labels_local"].astype(np.int32)).to(self.dev)
-        self.feature_rows = {"owned": n_local, "train_pos": P, "halo": halo_rows, "serve_buffer": serve_rows,
-                             "unpartitioned_table": int(w.n)}
+        self.window = max(int(window), 1)
+        self.feature_rows = {"owned": n_local, "train_pos": P, "halo": halo_rows, "halo_pitch": halo_pitch,
+                             "serve_buffer": halo_rows, "window_steps": self.window, "unpartitioned_table": int(w.n)}
 
         # parameters: identical on every rank (same seed), flat buffer as in fused.py
         self.E, self.R, self.F = cfg["emb_size"], g.R, F
@@ -371,12 +399,12 @@ class DistributedPCGNN:
         self.w_clf = self.theta[o3:o3 + 2 * F].view(2, F)
         self.b_clf = self.theta[o4:o4 + 2]
 
-        # score all-gather: shards padded to the longest one, then copied to their places in s0_full
-        self.s0_send = torch.zeros(part.n_max, dtype=torch.float32, device=self.dev)
-        self.s0_pad = torch.zeros(part.n_max * self.world, dtype=torch.float32, device=self.dev)
+        # scores by GLOBAL node id (4 bytes per node of the whole graph; only the entries of rows this rank holds are ever
+        # written or read)
         self.s0_full = torch.zeros(w.n, dtype=torch.float32, device=self.dev)
         self.keys = torch.empty(self.lib.pcg_pos_sort_capacity(P), dtype=torch.int64, device=self.dev)
-        self.ws = ops.ChooseWorkspace(g, B)
+        self.status = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self.ws = ops.ChooseWorkspace(g, B, status=self.status)
         self.cnt = torch.empty(g.R * B, dtype=torch.int32, device=self.dev)
         self.agg = torch.empty(g.R, B, F, dtype=torch.float32, device=self.dev)
         self.logits = torch.empty(B, 2, dtype=torch.float32, device=self.dev)
@@ -392,18 +420,19 @@ class DistributedPCGNN:
         self.B = B
         self.ids_buf = torch.zeros(B, dtype=torch.int32, device=self.dev)
         self.lab_buf = torch.zeros(B, dtype=torch.int32, device=self.dev)
+        self.gid_buf = torch.zeros(B, dtype=torch.int32, device=self.dev)
         self.center_buf = torch.zeros(B, dtype=torch.float32, device=self.dev)
         self._graphs, self._ws_extra = {}, {}
 
-    # -- collectives ----------------------------------------------------------------------------
-    def _all_gather(self, out, inp):
-        if self.stage_host:
-            o = torch.empty(out.shape, dtype=out.dtype)
-            dist.all_gather_into_tensor(o, inp.cpu(), group=self.group)
-            out.copy_(o)
-        else:
-            dist.all_gather_into_tensor(out, inp, group=self.group)
+    def _agree_max(self, value: int) -> int:
+        """the largest `value` over the ranks (construction-time collective)"""
+        if self.world == 1:
+            return value
+        t = torch.tensor([value], dtype=torch.int64, device="cpu" if self.stage_host else self.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return int(t.item())
 
+    # -- collectives ----------------------------------------------------------------------------
     def _all_reduce(self, t):
         if self.stage_host:
             c = t.cpu()
@@ -412,44 +441,45 @@ class DistributedPCGNN:
         else:
             dist.all_reduce(t, group=self.group)
 
-    def _gather_scores(self):
-        """s0 of every node from every rank's shard (step 1's collective)."""
-        part = self.part
-        if self.world == 1:
-            self.s0_full.copy_(self.s0_send[:part.n_local])
-            return
-        self._all_gather(self.s0_pad, self.s0_send)
-        for r in range(self.world):                                        # (shards of unequal length: `world` small copies)
-            lo, hi = int(part.bounds_host[r]), int(part.bounds_host[r + 1])
-            self.s0_full[lo:hi].copy_(self.s0_pad[r * part.n_max:r * part.n_max + hi - lo])
+    # -- the window's exchange -------------------------------------------------------------------
+    def begin_window(self, ids_window_local: torch.Tensor) -> None:
+        """COLLECTIVE.  Fetch the feature rows of every remote neighbour the given centres (local rows of owned nodes, any
+        number, duplicates allowed) have; until the next call, steps on (subsets of) these centres need no exchange.  Two
+        equal-split all-to-alls, no host synchronisation."""
+        self.halo.prefetch(self.g, ids_window_local.to(torch.int32))
 
     # -- one step ---------------------------------------------------------------------------------
-    def _seg_scores(self, ids_local, labels, B, train_flag):
-        """collective-free segment 0: this rank's rows of the score table || plan pass 1 (pcg_step_front_a)."""
-        self.ops.step_front_a(self.g, self.w_clf, self.b_clf, self.s0_send, 0, self.part.n_local, ids_local,
-                              labels if train_flag else None, self.thresholds, self.rho, train_flag, self._ws_of(B))
-
-    def _seg_select(self, ids_local, labels, B, train_flag):
-        """collective-free segment 1 (after the score all-gather): train-pos sort || plan pass 2, centre scores,
-        select (lists of global ids)."""
+    def _seg_front(self, ids_local, labels, B, train_flag):
+        """scores of every row this rank holds (owned, train-pos, halo), by node id || plan pass 1; train-pos sort || plan
+        pass 2; centre scores; select (lists of global ids); lists -> rows of the extended table."""
         ops, g, part = self.ops, self.g, self.part
         ws = self._ws_of(B)
-        keys = ops.step_front_b(g, self.s0_full, self.keys, ids_local, labels if train_flag else None, self.thresholds,
-                                self.rho, train_flag, ws)
-        self.center_buf[:B].copy_(self.s0_full[(ids_local.long() + part.lo)])
-        ops.choose_select(g, ids_local, labels if train_flag else None, self.s0_full, keys, self.thresholds, self.rho,
-                          train_flag, ws, self.cnt[:g.R * B], center_s0=self.center_buf[:B], planned=True)
+        lab = labels if train_flag else None
+        ops.step_front_a(g, self.w_clf, self.b_clf, self.s0_full, 0, g.n_nodes, ids_local, lab, self.thresholds, self.rho,
+                         train_flag, ws, row_ids=self.row_gid)
+        keys = ops.step_front_b(g, self.s0_full, self.keys, ids_local, lab, self.thresholds, self.rho, train_flag, ws)
+        torch.add(ids_local, part.lo, out=self.gid_buf[:B])
+        torch.index_select(self.s0_full, 0, self.gid_buf[:B], out=self.center_buf[:B])
+        ops.choose_select(g, ids_local, lab, self.s0_full, keys, self.thresholds, self.rho, train_flag, ws,
+                          self.cnt[:g.R * B], center_s0=self.center_buf[:B], planned=True)
+        self.halo.lookup(ws, B, g)
 
-    def _seg_dense(self, ids_local, labels, B):
-        """collective-free segment 2: gather + mean over the extended table, dense step, gradient reduction."""
+    def _seg_step(self, ids_local, labels, B):
+        """the collective-free part of a training step: front, gather over the extended table, dense step (it finishes the
+        long rows' means), this rank's gradient (slabs summed in tile order)."""
         ops, g, lib, _p = self.ops, self.g, self.lib, self.ops._p
-        agg = self.agg.view(-1)[:g.R * B * self.F].view(g.R, B, self.F)
-        ops.aggregate_lists(g, g.X, B, self._ws_of(B), self.cnt[:g.R * B], agg)
+        self._seg_front(ids_local, labels, B, True)
+        ws = self._ws_of(B)
         st = ops._stream(self.dev)
         check, c = self._libmod.check, self.cfg
-        check(lib.pcg_dense_step(g.desc_ref(), _p(self.theta), self.E, _p(ids_local), _p(labels), B, _p(agg), agg.stride(1),
-                                 float(c["alpha"]), 1.0 / (B * self.world), _p(self.logits), _p(self.center), None,
-                                 _p(self.row_loss), _p(self.slabs), _p(self.step_counter), st), "pcg_dense_step")
+        agg = self.agg.view(-1)[:g.R * B * self.F].view(g.R, B, self.F)
+        check(lib.pcg_gather_lists(_p(g.X), g.feat_dim, g.X.stride(0), g.X.shape[0], _p(self.cnt), g.desc_ref(), B, _p(ws.buf),
+                                   ws.list_capacity, _p(agg), agg.stride(1), st), "pcg_gather_lists")
+        check(lib.pcg_train_dense(g.desc_ref(), _p(self.theta), None, None, self.E, _p(ids_local), _p(labels), B, _p(agg),
+                                  agg.stride(1), _p(self.cnt), _p(ws.buf), ws.list_capacity, float(c["alpha"]),
+                                  1.0 / (B * self.world), _p(self.logits), _p(self.center), None, _p(self.row_loss),
+                                  _p(self.slabs), _p(self.step_counter), None, c["lr"], 0.9, 0.999, 1e-8, c["weight_decay"], 0,
+                                  st), "pcg_train_dense")
         check(lib.pcg_adam_step(_p(self.theta), _p(self.m), _p(self.v), _p(self.slabs), lib.pcg_dense_n_tiles(B),
                                 self.n_params, _p(self.step_counter), c["lr"], 0.9, 0.999, 1e-8, c["weight_decay"],
                                 _p(self.grad), 0, st), "pcg_adam_step")
@@ -458,20 +488,18 @@ class DistributedPCGNN:
         if B == self.ws.B:
             return self.ws
         if B not in self._ws_extra:
-            self._ws_extra[B] = self.ops.ChooseWorkspace(self.g, B)
+            self._ws_extra[B] = self.ops.ChooseWorkspace(self.g, B, status=self.status)
         return self._ws_extra[B]
 
-    def _exchange(self, B):
-        self.halo.fetch_and_remap_device(self._ws_of(B), B, self.g)
-
-    def forward_sample(self, ids_local: torch.Tensor, labels: Optional[torch.Tensor], train_flag: bool = True):
-        """steps 1-3 + aggregate: returns agg [R, B, F] for this rank's centres (local row numbers)."""
+    def forward_sample(self, ids_local: torch.Tensor, labels: Optional[torch.Tensor], train_flag: bool = True,
+                       prefetch: bool = True):
+        """COLLECTIVE if prefetch.  Scores, choose and aggregate for this rank's centres (local row numbers): returns agg
+        [R, B, F] and the set sizes.  prefetch=False: the centres are covered by the current window."""
         ops, g = self.ops, self.g
         B = ids_local.numel()
-        self._seg_scores(ids_local, labels, B, train_flag)
-        self._gather_scores()
-        self._seg_select(ids_local, labels, B, train_flag)
-        self._exchange(B)
+        if prefetch:
+            self.begin_window(ids_local)
+        self._seg_front(ids_local, labels, B, train_flag)
         agg = self.agg.view(-1)[:g.R * B * self.F].view(g.R, B, self.F)
         cnt = self.cnt[:g.R * B]
         ops.aggregate_lists(g, g.X, B, self._ws_of(B), cnt, agg)
@@ -483,66 +511,85 @@ class DistributedPCGNN:
                                              _p(self.step_counter), c["lr"], 0.9, 0.999, 1e-8, c["weight_decay"], None, 1,
                                              self.ops._stream(self.dev)), "pcg_adam_step")
 
-    def _eager_step(self, ids_local, labels, B):
-        self._seg_scores(ids_local, labels, B, True)
-        self._gather_scores()
-        self._seg_select(ids_local, labels, B, True)
-        self._exchange(B)
-        self._seg_dense(ids_local, labels, B)
-        self._all_reduce(self.grad)
-        self._apply_adam()
-
-    def _graphs_for(self, B):
-        """hipGraphs of the two collective-free segments for batch size B (static id / label buffers).  The warm-up that
-        precedes the capture is one whole eager step - exchange included, so the dense segment never sees a list of
-        global ids (every rank captures at the same step: the first one of a batch size) - whose effect on the
-        parameters is undone."""
+    def _graph_for(self, B):
+        """hipGraph of the collective-free part of a step for batch size B (static id / label buffers).  The warm-up that
+        precedes the capture runs the same kernels once; its effect on the step counter is undone (parameters are only
+        touched by _apply_adam, outside the graph)."""
         gr = self._graphs.get(B)
         if gr is not None:
             return gr
         ids, lab = self.ids_buf[:B], self.lab_buf[:B]
-        state = (self.theta.clone(), self.m.clone(), self.v.clone(), self.step_counter.clone())
-        self._eager_step(ids, lab, B)              # warm-up: kernel attributes, workspaces, RCCL channels
+        counter = self.step_counter.clone()
+        self._seg_step(ids, lab, B)                # warm-up: kernel attributes, workspaces
         torch.cuda.synchronize(self.dev)           # no collective of ours is in flight while capturing
-        gr = {}
-        for name, fn in (("select", lambda: self._seg_select(ids, lab, B, True)), ("dense", lambda: self._seg_dense(ids, lab, B))):
-            g_ = torch.cuda.CUDAGraph()
-            # thread_local: RCCL's watchdog thread may query events while this thread captures
-            with torch.cuda.graph(g_, capture_error_mode="thread_local"):
-                fn()
-            gr[name] = g_
-        for dst, src in zip((self.theta, self.m, self.v, self.step_counter), state):
-            dst.copy_(src)
+        gr = torch.cuda.CUDAGraph()
+        # thread_local: RCCL's watchdog thread may query events while this thread captures
+        with torch.cuda.graph(gr, capture_error_mode="thread_local"):
+            self._seg_step(ids, lab, B)
+        self.step_counter.copy_(counter)
         self._graphs[B] = gr
         return gr
 
     def train_step(self, ids_local: torch.Tensor, labels: torch.Tensor, use_graphs: bool = True):
-        """One training step of this rank: only the score all-gather, the halo exchange and the gradient
-        all-reduce are launched eagerly; the rest replays two captured graphs."""
+        """COLLECTIVE.  One training step on centres the current window covers (begin_window): one graph replay (or the same
+        kernels launched one by one), the gradient all-reduce - the step's only collective -, Adam.  Nothing waits for the
+        host; a list or an exchange over capacity raises a device flag (check())."""
         B = ids_local.numel()
-        if not use_graphs:
-            return self._eager_step(ids_local, labels, B)
-        self.ids_buf[:B].copy_(ids_local)
-        self.lab_buf[:B].copy_(labels)
-        ids_local, labels = self.ids_buf[:B], self.lab_buf[:B]
-        gr = self._graphs_for(B)
-        self._seg_scores(ids_local, labels, B, True)
-        self._gather_scores()
-        prof = getattr(self, "_prof", None)
-        timed = prof is not None and self._prof_step % self._prof_every == 0
-        if prof is not None:
-            self._prof_step += 1
-        if timed:      # HIP events around the select segment (bench.py's roofline at N > 1), on the launching stream
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            ev[0].record()
-        gr["select"].replay()
-        if timed:
-            ev[1].record()
-            prof.append((ev[0], ev[1], ids_local.clone(), self.cnt[:self.g.R * B].clone()))
-        self._exchange(B)
-        gr["dense"].replay()
+        timed = False
+        if use_graphs:
+            self.ids_buf[:B].copy_(ids_local)
+            self.lab_buf[:B].copy_(labels)
+            ids_local, labels = self.ids_buf[:B], self.lab_buf[:B]
+            gr = self._graph_for(B)
+            prof = getattr(self, "_prof", None)
+            timed = prof is not None and self._prof_step % self._prof_every == 0
+            if prof is not None:
+                self._prof_step += 1
+            if timed:      # HIP events around the step's kernels (bench.py's roofline at N > 1), on the launching stream
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+            gr.replay()
+            if timed:
+                ev[1].record()
+                prof.append((ev[0], ev[1], ids_local.clone(), self.cnt[:self.g.R * B].clone()))
+        else:
+            self._seg_step(ids_local, labels, B)
         self._all_reduce(self.grad)
         self._apply_adam()
+
+    def train_window(self, ids_window_local: torch.Tensor, labels_window: torch.Tensor, use_graphs: bool = True) -> None:
+        """COLLECTIVE.  begin_window on all the centres, then one train_step per consecutive batch of cfg['batch_size'] (the
+        tail batch may be shorter; every rank must pass the same number of centres)."""
+        self.begin_window(ids_window_local)
+        for b0 in range(0, ids_window_local.numel(), self.B):
+            self.train_step(ids_window_local[b0:b0 + self.B], labels_window[b0:b0 + self.B], use_graphs)
+
+    def check(self) -> None:
+        """COLLECTIVE.  Raise - on every rank, or on none - if any rank's exchange or selection list went over capacity, or a
+        step met an id outside its window, since the last check (those steps worked on lists with holes).  One small
+        all-reduce and one host read: call it per epoch, not per step."""
+        flags = torch.stack([self.halo.overflow_word[0], self.status[0]]).to(torch.int64)
+        if self.world > 1:
+            if self.stage_host:
+                c = flags.cpu()
+                dist.all_reduce(c, op=dist.ReduceOp.MAX, group=self.group)
+                flags = c
+            else:
+                dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)
+        halo, lists = (int(x) for x in flags.cpu().tolist())
+        self.halo.overflow_word.zero_()
+        self.status.zero_()
+        if halo or lists:
+            seen = self.halo.max_seen
+            what = []
+            if halo & 3:
+                what.append(f"halo exchange (flags {halo}; this rank needed up to {seen['rows_from_one_owner']} rows from one "
+                            f"owner, pitch {seen['pitch']}) - raise halo_pitch / halo_rows or shorten the window")
+            if halo & 4:
+                what.append("a step's list named a remote node its window did not fetch (begin_window must cover the step's centres)")
+            if lists:
+                what.append(f"selection list (status {lists}) - raise the list capacity")
+            raise RuntimeError("partitioned step over capacity on some rank: " + "; ".join(what))
 
     def profile_select(self, every: int = 10):
         """Start collecting (start event, end event, ids, |set| counts) of every `every`-th step's select segment."""

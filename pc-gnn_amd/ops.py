@@ -271,11 +271,12 @@ def pick_shuffled(cum: torch.Tensor, idx_train: torch.Tensor, k: int, seed: int,
 
 def step_front_a(g: DeviceGraph, W: torch.Tensor, b: torch.Tensor, s0_out: torch.Tensor, row_begin: int, row_end: int,
                  nodes: torch.Tensor, labels: Optional[torch.Tensor], thresholds: Sequence[float], rho, train_flag: bool,
-                 ws: ChooseWorkspace, add_self: bool = False):
-    """first half of step_front: scores of rows [row_begin, row_end) (as score_table) || plan pass 1."""
+                 ws: ChooseWorkspace, add_self: bool = False, row_ids: Optional[torch.Tensor] = None):
+    """first half of step_front: scores of rows [row_begin, row_end) (as score_table; with row_ids: row r's score goes to
+    s0_out[row_ids[r]], negative = skipped) || plan pass 1."""
     lib = _lib.load()
     thr, rhos = _host_arrays(g, thresholds, rho)
-    _lib.check(lib.pcg_step_front_a(g.desc_ref(), _p(W), _p(b), row_begin, row_end, _p(s0_out), None, _p(nodes), _p(labels),
+    _lib.check(lib.pcg_step_front_a(g.desc_ref(), _p(W), _p(b), row_begin, row_end, _p(s0_out), _p(row_ids), None, _p(nodes), _p(labels),
                                     nodes.numel(), thr, rhos, 1 if train_flag else 0, 1 if add_self else 0, _p(ws.buf),
                                     ws.list_capacity, _p(ws.status), _stream(g.device)), "pcg_step_front_a")
 

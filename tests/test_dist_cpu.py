@@ -1,6 +1,6 @@
 """Multi-process CPU tests (gloo, world size 2) of the N>1 path's host logic: node partition (equal and in-edge
-balanced), shard construction, pick weights with the global label frequencies, and the halo exchange (ids all-to-all ->
-rows all-to-all -> list re-index; capacity errors raised by every rank together).
+balanced), shard construction, pick weights with the global label frequencies, and the halo exchange of a window of
+steps (request list in fixed per-owner ranges -> ids all-to-all -> rows all-to-all; list look-up; capacity flags).
 The HIP kernels are not involved (they have no CPU path); GPU coverage is tests/test_dist_gpu.py."""
 import os
 import socket
@@ -20,6 +20,10 @@ def _free_port():
     return p
 
 
+def parts_owner(part, ids):
+    return part.owner(np.maximum(ids, 0))
+
+
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -31,7 +35,7 @@ def _worker(rank, world, port, q):
         w = synth.make_workload("t", 601, 25, (900, 4000), 0.2, seed=3)      # odd N: last shard is shorter
         for balanced in (False, True):
             part = Partition.balanced(total_degree(w.csr), world, rank) if balanced else Partition(w.n, world, rank)
-            if not balanced:
+            if not balanced and world == 2:
                 assert part.n_max == 301 and part.n_local == (301 if rank == 0 else 300)
             sh = shard_workload(w, part)
             # shard CSR rows == the global rows, neighbour ids stay global
@@ -47,31 +51,56 @@ def _worker(rank, world, port, q):
             sel = (w.idx_train >= part.lo) & (w.idx_train < part.hi)
             np.testing.assert_allclose(mine, glob[sel], rtol=1e-12)
             P = len(sh["train_pos"])
-            halo_rows = 400
-            X_ext = torch.zeros(part.n_local + P + halo_rows, 28)
+            pitch = 200
+            X_ext = torch.zeros(part.n_local + P + (world - 1) * pitch, 28)
             X_ext[:part.n_local, :25] = torch.from_numpy(sh["X_local"])
             X_ext[part.n_local:part.n_local + P, :25] = torch.from_numpy(sh["X_pos"])
-            hx = HaloExchange(part, X_ext, sh["train_pos"])
+            hx = HaloExchange(part, X_ext, sh["train_pos"], pitch)
+            csr_t = [(torch.from_numpy(ip), torch.from_numpy(ix.astype(np.int64))) for ip, ix in sh["csr"]]
             tp = np.asarray(sh["train_pos"])
             rs = np.random.RandomState(10 + rank)
             for trial in range(3):
-                n_list = [500, 37, 0][trial] if rank == 0 else [300, 0, 5][trial]   # uneven, incl. an empty list
-                orig = rs.randint(0, w.n, size=n_list).astype(np.int32)
-                orig[rs.rand(n_list) < 0.1] = -1                                    # holes
+                # a window of centres (uneven across ranks, duplicates, once an empty one) -> the halo holds their remote neighbourhood
+                n_c = [40, 7, 0][trial] if rank == 0 else [25, 0, 3 + rank][trial]
+                centres = torch.from_numpy(rs.randint(0, part.n_local, size=n_c).astype(np.int32))
+                hx.prefetch(csr_t, centres)
+                nbrs = np.concatenate([ix[ip[c]:ip[c + 1]] for ip, ix in sh["csr"] for c in centres.tolist()] + [np.zeros(0, np.int32)])
+                rem = ~((nbrs >= part.lo) & (nbrs < part.hi)) & ~np.isin(nbrs, tp)
+                want = np.unique(nbrs[rem])
+                req = hx.req_out.numpy()
+                assert np.array_equal(np.sort(req[req >= 0]), want), "request list = the distinct remote neighbours"
+                for j, o in enumerate(r for r in range(world) if r != rank):   # the j-th other rank's requests sit in its fixed range
+                    mine = req[j * pitch:(j + 1) * pitch]
+                    assert np.all((mine < 0) | (parts_owner(part, mine) == o))
+                got = X_ext[hx.halo_base:][req >= 0][:, :25].numpy()
+                assert np.array_equal(got, w.X[req[req >= 0]]), "halo rows = the requested global rows"
+                # a step's list: any subset of the window's neighbourhood (+ owned ids, train positives, holes)
+                pool = np.concatenate([nbrs, np.arange(part.lo, part.hi)[:50], tp[:20]]).astype(np.int32)
+                orig = rs.choice(pool, size=min(300, 4 * len(pool)), replace=True) if len(pool) else np.zeros(0, np.int32)
+                orig = orig.copy()
+                orig[rs.rand(orig.size) < 0.1] = -1
                 lst = torch.from_numpy(orig.copy())
-                n_halo = hx.fetch_and_remap(lst)
+                hx.lookup(lst)
                 new = lst.numpy()
                 keep = orig >= 0
                 assert np.array_equal(new[~keep], orig[~keep])                       # holes untouched
-                got = X_ext[torch.from_numpy(new[keep]).long(), :25].numpy()
-                assert np.array_equal(got, w.X[orig[keep]]), "re-indexed rows must be the requested global rows"
-                rem = keep & ~((orig >= part.lo) & (orig < part.hi)) & ~np.isin(orig, tp)
-                assert n_halo == len(np.unique(orig[rem])) and hx.last_stats["remote_entries"] == int(rem.sum())
-            # a halo too small on ONE rank: every rank raises (same count matrix, same verdict) - nobody is left in a collective
-            small = HaloExchange(part, X_ext[:part.n_local + P + (3 if rank == 0 else 400)], sh["train_pos"])
-            lst = torch.from_numpy(rs.randint(0, w.n, size=200).astype(np.int32))
-            with pytest.raises(RuntimeError, match="rank 0 needs"):
-                small.fetch_and_remap(lst)
+                rows = X_ext[torch.from_numpy(new[keep]).long(), :25].numpy()
+                assert np.array_equal(rows, w.X[orig[keep]]), "re-indexed rows must be the requested global rows"
+                assert int(hx.overflow_word) == 0
+            # an id outside the window: a hole + bit 4
+            far = np.setdiff1d(np.arange(w.n), np.concatenate([np.arange(part.lo, part.hi), tp, hx.req_out.numpy()]))[:1].astype(np.int32)
+            lst = torch.from_numpy(far.copy())
+            hx.lookup(lst)
+            assert int(lst[0]) == -1 and int(hx.overflow_word) == 4
+            hx.overflow_word.zero_()
+            # a pitch too small: the ids that do not fit get no slot (bit 2, holes at lookup) - and nobody waits for anybody:
+            # the all-to-alls have fixed sizes
+            small = HaloExchange(part, X_ext[:part.n_local + P + (world - 1) * 3], sh["train_pos"], 3)
+            centres = torch.from_numpy(rs.randint(0, part.n_local, size=60).astype(np.int32))
+            small.prefetch(csr_t, centres)
+            assert int(small.overflow_word) & 2 and small.max_seen["rows_from_one_owner"] > 3
+            req = small.req_out.numpy()
+            assert (req >= 0).sum() <= (world - 1) * 3
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         import traceback
@@ -80,11 +109,12 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_halo_exchange_two_ranks_gloo():
+@pytest.mark.parametrize("world", [2, 3])
+def test_halo_exchange_gloo(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in procs]
@@ -128,8 +158,10 @@ def test_balanced_partition_equalises_edges():
     d = [np.full(100, 40), np.full(100, 10)]
     wts = np.ones(100)
     assert expected_halo_rows(d, wts, 64, 1, 1000) == 1
-    assert expected_halo_rows(d, wts, 64, 2, 10 ** 9) == int(np.ceil(25 * 64 * 0.5 * 1.5 + 1024))
+    assert abs(expected_halo_rows(d, wts, 64, 2, 10 ** 9) - int(np.ceil(25 * 64 * 0.5 * 1.5 + 1024))) <= 1      # (few draws from many nodes: all distinct)
     assert expected_halo_rows(d, wts, 64, 8, 300) == 300
+    e = 25 * 6400 * 0.5                     # as many draws as there are remote nodes: 1 - 1/e of them distinct
+    assert expected_halo_rows(d, wts, 6400, 2, int(e)) == int(np.ceil(e * (1 - np.exp(-1.0)) * 1.5 + 1024))
 
 
 def test_sharded_generator_agrees_across_ranks():

@@ -2,8 +2,8 @@
 against the single-GPU path on the same global batch.  -m gpu.
 
 Shape: BASELINE configs[2]'s model (emb 128: the dense kernel variant that streams its weights) at batch 1024 per rank,
-in-edge-balanced partition, a halo region much smaller than the node count (n_ext < N), and a third scenario whose halo is
-too small on purpose: every rank must raise together."""
+in-edge-balanced partition, a halo region much smaller than the node count (n_ext < N), a scenario whose halo is too small
+on purpose and one that steps outside its prefetch window: every rank must raise together."""
 import os
 import socket
 
@@ -37,7 +37,7 @@ def _worker(rank, world, port, q):
         w = synth.make_workload("t", NODES, 32, (20000, 100000, 400000), 0.15, seed=5, skew=1.5)
         B, E, F = BATCH, EMB, 32
         cfg = dict(emb_size=E, rho=0.5, alpha=2.0, lr=0.01, weight_decay=0.001, batch_size=B, seed=11)
-        d = DistributedPCGNN(w, cfg, dev, stage_host=True)           # default: halo sized from the batch's demand
+        d = DistributedPCGNN(w, cfg, dev, stage_host=True, window=1)  # default: halo sized from the demand of a window of one batch
         part = d.part
         rows = d.feature_rows
         assert rows["owned"] + rows["train_pos"] + rows["halo"] < w.n, "the extended table must be smaller than the full one"
@@ -56,15 +56,18 @@ def _worker(rank, world, port, q):
         gids = (ids_local.long() + part.lo).to(torch.int32)
         agg_ref, cnt_ref = ops.choose_aggregate(g, gids, labels, s0, keys, [0.5] * 3, 0.5, True)
 
-        # ---- partitioned: scores all-gather, select, halo exchange, aggregate ----
+        # ---- partitioned: halo prefetch for these centres, scores of every held row, select, look-up, aggregate ----
         agg, cnt = d.forward_sample(ids_local, labels, True)
         torch.cuda.synchronize()
-        assert torch.equal(d.s0_full[:w.n], s0), "all-gathered scores must equal the single-GPU score table"
+        held = d.row_gid[d.row_gid >= 0].long()
+        assert held.numel() > part.n_local + len(w.train_pos), "the halo holds fetched rows"
+        assert torch.equal(d.s0_full[held], s0[held]), "a row's score is the same on whichever rank computes it"
         assert torch.equal(cnt.view(3, B), cnt_ref)
         assert torch.equal(agg, agg_ref), "same lists, same order of summation: bitwise equal"
-        stats = d.halo.last_stats
-        assert stats["halo_rows"] > 0 and stats["rows_served"] > 0
-        assert stats["halo_rows"] <= rows["halo"] and stats["rows_served"] <= rows["serve_buffer"]
+        seen = d.halo.max_seen
+        assert 0 < seen["rows_from_one_owner"] <= rows["halo_pitch"] and seen["halo_rows"] <= rows["halo"]
+        assert int((d.halo.req_in >= 0).sum()) > 0, "the other rank asked this one for rows"
+        d.check()                                                   # nothing over capacity
 
         # ---- one train step: gradient = all-reduced; compare with the single-GPU gradient on the global batch ----
         d.train_step(ids_local, labels, use_graphs=False)           # (every rank in the same mode: a rank's first graph step runs a whole warm-up step, collectives included)
@@ -94,20 +97,32 @@ def _worker(rank, world, port, q):
         dist.all_gather(th, d.theta.cpu())
         assert torch.equal(th[0], th[1])
         assert not torch.equal(th[0], theta0.cpu())
-        # a second and third step through the captured segments on both ranks (fresh batches): the first of them warms up and
+        # a window of two more batches through the captured step on both ranks (fresh centres): the first step warms up and
         # captures, the second replays
-        for ep in (1, 2):
-            ids2 = d.pick_epoch(B, ep)
-            d.train_step(ids2, d.labels_of(ids2))
+        ids2 = d.pick_epoch(2 * B, 1)
+        d.train_window(ids2, d.labels_of(ids2))
         torch.cuda.synchronize()
         dist.all_gather(th, d.theta.cpu())
         assert torch.equal(th[0], th[1]) and torch.isfinite(th[0]).all()
 
-        # ---- a halo that is too small on one rank only: both ranks raise (nobody is left inside a collective) ----
-        small = DistributedPCGNN(w, dict(cfg, batch_size=256), dev, stage_host=True, halo_rows=(16 if rank == 1 else 20000))
+        d.check()
+        # ---- a halo that is too small: the step itself never waits for the host (ids that do not fit become holes, a device
+        # flag is raised); check() then raises on BOTH ranks (the flags are all-reduced: nobody is left inside a collective).
+        # Rank 1 asks for a pitch of 16, rank 0 for plenty: the ranks agree on the larger - no overflow; then 16 on both. ----
+        roomy = DistributedPCGNN(w, dict(cfg, batch_size=256), dev, stage_host=True, halo_pitch=(16 if rank == 1 else 30000))
+        assert roomy.feature_rows["halo_pitch"] == 30000
+        small = DistributedPCGNN(w, dict(cfg, batch_size=256), dev, stage_host=True, halo_pitch=16)
         ids3 = small.pick_epoch(256, 0)
-        with pytest.raises(RuntimeError, match="rank 1 needs"):
-            small.train_step(ids3, small.labels_of(ids3), use_graphs=False)
+        small.begin_window(ids3)
+        small.train_step(ids3, small.labels_of(ids3), use_graphs=False)
+        with pytest.raises(RuntimeError, match="over capacity.*halo exchange"):
+            small.check()
+        small.check()                                               # the flags were cleared by the look
+        # ---- a step on centres its window does not cover: holes + a flag, and check() says so on both ranks ----
+        ids4 = d.pick_epoch(B, 9)
+        d.train_step(ids4, d.labels_of(ids4))
+        with pytest.raises(RuntimeError, match="window did not fetch"):
+            d.check()
         q.put((rank, "ok"))
     except Exception:  # pragma: no cover
         import traceback
