@@ -142,9 +142,7 @@ def run_partitioned(args, w, B, lr, wd, dev, dist, world, rank):
             m = min(W, n - k)
             ids = d.pick_epoch(m * B, first + k)
             lab = d.labels_of(ids)
-            d.begin_window(ids)
-            for i in range(m):
-                d.train_step(ids[i * B:(i + 1) * B], lab[i * B:(i + 1) * B])
+            d.train_window(ids, lab)
             k += m
 
     def barrier():

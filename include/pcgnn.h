@@ -162,6 +162,9 @@ int pcg_step_front(const pcg_graph_desc *g, const float *W, const float *b, floa
  * _a with row_ids != NULL (int32 [n_nodes] on the device; pos_keys must be NULL then): row r's score goes to s0_out[row_ids[r]],
  * rows with row_ids[r] < 0 are skipped - the partitioned path, whose table rows are owned / train-pos / halo rows while scores
  * are looked up by global node id (every rank scores the rows it holds; no score all-gather).
+ * _b with center_s0_out != NULL (float [B]): also center_s0_out[i] = s0[nodes[i] + center_id_offset] - the centres' own
+ * scores for pcg_choose_select_planned's center_s0, when `nodes` are table rows but s0 is indexed by global id (a rank of the
+ * partitioned path owns the ids [offset, offset + n_local)).
  * _a with pos_keys != NULL (training, 0 < n_pos <= 16384, every train-pos row present in g->X) also forms the unsorted keys
  * from the feature rows in the scratch half of pos_keys (a third group of workgroups); pass raw_keys_ready = 1 to _b then,
  * and its sort stages them with coalesced loads instead of gathering n_pos scores in every sort workgroup. */
@@ -172,7 +175,7 @@ int pcg_step_front_a(const pcg_graph_desc *g, const float *W, const float *b, in
 int pcg_step_front_b(const pcg_graph_desc *g, const float *s0, uint64_t *pos_keys, int32_t raw_keys_ready,
                      const int32_t *nodes, const int32_t *labels, int32_t B, const double *thresholds,
                      const double *rho, int32_t train_flag, int32_t add_self, void *workspace, int64_t list_capacity,
-                     uint32_t *status, void *stream);
+                     uint32_t *status, float *center_s0_out, int64_t center_id_offset, void *stream);
 int pcg_choose_select_planned(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B,
                               const float *s0, const float *center_s0, const uint64_t *pos_keys,
                               const double *thresholds, const double *rho, int32_t train_flag, int32_t add_self,

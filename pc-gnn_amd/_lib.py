@@ -55,7 +55,7 @@ PROTOTYPES = {
     "pcg_step_front_a": (C.c_int, [_G, _P, _P, _I64, _I64, _P, _P, _P, _P, _P, _I32, C.POINTER(_F64), C.POINTER(_F64), _I32, _I32,
                                    _P, _I64, _P, _P]),
     "pcg_step_front_b": (C.c_int, [_G, _P, _P, _I32, _P, _P, _I32, C.POINTER(_F64), C.POINTER(_F64), _I32, _I32, _P, _I64, _P,
-                                   _P]),
+                                   _P, _I64, _P]),
     "pcg_choose_select_planned": (C.c_int, [_G, _P, _P, _I32, _P, _P, _P, C.POINTER(_F64), C.POINTER(_F64), _I32, _I32,
                                             _P, _P, _I64, _P, _P]),
     "pcg_choose_aggregate_planned": (C.c_int, [_G, _P, _P, _I32, _P, _P, _P, C.POINTER(_F64), C.POINTER(_F64), _I32, _I32,

@@ -362,13 +362,17 @@ __global__ void __launch_bounds__(FRONT_COUNT_THREADS) front_a_kernel(const Choo
 
 __global__ void __launch_bounds__(PLAN_THREADS) front_b_kernel(const ChooseArgs a, const PlanTotals *totals, int n_write_blocks,
                                                                int n_count_blocks, uint64_t *__restrict__ keys, int cap,
-                                                               const uint64_t *__restrict__ raw_keys, uint32_t *pending) {
+                                                               const uint64_t *__restrict__ raw_keys, uint32_t *pending,
+                                                               float *__restrict__ center_out, int64_t center_id_offset) {
     __shared__ uint64_t sh[RANK_TILE];
     __shared__ int part[RANK_WAVES * PCG_WAVE];
     if (pending && blockIdx.x == 0 && threadIdx.x == 0) pending[0] = 0u;   // front_a (the launch before) has applied the deferred update
-    if ((int)blockIdx.x < n_write_blocks)
+    if ((int)blockIdx.x < n_write_blocks) {
+        // (partitioned path) the centres' own scores, looked up by global id: center_out[b] = s0[nodes[b] + offset]
+        const int b = (int)blockIdx.x * PLAN_THREADS + (int)threadIdx.x;
+        if (center_out && b < a.B) center_out[b] = a.s0[(int64_t)a.nodes[b] + center_id_offset];
         plan_write_body<PLAN_THREADS, FRONT_COUNT_THREADS>(a, totals, (int)blockIdx.x, n_count_blocks);
-    else
+    } else
         rank_sort_body(a.s0, a.g.train_pos, a.g.n_pos, cap, keys, (int)blockIdx.x - n_write_blocks, sh, part, raw_keys);
 }
 
@@ -543,8 +547,8 @@ int pcg_step_front_a(const pcg_graph_desc *g, const float *W, const float *b, in
 static int front_b(const pcg_graph_desc *g, const float *s0, uint64_t *pos_keys, int32_t raw_keys_ready,
                    const int32_t *nodes, const int32_t *labels, int32_t B, const double *thresholds, const double *rho,
                    int32_t train_flag, int32_t add_self, void *workspace, int64_t list_capacity, uint32_t *status,
-                   uint32_t *pending, void *stream) {
-    if (!g || !s0 || B < 0) return PCG_E_ARG;
+                   uint32_t *pending, float *center_out, int64_t center_id_offset, void *stream) {
+    if (!g || !s0 || B < 0 || (center_out && center_id_offset < 0)) return PCG_E_ARG;
     const bool sort = train_flag && g->n_pos > 0;
     if (sort && (!pos_keys || !g->train_pos)) return PCG_E_ARG;
     if (B == 0) return sort ? pcg_pos_sort(g, s0, pos_keys, stream) : PCG_OK;
@@ -561,7 +565,7 @@ static int front_b(const pcg_graph_desc *g, const float *s0, uint64_t *pos_keys,
     const int64_t cap = sort ? pcg_pos_sort_capacity(g->n_pos) / 2 : 0;
     const uint64_t *raw_keys = (rank && raw_keys_ready) ? pos_keys + cap : nullptr;
     hipLaunchKernelGGL(pcg::front_b_kernel, dim3(n_write + n_sort), dim3(pcg::PLAN_THREADS), 0, static_cast<hipStream_t>(stream), a,
-                       tot, n_write, n_count, pos_keys, (int)cap, raw_keys, pending);
+                       tot, n_write, n_count, pos_keys, (int)cap, raw_keys, pending, center_out, center_id_offset);
     PCG_LAUNCH_CHECK();
     if (sort && !rank) return pcg_pos_sort(g, s0, pos_keys, stream);    // many positives: the chunk sort's own launches
     return PCG_OK;
@@ -570,9 +574,9 @@ static int front_b(const pcg_graph_desc *g, const float *s0, uint64_t *pos_keys,
 int pcg_step_front_b(const pcg_graph_desc *g, const float *s0, uint64_t *pos_keys, int32_t raw_keys_ready,
                      const int32_t *nodes, const int32_t *labels, int32_t B, const double *thresholds, const double *rho,
                      int32_t train_flag, int32_t add_self, void *workspace, int64_t list_capacity, uint32_t *status,
-                     void *stream) {
+                     float *center_s0_out, int64_t center_id_offset, void *stream) {
     return front_b(g, s0, pos_keys, raw_keys_ready, nodes, labels, B, thresholds, rho, train_flag, add_self, workspace,
-                   list_capacity, status, nullptr, stream);
+                   list_capacity, status, nullptr, center_s0_out, center_id_offset, stream);
 }
 
 /* pcg_step_front of a TRAINING step, with the previous step's deferred Adam update riding along the score pass */
@@ -597,7 +601,7 @@ int pcg_step_front_train(const pcg_graph_desc *g, float *theta, float *m, float 
                            workspace, list_capacity, status, &ad, stream);
     if (rc != PCG_OK) return rc;
     return front_b(g, s0, pos_keys, 1, nodes, labels, B, thresholds, rho, 1, add_self, workspace, list_capacity, status,
-                   sync_words + 1, stream);
+                   sync_words + 1, nullptr, 0, stream);
 }
 
 int pcg_step_front(const pcg_graph_desc *g, const float *W, const float *b, float *s0, uint64_t *pos_keys,
@@ -609,7 +613,7 @@ int pcg_step_front(const pcg_graph_desc *g, const float *W, const float *b, floa
                                     workspace, list_capacity, status, stream);
     if (rc != PCG_OK) return rc;
     return pcg_step_front_b(g, s0, pos_keys, B > 0 ? 1 : 0, nodes, labels, B, thresholds, rho, train_flag, add_self, workspace,
-                            list_capacity, status, stream);
+                            list_capacity, status, nullptr, 0, stream);
 }
 
 int pcg_choose_aggregate(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B,

@@ -420,7 +420,8 @@ class DistributedPCGNN:
         self.B = B
         self.ids_buf = torch.zeros(B, dtype=torch.int32, device=self.dev)
         self.lab_buf = torch.zeros(B, dtype=torch.int32, device=self.dev)
-        self.gid_buf = torch.zeros(B, dtype=torch.int32, device=self.dev)
+        self.win_ids = torch.zeros(B * self.window, dtype=torch.int32, device=self.dev)
+        self.win_lab = torch.zeros(B * self.window, dtype=torch.int32, device=self.dev)
         self.center_buf = torch.zeros(B, dtype=torch.float32, device=self.dev)
         self._graphs, self._ws_extra = {}, {}
 
@@ -457,9 +458,8 @@ class DistributedPCGNN:
         lab = labels if train_flag else None
         ops.step_front_a(g, self.w_clf, self.b_clf, self.s0_full, 0, g.n_nodes, ids_local, lab, self.thresholds, self.rho,
                          train_flag, ws, row_ids=self.row_gid)
-        keys = ops.step_front_b(g, self.s0_full, self.keys, ids_local, lab, self.thresholds, self.rho, train_flag, ws)
-        torch.add(ids_local, part.lo, out=self.gid_buf[:B])
-        torch.index_select(self.s0_full, 0, self.gid_buf[:B], out=self.center_buf[:B])
+        keys = ops.step_front_b(g, self.s0_full, self.keys, ids_local, lab, self.thresholds, self.rho, train_flag, ws,
+                                center_out=self.center_buf[:B], center_id_offset=part.lo)
         ops.choose_select(g, ids_local, lab, self.s0_full, keys, self.thresholds, self.rho, train_flag, ws,
                           self.cnt[:g.R * B], center_s0=self.center_buf[:B], planned=True)
         self.halo.lookup(ws, B, g)
@@ -511,14 +511,18 @@ class DistributedPCGNN:
                                              _p(self.step_counter), c["lr"], 0.9, 0.999, 1e-8, c["weight_decay"], None, 1,
                                              self.ops._stream(self.dev)), "pcg_adam_step")
 
-    def _graph_for(self, B):
-        """hipGraph of the collective-free part of a step for batch size B (static id / label buffers).  The warm-up that
-        precedes the capture runs the same kernels once; its effect on the step counter is undone (parameters are only
-        touched by _apply_adam, outside the graph)."""
-        gr = self._graphs.get(B)
+    def _graph_for(self, B, slot: Optional[int] = None):
+        """hipGraph of the collective-free part of a step for batch size B, reading its centres from the static id / label
+        buffers (slot None) or from batch `slot` of the static window buffers.  The warm-up that precedes the capture runs the
+        same kernels once; its effect on the step counter is undone (parameters are only touched by _apply_adam, outside
+        the graph)."""
+        gr = self._graphs.get((B, slot))
         if gr is not None:
             return gr
-        ids, lab = self.ids_buf[:B], self.lab_buf[:B]
+        if slot is None:
+            ids, lab = self.ids_buf[:B], self.lab_buf[:B]
+        else:
+            ids, lab = self.win_ids[slot * self.B:slot * self.B + B], self.win_lab[slot * self.B:slot * self.B + B]
         counter = self.step_counter.clone()
         self._seg_step(ids, lab, B)                # warm-up: kernel attributes, workspaces
         torch.cuda.synchronize(self.dev)           # no collective of ours is in flight while capturing
@@ -527,42 +531,56 @@ class DistributedPCGNN:
         with torch.cuda.graph(gr, capture_error_mode="thread_local"):
             self._seg_step(ids, lab, B)
         self.step_counter.copy_(counter)
-        self._graphs[B] = gr
-        return gr
+        self._graphs[(B, slot)] = (gr, ids)
+        return gr, ids
+
+    def _replay_step(self, gr, ids, B):
+        """graph replay (bracketed by HIP events on every `profile_select`-th step), gradient all-reduce, Adam"""
+        prof = getattr(self, "_prof", None)
+        timed = prof is not None and self._prof_step % self._prof_every == 0
+        if prof is not None:
+            self._prof_step += 1
+        if timed:      # on the launching stream: bench.py's roofline at N > 1
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        gr.replay()
+        if timed:
+            ev[1].record()
+            prof.append((ev[0], ev[1], ids.clone(), self.cnt[:self.g.R * B].clone()))
+        self._all_reduce(self.grad)
+        self._apply_adam()
 
     def train_step(self, ids_local: torch.Tensor, labels: torch.Tensor, use_graphs: bool = True):
         """COLLECTIVE.  One training step on centres the current window covers (begin_window): one graph replay (or the same
         kernels launched one by one), the gradient all-reduce - the step's only collective -, Adam.  Nothing waits for the
         host; a list or an exchange over capacity raises a device flag (check())."""
         B = ids_local.numel()
-        timed = False
-        if use_graphs:
-            self.ids_buf[:B].copy_(ids_local)
-            self.lab_buf[:B].copy_(labels)
-            ids_local, labels = self.ids_buf[:B], self.lab_buf[:B]
-            gr = self._graph_for(B)
-            prof = getattr(self, "_prof", None)
-            timed = prof is not None and self._prof_step % self._prof_every == 0
-            if prof is not None:
-                self._prof_step += 1
-            if timed:      # HIP events around the step's kernels (bench.py's roofline at N > 1), on the launching stream
-                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                ev[0].record()
-            gr.replay()
-            if timed:
-                ev[1].record()
-                prof.append((ev[0], ev[1], ids_local.clone(), self.cnt[:self.g.R * B].clone()))
-        else:
+        if not use_graphs:
             self._seg_step(ids_local, labels, B)
-        self._all_reduce(self.grad)
-        self._apply_adam()
+            self._all_reduce(self.grad)
+            self._apply_adam()
+            return
+        self.ids_buf[:B].copy_(ids_local)
+        self.lab_buf[:B].copy_(labels)
+        gr, ids = self._graph_for(B)
+        self._replay_step(gr, ids, B)
 
     def train_window(self, ids_window_local: torch.Tensor, labels_window: torch.Tensor, use_graphs: bool = True) -> None:
-        """COLLECTIVE.  begin_window on all the centres, then one train_step per consecutive batch of cfg['batch_size'] (the
-        tail batch may be shorter; every rank must pass the same number of centres)."""
+        """COLLECTIVE.  begin_window on all the centres, then one training step per consecutive batch of cfg['batch_size'] (the
+        tail batch may be shorter; every rank must pass the same number of centres).  With graphs, the window's ids and
+        labels are copied once into static buffers that the steps' graphs (one per batch position) read in place."""
+        n = ids_window_local.numel()
         self.begin_window(ids_window_local)
-        for b0 in range(0, ids_window_local.numel(), self.B):
-            self.train_step(ids_window_local[b0:b0 + self.B], labels_window[b0:b0 + self.B], use_graphs)
+        if use_graphs and n <= self.win_ids.numel():
+            self.win_ids[:n].copy_(ids_window_local)
+            self.win_lab[:n].copy_(labels_window)
+            for slot, b0 in enumerate(range(0, n, self.B)):
+                B = min(self.B, n - b0)
+                gr, ids = self._graph_for(B, slot)
+                self._replay_step(gr, ids, B)
+        else:
+            for b0 in range(0, n, self.B):
+                self.train_step(ids_window_local[b0:b0 + self.B], labels_window[b0:b0 + self.B], use_graphs)
 
     def check(self) -> None:
         """COLLECTIVE.  Raise - on every rank, or on none - if any rank's exchange or selection list went over capacity, or a

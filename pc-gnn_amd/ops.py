@@ -283,12 +283,14 @@ def step_front_a(g: DeviceGraph, W: torch.Tensor, b: torch.Tensor, s0_out: torch
 
 def step_front_b(g: DeviceGraph, s0: torch.Tensor, pos_keys: Optional[torch.Tensor], nodes: torch.Tensor,
                  labels: Optional[torch.Tensor], thresholds: Sequence[float], rho, train_flag: bool, ws: ChooseWorkspace,
-                 add_self: bool = False):
-    """second half of step_front: train-pos sort by s0 || plan pass 2.  Returns the sorted keys (or None)."""
+                 add_self: bool = False, center_out: Optional[torch.Tensor] = None, center_id_offset: int = 0):
+    """second half of step_front: train-pos sort by s0 || plan pass 2 (|| center_out[i] = s0[nodes[i] + center_id_offset]).
+    Returns the sorted keys (or None)."""
     lib = _lib.load()
     thr, rhos = _host_arrays(g, thresholds, rho)
     sort = bool(train_flag) and g.n_pos > 0
     _lib.check(lib.pcg_step_front_b(g.desc_ref(), _p(s0), _p(pos_keys) if sort else None, 0, _p(nodes), _p(labels),
                                     nodes.numel(), thr, rhos, 1 if train_flag else 0, 1 if add_self else 0, _p(ws.buf),
-                                    ws.list_capacity, _p(ws.status), _stream(g.device)), "pcg_step_front_b")
+                                    ws.list_capacity, _p(ws.status), _p(center_out), center_id_offset, _stream(g.device)),
+               "pcg_step_front_b")
     return pos_keys if sort else None
