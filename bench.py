@@ -59,6 +59,8 @@ def parse():
                     help="run the node-partitioned RCCL path even at world size 1 (rehearsal of the N>1 code)")
     ap.add_argument("--window", type=int, default=8, help="partitioned path: steps per halo prefetch (feature rows never change, "
                     "so the remote rows of a window's centres are fetched once)")
+    ap.add_argument("--timed-graphs", action="store_true", help="event-bracketed steps as three graph launches instead of five "
+                    "kernel launches (the middle graph's launch latency then lands inside the bracket)")
     ap.add_argument("--event-every", type=int, default=10,
                     help="graph engine: bracket the select+aggregate launch with HIP events on every step of every Nth epoch")
     ap.add_argument("--engine", default=None, choices=["graph", "fused", "torch", "dp"],
@@ -277,7 +279,7 @@ def main():
                     o += p.numel()
             tr.opt.step()
         elif epoch_graphs and timed:   # the staged batch as front | select + aggregate | dense + Adam graphs with events
-            tr.fused.epoch_step_timed(state["b"] - 1)
+            tr.fused.epoch_step_timed(state["b"] - 1, eager=not args.timed_graphs)
         elif dist is None:        # (graph engine: the per-batch graphs; whole epochs go through run_epoch_one_graph below)
             tr.step(ids, timed)
         else:

@@ -108,6 +108,7 @@ __device__ __forceinline__ void score_table_body(const float *__restrict__ X, in
                                                  const float *__restrict__ W, const float *__restrict__ bias,
                                                  int64_t row_begin, int64_t row_end, float *__restrict__ s0, int block,
                                                  int n_blocks, const int32_t *__restrict__ row_ids = nullptr) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
     const int lane = lane_id();
     const int lpr = lanes_per_row(stride);
     const int rpw = PCG_WAVE / lpr;
@@ -116,12 +117,59 @@ __device__ __forceinline__ void score_table_body(const float *__restrict__ X, in
     const int64_t n_waves = (int64_t)n_blocks * (blockDim.x >> 6);
     const float b0 = bias[0];
     const int64_t rows_per_iter = (int64_t)rpw * SCORE_UNROLL;
+    // A lane's share of a row is the same float4 chunk(s) of every row (sub, sub + lpr: feat_stride <= 512 floats => at most
+    // two), so its weights are loaded once.  All loads are unconditional - index clamped, value discarded by a select - because
+    // a load inside a conditional is compiled into a branch that first waits for every load in flight: the row loads of the
+    // unrolled iterations would go out one at a time.  Same fma order as score_partial => the same bits.
+    const int nch = stride >> 2;
+    constexpr int SCORE_K = 2;
+    bool has[SCORE_K];
+    int chc[SCORE_K];
+    float wv[SCORE_K][4];
+#pragma unroll
+    for (int k = 0; k < SCORE_K; ++k) {
+        const int ch = sub + k * lpr;
+        has[k] = ch < nch;
+        chc[k] = has[k] ? ch : nch - 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = 4 * chc[k] + j;
+            // (masked with AND rather than replaced by a select: a value that is only used under a condition gets its load
+            //  sunk into a branch again)
+            const float wj = W[f < feat_dim ? f : feat_dim - 1];
+            wv[k][j] = __int_as_float(__float_as_int(wj) & ((has[k] && f < feat_dim) ? -1 : 0));
+        }
+    }
+    const bool two = lpr < nch;                                           // (wave-uniform)
     for (int64_t base = row_begin + wave_global * rows_per_iter; base < row_end; base += n_waves * rows_per_iter) {
-        float p[SCORE_UNROLL];
+        f4 xv[SCORE_UNROLL][SCORE_K];
 #pragma unroll
         for (int u = 0; u < SCORE_UNROLL; ++u) {
             const int64_t row = base + (int64_t)u * rpw + slot;
-            p[u] = row < row_end ? score_partial<PCG_SCORE_NT != 0>(X + row * stride, W, feat_dim, stride, sub, lpr) : 0.f;
+            const float *xrow = X + (row < row_end ? row : row_end - 1) * stride;
+            xv[u][0] = PCG_SCORE_NT != 0 ? __builtin_nontemporal_load(reinterpret_cast<const f4 *>(xrow + 4 * chc[0]))
+                                         : *reinterpret_cast<const f4 *>(xrow + 4 * chc[0]);
+            if (two)
+                xv[u][1] = PCG_SCORE_NT != 0 ? __builtin_nontemporal_load(reinterpret_cast<const f4 *>(xrow + 4 * chc[1]))
+                                             : *reinterpret_cast<const f4 *>(xrow + 4 * chc[1]);
+        }
+        float p[SCORE_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SCORE_UNROLL; ++u) {
+            float q = 0.f;
+            if (has[0]) {
+                q = fmaf(xv[u][0].x, wv[0][0], q);
+                q = fmaf(xv[u][0].y, wv[0][1], q);
+                q = fmaf(xv[u][0].z, wv[0][2], q);
+                q = fmaf(xv[u][0].w, wv[0][3], q);
+            }
+            if (two && has[1]) {
+                q = fmaf(xv[u][1].x, wv[1][0], q);
+                q = fmaf(xv[u][1].y, wv[1][1], q);
+                q = fmaf(xv[u][1].z, wv[1][2], q);
+                q = fmaf(xv[u][1].w, wv[1][3], q);
+            }
+            p[u] = q;
         }
         // after the butterfly every lane of a row-group holds that row's sum: lane `sub` keeps the result of
         // unrolled row `sub`, so the wave writes its rpw * SCORE_UNROLL consecutive scores in ONE store
@@ -200,8 +248,12 @@ __device__ __forceinline__ void rank_sort_body(const float *__restrict__ s0, con
     // a key costs two dependent loads (train_pos[i], then s0 of it): this thread's own key and its share of a tile's keys
     // are requested level by level, so the staging of a tile costs two load latencies in all
     constexpr int PER = RANK_TILE / (RANK_WAVES * PCG_WAVE);
-    const int id_mine = (!raw && i < n_pos) ? train_pos[i] : 0;
-    uint64_t mine = (raw && i < n_pos) ? raw[i] : ~0ull;                   // ~0 when i >= n_pos
+    // (every load here is unconditional - index clamped, the value OR-ed with all-ones where it must not count: a load inside
+    //  a conditional is compiled into a branch that waits for every load in flight, and a tile's PER loads per thread would
+    //  go out one at a time)
+    const int ic = i < n_pos ? i : (n_pos > 0 ? n_pos - 1 : 0);
+    const int id_mine = raw ? 0 : train_pos[ic];
+    uint64_t mine = (raw ? raw[ic] : 0ull) | (i < n_pos ? 0ull : ~0ull);   // ~0 when i >= n_pos
     int c = 0;
     for (int t0 = 0; t0 < n_pos; t0 += RANK_TILE) {
         const int nt = (n_pos - t0 < RANK_TILE) ? n_pos - t0 : RANK_TILE;
@@ -210,7 +262,7 @@ __device__ __forceinline__ void rank_sort_body(const float *__restrict__ s0, con
 #pragma unroll
             for (int u = 0; u < PER; ++u) {
                 const int t = (int)threadIdx.x + u * (int)blockDim.x;
-                kt[u] = t < nt ? raw[t0 + t] : ~0ull;
+                kt[u] = raw[t0 + (t < nt ? t : nt - 1)] | (t < nt ? 0ull : ~0ull);
             }
             __syncthreads();
 #pragma unroll
@@ -224,12 +276,12 @@ __device__ __forceinline__ void rank_sort_body(const float *__restrict__ s0, con
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int t = (int)threadIdx.x + u * (int)blockDim.x;
-            idt[u] = t < nt ? train_pos[t0 + t] : 0;
+            idt[u] = train_pos[t0 + (t < nt ? t : nt - 1)];
         }
         float st[PER];
 #pragma unroll
         for (int u = 0; u < PER; ++u) st[u] = s0[idt[u]];
-        if (t0 == 0 && i < n_pos) mine = ((uint64_t)orderable(s0[id_mine]) << 32) | (uint32_t)i;
+        if (t0 == 0) mine = (((uint64_t)orderable(s0[id_mine]) << 32) | (uint32_t)i) | (i < n_pos ? 0ull : ~0ull);
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < PER; ++u) {

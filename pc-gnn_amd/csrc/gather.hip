@@ -74,35 +74,47 @@ __global__ void __launch_bounds__(256) gather_chunks(const AggArgs a) {
         if (ch != ch0) desc = a.chunk_desc[ch];
         const int row = desc.x, n = desc.z, nch_row = desc.w;
         const int32_t *__restrict__ list = a.list + desc.y;
-        const int cnt = nch_row == 1 ? a.cnt[row] : 1;
+        const int cnt = a.cnt[row];                                    // (only single-chunk rows use it; requested up front)
         float4 acc[NACC];
 #pragma unroll
         for (int x = 0; x < NACC; ++x) acc[x] = make_float4(0.f, 0.f, 0.f, 0.f);
+        // Every load below is UNCONDITIONAL (index clamped, value discarded by a select afterwards): a load inside a
+        // conditional makes the compiler branch around it and wait for everything outstanding first, which serialises the
+        // row gathers - one in flight per wave instead of UNROLL.  The ids of one iteration (rpw * UNROLL <= 64) are one
+        // coalesced load, dealt out to the row slots by cross-lane reads; the next iteration's ids are requested before
+        // this iteration's rows.
         const int per_iter = q.rpw * UNROLL;
+        // (negative = nothing there, or a hole left by a duplicate.  The sign bit is OR-ed in rather than the value replaced:
+        //  a value that is only used under a condition gets its load sunk into a branch again)
+        int my = list[lane < n ? lane : (n > 0 ? n - 1 : 0)];
+        my |= (lane >= n || lane >= per_iter) ? (int)0x80000000 : 0;
         for (int base = 0; base < n; base += per_iter) {
+            const int ln = base + per_iter + lane;
+            int nxt = list[ln < n ? ln : n - 1];
+            nxt |= (ln >= n || lane >= per_iter) ? (int)0x80000000 : 0;
             float4 v[UNROLL][NACC];
+            int ids[UNROLL];
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
-                const int i = base + u * q.rpw + q.slot;
-                const int id = i < n ? list[i] : -1;                  // -1: hole left by a duplicate
-                const bool ok = id >= 0;
-                const float *rowp = a.X + (size_t)(ok ? id : 0) * a.feat_stride;
+                ids[u] = __shfl(my, u * q.rpw + q.slot);
+                const float *rowp = a.X + (size_t)(ids[u] >= 0 ? ids[u] : 0) * a.feat_stride;
 #pragma unroll
                 for (int x = 0; x < NACC; ++x) {
                     const int c4 = x * q.lpr + q.sub;
-                    v[u][x] = (ok && c4 < q.nch) ? *reinterpret_cast<const float4 *>(rowp + 4 * c4)
-                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+                    v[u][x] = *reinterpret_cast<const float4 *>(rowp + 4 * (c4 < q.nch ? c4 : q.nch - 1));
                 }
             }
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u)
 #pragma unroll
                 for (int x = 0; x < NACC; ++x) {
-                    acc[x].x += v[u][x].x;
-                    acc[x].y += v[u][x].y;
-                    acc[x].z += v[u][x].z;
-                    acc[x].w += v[u][x].w;
+                    const bool ok = ids[u] >= 0 && x * q.lpr + q.sub < q.nch;
+                    acc[x].x += ok ? v[u][x].x : 0.f;
+                    acc[x].y += ok ? v[u][x].y : 0.f;
+                    acc[x].z += ok ? v[u][x].z : 0.f;
+                    acc[x].w += ok ? v[u][x].w : 0.f;
                 }
+            my = nxt;
         }
 #pragma unroll
         for (int x = 0; x < NACC; ++x)

@@ -336,10 +336,12 @@ class FusedPCGNN:
             self._ep_graphs[key] = gr
         gr.replay()
 
-    def epoch_step_timed(self, b: int):
-        """Batch b of the staged epoch as three graphs - front | select + aggregate | dense + Adam - with HIP events
-        around the middle one (appended to ``_prof``): the same kernels in the same order as one step of ``epoch_run``,
-        reading the staged ids in place (no copies, no label gather)."""
+    def epoch_step_timed(self, b: int, eager: bool = True):
+        """Batch b of the staged epoch with HIP events around the select + gather call (appended to ``_prof``): the same
+        kernels in the same order as one step of ``epoch_run``, reading the staged ids in place (no copies, no label
+        gather).  eager: the five kernels launched one by one with the two event records between them (the host stays
+        ahead of the GPU, so the events bracket the two kernels and nothing else); otherwise three graphs - front | select +
+        gather | dense - whose launch latency lands inside the bracket."""
         lo = b * self._ep_bs
         B = min(self._ep_bs, self._ep_n - lo)
         if B <= 0:
@@ -349,6 +351,21 @@ class FusedPCGNN:
         grs = self._ep_graphs.get(key)
         ids, lab = self._ep_ids[lo:lo + B], self._ep_lab[lo:lo + B]
         g = self.g
+        if eager:
+            agg = self.agg.view(-1)[:g.R * B * g.feat_dim].view(g.R, B, g.feat_dim)
+            keys = self.keys if g.n_pos else None
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self._enqueue_front_train(ids, lab, B)
+            ev[0].record()
+            self._enqueue_choose(ids, lab, B, keys, True, planned=True, combine=False)
+            ev[1].record()
+            self._enqueue_tail(ids, lab, B, agg, True)
+            if lo + B >= self._ep_n:              # the epoch's last batch: nothing follows that would apply the deferred update
+                self.flush()
+            if self._prof is not None:
+                self._prof.append(ev)
+            self.last_counts = self.cnt.view(-1)[:g.R * B].view(g.R, B)
+            return
         if grs is None:
             agg = self.agg.view(-1)[:g.R * B * g.feat_dim].view(g.R, B, g.feat_dim)
             keys = self.keys if g.n_pos else None
