@@ -276,17 +276,36 @@ __device__ __forceinline__ void plan_write_body(const ChooseArgs &a, const PlanT
     long long run_cap = 0, all_cap = 0;
     int run_chunk = 0, all_chunk = 0;
     TierCounts run = {0, 0, 0, 0, 0}, all = {0, 0, 0, 0, 0};
+    // the totals of the count blocks before this block's rows, and of all of them: wave 0 reads them a lane each (one load
+    // latency; a loop of uniform loads is one scalar-load round trip per count block - 48 of them at B = 4096) and adds them up
+    // across lanes; everybody picks the 14 sums up from LDS
     const int before = block * (THREADS / COUNT_THREADS);
-    for (int bk = 0; bk < n_count_blocks; ++bk) {       // a few dozen uniform loads
-        const PlanTotals t = totals[bk];
-        const TierCounts tc = {t.na, t.n0, t.n1, t.n4, t.n16};
-        if (bk < before) {
-            run_cap += t.cap; run_chunk += t.chunk;
-            tier_add(run, tc);
+    __shared__ long long s_sum[2][8];
+    if (threadIdx.x < PCG_WAVE) {
+        long long v[2][7] = {{0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0}};
+        for (int bk = (int)threadIdx.x; bk < n_count_blocks; bk += PCG_WAVE) {
+            const PlanTotals t = totals[bk];
+            const long long q[7] = {t.cap, t.chunk, t.na, t.n0, t.n1, t.n4, t.n16};
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                v[1][j] += q[j];
+                v[0][j] += bk < before ? q[j] : 0;
+            }
         }
-        all_cap += t.cap; all_chunk += t.chunk;
-        tier_add(all, tc);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                long long x = v[h][j];
+                for (int o = 1; o < PCG_WAVE; o <<= 1) x += __shfl_xor(x, o);
+                if (threadIdx.x == 0) s_sum[h][j] = x;
+            }
     }
+    __syncthreads();
+    run_cap = s_sum[0][0]; run_chunk = (int)s_sum[0][1];
+    run = {(int)s_sum[0][2], (int)s_sum[0][3], (int)s_sum[0][4], (int)s_sum[0][5], (int)s_sum[0][6]};
+    all_cap = s_sum[1][0]; all_chunk = (int)s_sum[1][1];
+    all = {(int)s_sum[1][2], (int)s_sum[1][3], (int)s_sum[1][4], (int)s_sum[1][5], (int)s_sum[1][6]};
     const bool overflow = all_cap > a.w.list_capacity || (long long)all_chunk > a.w.chunk_cap;
     const int row = block * THREADS + (int)threadIdx.x;
     RowRec rec;
@@ -364,7 +383,7 @@ __global__ void __launch_bounds__(PLAN_THREADS) front_b_kernel(const ChooseArgs 
                                                                int n_count_blocks, uint64_t *__restrict__ keys, int cap,
                                                                const uint64_t *__restrict__ raw_keys, uint32_t *pending,
                                                                float *__restrict__ center_out, int64_t center_id_offset) {
-    __shared__ uint64_t sh[RANK_TILE];
+    __shared__ __align__(16) uint64_t sh[RANK_TILE];
     __shared__ int part[RANK_WAVES * PCG_WAVE];
     if (pending && blockIdx.x == 0 && threadIdx.x == 0) pending[0] = 0u;   // front_a (the launch before) has applied the deferred update
     if ((int)blockIdx.x < n_write_blocks) {

@@ -266,10 +266,7 @@ __device__ __forceinline__ void rank_sort_body(const float *__restrict__ s0, con
             }
             __syncthreads();
 #pragma unroll
-            for (int u = 0; u < PER; ++u) {
-                const int t = (int)threadIdx.x + u * (int)blockDim.x;
-                if (t < nt) sh[t] = kt[u];
-            }
+            for (int u = 0; u < PER; ++u) sh[(int)threadIdx.x + u * (int)blockDim.x] = kt[u];      // (all-ones beyond nt)
             __syncthreads();
         } else {
         int idt[PER];
@@ -286,18 +283,26 @@ __device__ __forceinline__ void rank_sort_body(const float *__restrict__ s0, con
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int t = (int)threadIdx.x + u * (int)blockDim.x;
-            if (t < nt) sh[t] = ((uint64_t)orderable(st[u]) << 32) | (uint32_t)(t0 + t);
+            sh[t] = (((uint64_t)orderable(st[u]) << 32) | (uint32_t)(t0 + t)) | (t < nt ? 0ull : ~0ull);
         }
         __syncthreads();
         }
-        const int chunk = (nt + RANK_WAVES - 1) / RANK_WAVES;
-        const int j0 = wave * chunk, j1 = (j0 + chunk < nt) ? j0 + chunk : nt;
-        int j = j0;
-        for (; j + 4 <= j1; j += 4) {
-            const uint64_t a0 = sh[j], a1 = sh[j + 1], a2 = sh[j + 2], a3 = sh[j + 3];
-            c += (a0 < mine) + (a1 < mine) + (a2 < mine) + (a3 < mine);
+        // this wave's stretch of the tile, eight keys (four 16-byte broadcast reads) per iteration; the tile is padded
+        // with all-ones keys (never smaller than anybody's), so the stretches need no tail handling
+        const int chunk = (((nt + RANK_WAVES - 1) / RANK_WAVES) + 7) & ~7;
+        const int j0 = wave * chunk;
+        int j1 = j0 + chunk;
+        const int nt8 = (nt + 7) & ~7;
+        j1 = j1 < nt8 ? j1 : nt8;
+        const uint4 *sh4 = reinterpret_cast<const uint4 *>(sh);
+        for (int j = j0; j < j1; j += 8) {
+            const uint4 q0 = sh4[(j >> 1) + 0], q1 = sh4[(j >> 1) + 1], q2 = sh4[(j >> 1) + 2], q3 = sh4[(j >> 1) + 3];
+            const uint64_t a0 = ((uint64_t)q0.y << 32) | q0.x, a1 = ((uint64_t)q0.w << 32) | q0.z;
+            const uint64_t a2 = ((uint64_t)q1.y << 32) | q1.x, a3 = ((uint64_t)q1.w << 32) | q1.z;
+            const uint64_t a4 = ((uint64_t)q2.y << 32) | q2.x, a5 = ((uint64_t)q2.w << 32) | q2.z;
+            const uint64_t a6 = ((uint64_t)q3.y << 32) | q3.x, a7 = ((uint64_t)q3.w << 32) | q3.z;
+            c += (a0 < mine) + (a1 < mine) + (a2 < mine) + (a3 < mine) + (a4 < mine) + (a5 < mine) + (a6 < mine) + (a7 < mine);
         }
-        for (; j < j1; ++j) c += sh[j] < mine;
     }
     part[wave * PCG_WAVE + lane] = c;
     __syncthreads();

@@ -556,21 +556,46 @@ __global__ void __launch_bounds__(DENSE_THREADS) dense_step_kernel(const DenseAr
         __syncthreads();
         const int n_tiles = (int)gridDim.x / S;
         const int64_t oc = off_clf(F, E, R);
-        for (int i = tid; i < 2 * F + 2; i += DENSE_THREADS) {
-            float acc[4] = {0.f, 0.f, 0.f, 0.f};
-            int s = 0;
-            for (; s + 4 <= n_tiles; s += 4) {
+        const int NC = 2 * F + 2;
+        // G threads per parameter: thread (g, i) adds up the tiles s = g, g + G, ... of parameter i in that order (the loads of
+        // a batch of eight are all in flight: one memory round trip per batch instead of one per tile), the G partial sums
+        // are added in group order - a fixed order for a given batch size, like everything else here.  s_dh is free by now.
+        int G = NC <= DENSE_THREADS ? (DENSE_THREADS / NC < 16 ? DENSE_THREADS / NC : 16) : 1;
+        const int room = (R * TB * ldE) / NC;                  // what s_dh can hold
+        G = G < room ? G : room;
+        G = G < 1 ? 1 : G;
+        float *s_red = s_dh;                                   // [G][NC] (only when G > 1)
+        for (int i0 = 0; i0 < NC; i0 += DENSE_THREADS) {       // (one pass unless there are more parameters than threads)
+            const int g = G > 1 ? tid / NC : 0, i = i0 + (G > 1 ? tid - g * NC : tid);
+            float acc = 0.f;
+            if (g < G && i < NC) {
+                const float *src = a.slabs + oc + i;
+                int s2 = g;
+                for (; s2 + 7 * G < n_tiles; s2 += 8 * G) {
+                    float x[8];
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    acc[u] += __hip_atomic_load(a.slabs + (size_t)(s + u) * a.n_params + oc + i, __ATOMIC_RELAXED,
-                                                __HIP_MEMORY_SCOPE_AGENT);
+                    for (int u = 0; u < 8; ++u)
+                        x[u] = __hip_atomic_load(src + (size_t)(s2 + u * G) * a.n_params, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc += x[u];
+                }
+                for (; s2 < n_tiles; s2 += G)
+                    acc += __hip_atomic_load(src + (size_t)s2 * a.n_params, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            for (; s < n_tiles; ++s)
-                acc[0] += __hip_atomic_load(a.slabs + (size_t)s * a.n_params + oc + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const float g = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-            // t: the step this launch counted (block 0 incremented the counter at its start; read it past the L1)
-            const float t = (float)__hip_atomic_load(a.step_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            adam_apply_one(a.theta, a.m, a.v, oc + i, g, t, a.h);
+            if (G > 1) {
+                if (g < G && i < NC) s_red[g * NC + i] = acc;
+                __syncthreads();
+                if (tid < NC) {
+                    acc = s_red[tid];
+                    for (int gg = 1; gg < G; ++gg) acc += s_red[gg * NC + tid];
+                }
+            }
+            const int ip = G > 1 ? tid : i;
+            if (ip < NC) {
+                // t: the step this launch counted (block 0 incremented the counter at its start; read it past the L1)
+                const float t = (float)__hip_atomic_load(a.step_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                adam_apply_one(a.theta, a.m, a.v, oc + ip, acc, t, a.h);
+            }
         }
         if (tid == 0) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }

@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(SORT_THREADS) pos_sort_local(const float *__re
 __global__ void __launch_bounds__(RANK_WAVES *PCG_WAVE) pos_rank_sort(const float *__restrict__ s0,
                                                                       const int32_t *__restrict__ train_pos,
                                                                       int n_pos, int cap, uint64_t *__restrict__ keys) {
-    __shared__ uint64_t sh[RANK_TILE];
+    __shared__ __align__(16) uint64_t sh[RANK_TILE];
     __shared__ int part[RANK_WAVES * PCG_WAVE];
     rank_sort_body(s0, train_pos, n_pos, cap, keys, (int)blockIdx.x, sh, part);
 }
