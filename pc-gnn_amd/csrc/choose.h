@@ -103,6 +103,24 @@ struct ChooseArgs {
     Workspace w;
 };
 
+// DPP-selected lane value (full-rate VALU, no LDS crossbar round trip as __shfl would make)
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v, uint32_t old = 0u) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, 0xF, 0xF, false);
+}
+
+// wave-wide inclusive scan: row_shr 1, 2, 4, 8 inside every 16-lane row (a lane without a source adds 0), then the row
+// totals through scalar registers
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+    v += (int)dpp_u32<0x111>((uint32_t)v);
+    v += (int)dpp_u32<0x112>((uint32_t)v);
+    v += (int)dpp_u32<0x114>((uint32_t)v);
+    v += (int)dpp_u32<0x118>((uint32_t)v);
+    const int t0 = __builtin_amdgcn_readlane(v, 15), t1 = __builtin_amdgcn_readlane(v, 31), t2 = __builtin_amdgcn_readlane(v, 47);
+    const int row = lane >> 4;
+    return v + (row > 0 ? t0 : 0) + (row > 1 ? t1 : 0) + (row > 2 ? t2 : 0);
+}
+
 // select.hip
 int launch_select_rows(const ChooseArgs &a, hipStream_t st);
 

@@ -97,6 +97,40 @@ __device__ __forceinline__ T block_excl_scan(T v, T *lds /* >= waves */, T &tota
     return pre + inc - v;
 }
 
+// The plan's four per-row quantities (list entries, gather chunks, tier membership) scanned over the block with ONE pair of
+// barriers: 32-bit DPP scans inside every wave (the tier of a row is a one in one of five 8-bit counters - a wave has at most
+// 64 rows), the waves' totals through LDS as one int4 each, the list offset widened to 64 bits across waves.
+struct PlanScan {
+    long long cap;
+    int chunk;
+    TierCounts t;
+};
+__device__ __forceinline__ void plan_scan_add(PlanScan &s, const int4 x) {
+    s.cap += (long long)(uint32_t)x.x;
+    s.chunk += x.y;
+    s.t.na += x.z & 0xFF; s.t.n0 += (x.z >> 8) & 0xFF; s.t.n1 += (x.z >> 16) & 0xFF; s.t.n4 += (x.z >> 24) & 0xFF;
+    s.t.n16 += x.w;
+}
+// tier < 0: the thread has no row.  pre = sums over the block's threads before this one, tot = over the whole block
+__device__ __forceinline__ void block_excl_scan_plan(int cap, int nch, int tier, int4 *lds /* >= waves */, PlanScan &pre,
+                                                     PlanScan &tot) {
+    const int lane = lane_id(), wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int w1 = (tier >= 0 && tier < 4) ? 1 << (8 * tier) : 0, w2 = tier == 4 ? 1 : 0;
+    const int4 inc = make_int4(wave_incl_scan(cap, lane), wave_incl_scan(nch, lane), wave_incl_scan(w1, lane),
+                               wave_incl_scan(w2, lane));
+    if (lane == PCG_WAVE - 1) lds[wave] = inc;
+    __syncthreads();
+    pre = {0, 0, {0, 0, 0, 0, 0}};
+    tot = {0, 0, {0, 0, 0, 0, 0}};
+    for (int w = 0; w < nw; ++w) {
+        const int4 x = lds[w];
+        if (w < wave) plan_scan_add(pre, x);
+        plan_scan_add(tot, x);
+    }
+    __syncthreads();
+    plan_scan_add(pre, make_int4(inc.x - cap, inc.y - nch, inc.z - w1, inc.w - w2));
+}
+
 // chunk descriptors of one row: {row, first list entry, entries in use, chunks of the row}.  The plan writes the
 // capacity share; the select kernel overwrites .z with what the row actually uses (so nothing has to fill the tail).
 __device__ __forceinline__ void write_chunk_desc(const Workspace &w, int row, int o_chunk, long long o_cap, int cap) {
@@ -233,34 +267,23 @@ static_assert(sizeof(PlanTotals) <= 64, "the workspace carve reserves 64 bytes p
 // pass 1, workgroup `block` of THREADS threads, one row per thread
 template <int THREADS>
 __device__ __forceinline__ void plan_count_body(const ChooseArgs &a, PlanTotals *totals, int block) {
-    __shared__ int lds[THREADS / PCG_WAVE];
-    __shared__ long long lds64[THREADS / PCG_WAVE];
+    __shared__ int4 lds4[THREADS / PCG_WAVE];
     const int rows = a.g.n_rel * a.B;
     const int row = block * THREADS + (int)threadIdx.x;
-    long long cap_sum = 0, tiers = 0;
-    int chunk_sum = 0, na = 0;
+    int cap = 0, tier = -1;
     if (row < rows) {
         const RowRec p = row_plan(a, row);
         a.w.recs[row] = p;
-        const int cap = rec_cap(p, a.add_self);
-        cap_sum = cap;
-        chunk_sum = (cap + CHUNK - 1) / CHUNK;
-        const int tier = row_tier(p.d, p.m > 0 || a.add_self);
-        tiers = tier_word(tier);
-        na = tier == 0;
+        cap = rec_cap(p, a.add_self);
+        tier = row_tier(p.d, p.m > 0 || a.add_self);
     }
-    long long t_cap, t_tiers;
-    int t_chunk, t_na;
-    block_excl_scan<long long>(cap_sum, lds64, t_cap);
-    block_excl_scan(chunk_sum, lds, t_chunk);
-    block_excl_scan(na, lds, t_na);
-    block_excl_scan<long long>(tiers, lds64, t_tiers);
+    PlanScan pre, tot;
+    block_excl_scan_plan(cap, (cap + CHUNK - 1) / CHUNK, tier, lds4, pre, tot);
     if (threadIdx.x == 0) {
-        const TierCounts tt = tier_unpack(t_tiers, t_na);
         PlanTotals t;
-        t.cap = t_cap;
-        t.chunk = t_chunk;
-        t.n0 = tt.n0; t.n1 = tt.n1; t.n4 = tt.n4; t.n16 = tt.n16; t.na = tt.na;
+        t.cap = tot.cap;
+        t.chunk = tot.chunk;
+        t.n0 = tot.t.n0; t.n1 = tot.t.n1; t.n4 = tot.t.n4; t.n16 = tot.t.n16; t.na = tot.t.na;
         t.pad[0] = t.pad[1] = 0;
         totals[block] = t;
     }
@@ -270,8 +293,7 @@ __device__ __forceinline__ void plan_count_body(const ChooseArgs &a, PlanTotals 
 // COUNT_THREADS rows each (THREADS is a multiple of COUNT_THREADS)
 template <int THREADS, int COUNT_THREADS>
 __device__ __forceinline__ void plan_write_body(const ChooseArgs &a, const PlanTotals *totals, int block, int n_count_blocks) {
-    __shared__ int lds[THREADS / PCG_WAVE];
-    __shared__ long long lds64[THREADS / PCG_WAVE];
+    __shared__ int4 lds4[THREADS / PCG_WAVE];
     const int rows = a.g.n_rel * a.B;
     long long run_cap = 0, all_cap = 0;
     int run_chunk = 0, all_chunk = 0;
@@ -316,13 +338,12 @@ __device__ __forceinline__ void plan_write_body(const ChooseArgs &a, const PlanT
         cap = rec_cap(rec, a.add_self);
     }
     const int nch = (cap + CHUNK - 1) / CHUNK;
-    long long t_cap, t_tiers;
-    int t_chunk, t_na;
-    const long long o_cap = run_cap + block_excl_scan<long long>((long long)cap, lds64, t_cap);
-    const int o_chunk = run_chunk + block_excl_scan(nch, lds, t_chunk);
     const int tier = row < rows ? row_tier(rec.d, rec.m > 0 || a.add_self) : -1;
-    const int o_na = block_excl_scan(tier == 0 ? 1 : 0, lds, t_na);
-    TierCounts o = tier_unpack(block_excl_scan<long long>(tier >= 0 ? tier_word(tier) : 0ll, lds64, t_tiers), o_na);
+    PlanScan pre, tot;
+    block_excl_scan_plan(cap, nch, tier, lds4, pre, tot);
+    const long long o_cap = run_cap + pre.cap;
+    const int o_chunk = run_chunk + pre.chunk;
+    TierCounts o = pre.t;
     tier_add(o, run);
     if (row < rows) {
         a.w.row_begin[row] = o_cap;

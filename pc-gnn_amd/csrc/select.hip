@@ -62,11 +62,6 @@ __device__ __forceinline__ void grp_scan(int v, int wave, int lane, int *red, in
     }
 }
 
-// DPP-selected lane value (full-rate VALU, no LDS crossbar round trip as __shfl would make)
-template <int CTRL>
-__device__ __forceinline__ uint32_t dpp_u32(uint32_t v, uint32_t old = 0u) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, 0xF, 0xF, false);
-}
 // wave-wide min / max of uint32: butterfly inside every 16-lane row (quad permutes, half-row / row mirrors - after them every
 // lane of a row holds the row's result), then the four rows through scalar registers
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
@@ -91,18 +86,6 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     const uint32_t x = r0 > r1 ? r0 : r1, y = r2 > r3 ? r2 : r3;
     return x > y ? x : y;
 }
-// wave-wide inclusive scan: row_shr 1, 2, 4, 8 inside every 16-lane row (a lane without a source adds 0), then the row
-// totals through scalar registers
-__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
-    v += (int)dpp_u32<0x111>((uint32_t)v);
-    v += (int)dpp_u32<0x112>((uint32_t)v);
-    v += (int)dpp_u32<0x114>((uint32_t)v);
-    v += (int)dpp_u32<0x118>((uint32_t)v);
-    const int t0 = __builtin_amdgcn_readlane(v, 15), t1 = __builtin_amdgcn_readlane(v, 31), t2 = __builtin_amdgcn_readlane(v, 47);
-    const int row = lane >> 4;
-    return v + (row > 0 ? t0 : 0) + (row > 1 ? t1 : 0) + (row > 2 ? t2 : 0);
-}
-
 __device__ __forceinline__ bool sorted_contains(const uint32_t *list, int n, uint32_t x) {
     int lo = 0, hi = n;
     while (lo < hi) {
