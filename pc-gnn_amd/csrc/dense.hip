@@ -111,6 +111,36 @@ __device__ __forceinline__ f32x4 mfma_chain(int n_steps, FA fa, FB fb) {
     return acc;
 }
 
+// C[16x16] = A * Bt^T with Bt in GLOBAL memory, row-major [n][k] (a weight matrix used transposed): lane (n = r, kq) would read
+// Bt[n][4s + kq] for step s - 4 bytes from each of 16 rows per load instruction.  Instead a lane reads the float4
+// Bt[n][16u + 4kq .. + 3] (16 rows x 64 contiguous bytes per instruction, a quarter of the instructions) and the four MFMA
+// steps of block u take k = 16u + 4kq + i, i = 0..3: a permutation of the k order that the A operand (LDS, any pattern is
+// cheap there) follows.  All loads of eight blocks are in flight before the first MFMA.
+__device__ __forceinline__ f32x4 tile_lds_globT4(const float *ap /* A + r*lda + 4*kq */, const float *__restrict__ bp /* Bt + n*ldb + 4*kq */,
+                                                 int n_blocks) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    constexpr int NB = 8;
+    for (int u0 = 0; u0 < n_blocks; u0 += NB) {
+        f4 b[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int u = u0 + j < n_blocks ? u0 + j : n_blocks - 1;          // (clamped: unconditional loads)
+            b[j] = *reinterpret_cast<const f4 *>(bp + 16 * u);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            if (u0 + j >= n_blocks) break;                                    // (wave-uniform)
+            const float *aj = ap + 16 * (u0 + j);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aj[0], b[j].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aj[1], b[j].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aj[2], b[j].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aj[3], b[j].w, acc, 0, 0, 0);
+        }
+    }
+    return acc;
+}
+
 // C[16x16] += A[16 x k-steps] (LDS, row-major, leading dim lda) * B (global, ld ldb, column n0..n0+15), k in [k_lo, k_hi)
 __device__ __forceinline__ f32x4 tile_lds_glob(const float *A, int lda, const float *__restrict__ Bg, int ldb, int n0,
                                                int K, int k_lo, int k_hi, int lane) {
@@ -502,8 +532,9 @@ __global__ void __launch_bounds__(DENSE_THREADS) dense_step_kernel(const DenseAr
                 const float *ap = s_dcomb + rr * ldE + kq;                 // out[t][j] = sum_e dcomb[t][e] * Wr[j][e]
                 const float *bl = s_wi + (F + r * E + ct * 16 + rr) * ldW + kq;
                 const float *bg = Wr + (size_t)(ct * 16 + rr) * E + kq;
+                // (E is a multiple of 16.  Without the LDS copy the transposed weight rows come from L2 as float4 per lane)
                 const f32x4 acc = WLDS ? mfma_chain(E >> 2, [&](int s) { return ap[4 * s]; }, [&](int s) { return bl[4 * s]; })
-                                       : mfma_chain(E >> 2, [&](int s) { return ap[4 * s]; }, [&](int s) { return bg[4 * s]; });
+                                       : tile_lds_globT4(s_dcomb + rr * ldE + 4 * kq, bg + 3 * kq, E >> 4);
                 const int col = ct * 16 + rr, rq = kq * 4;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)

@@ -340,6 +340,11 @@ class DistributedPCGNN:
             y_all = w.labels[w.idx_train]
             n_train, n_train_pos, y_loc = len(y_all), int(y_all.sum()), w.labels[sh["idx_train_local"]]
             F = w.X.shape[1]
+        # every rank trains centres it owns: a rank without training nodes (e.g. the unlabeled head of the Amazon graph,
+        # utils.py:98-99, landing on one rank) cannot take part - say so on every rank instead of failing in the sampler
+        if self._agree_max(0 if len(sh["idx_train_local"]) else 1):
+            raise ValueError(f"node partition x{self.world}: some rank owns no training node - use fewer ranks or pass `bounds` "
+                             "that give every rank labeled training nodes")
         P = len(sh["train_pos"])
         B = cfg["batch_size"]
         n_local = part.n_local

@@ -1,4 +1,4 @@
-"""Two ranks of the node-partitioned path on ONE GPU (collectives staged through the host over gloo)
+"""Two and three ranks of the node-partitioned path on ONE GPU (collectives staged through the host over gloo)
 against the single-GPU path on the same global batch.  -m gpu.
 
 Shape: BASELINE configs[2]'s model (emb 128: the dense kernel variant that streams its weights) at batch 1024 per rank,
@@ -95,7 +95,7 @@ def _worker(rank, world, port, q):
         # every rank holds the same parameters after the step
         th = [torch.empty(d.n_params) for _ in range(world)]
         dist.all_gather(th, d.theta.cpu())
-        assert torch.equal(th[0], th[1])
+        assert all(torch.equal(th[0], t) for t in th[1:])
         assert not torch.equal(th[0], theta0.cpu())
         # a window of two more batches through the captured step on both ranks (fresh centres): the first step warms up and
         # captures, the second replays
@@ -103,7 +103,7 @@ def _worker(rank, world, port, q):
         d.train_window(ids2, d.labels_of(ids2))
         torch.cuda.synchronize()
         dist.all_gather(th, d.theta.cpu())
-        assert torch.equal(th[0], th[1]) and torch.isfinite(th[0]).all()
+        assert all(torch.equal(th[0], t) for t in th[1:]) and torch.isfinite(th[0]).all()
 
         d.check()
         # ---- a halo that is too small: the step itself never waits for the host (ids that do not fit become holes, a device
@@ -131,11 +131,12 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_ranks_match_single_gpu():
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_match_single_gpu(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=900) for _ in procs]
