@@ -48,7 +48,9 @@ struct Workspace {
     float *partial;        // [chunk_cap, feat_stride]
     uint32_t *row_ticket;  // [rows] arrivals of a multi-chunk row's chunks (gather; reset by the row's last chunk)
     int32_t *list;         // [list_capacity]  chosen ids; -1 = hole
-    int64_t list_capacity, chunk_cap;
+    uint32_t *key_scratch; // [scratch_cap] distance keys of rows too long for the select kernel's LDS: max_degree entries for
+                           // each workgroup of select_long_rows
+    int64_t list_capacity, chunk_cap, scratch_cap;
 };
 
 static inline int64_t align256(int64_t x) { return (x + 255) / 256 * 256; }
@@ -56,6 +58,14 @@ static inline int64_t align256(int64_t x) { return (x + 255) / 256 * 256; }
 static inline int64_t carve(const pcg_graph_desc *g, int32_t B, int64_t list_capacity, unsigned char *base, Workspace *w) {
     const int64_t rows = (int64_t)g->n_rel * B;
     const int64_t chunk_cap = list_capacity / CHUNK + rows + 1;
+    // key scratch: only graphs with rows beyond the LDS key capacity need it; max_degree entries for each workgroup of
+    // select_long_rows (up to 256 of them; fewer if that would be more than 1 GiB)
+    int64_t scratch_cap = 0;
+    if (g->max_degree > WG_KEYCAP) {
+        int64_t nb = (1ll << 28) / g->max_degree;
+        nb = nb < 1 ? 1 : (nb > 256 ? 256 : nb);
+        scratch_cap = nb * (int64_t)g->max_degree;
+    }
     int64_t off = 0;
     auto take = [&](int64_t bytes) {
         const int64_t o = off;
@@ -79,9 +89,11 @@ static inline int64_t carve(const pcg_graph_desc *g, int32_t B, int64_t list_cap
     p = take(4 * chunk_cap * g->feat_stride);      if (w) w->partial = reinterpret_cast<float *>(p);
     p = take(4 * rows);                            if (w) w->row_ticket = reinterpret_cast<uint32_t *>(p);
     p = take(4 * list_capacity);                   if (w) w->list = reinterpret_cast<int32_t *>(p);
+    p = take(4 * scratch_cap);                     if (w) w->key_scratch = reinterpret_cast<uint32_t *>(p);
     if (w) {
         w->list_capacity = list_capacity;
         w->chunk_cap = chunk_cap;
+        w->scratch_cap = scratch_cap;
     }
     return off;
 }

@@ -564,29 +564,26 @@ __device__ __forceinline__ void select_wave_row(const ChooseArgs &a, int row, ui
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// workgroup rows (> 512 neighbours): 8 waves, keys in LDS (LDSK) or recomputed from the scores on every pass
+// workgroup rows (> 512 neighbours): 8 waves, keys in LDS (LDSK) or - rows beyond its capacity - in global scratch
 // ---------------------------------------------------------------------------------------------------------------------
-// f(i, key) for every position i in [begin, end) with stride NT from `first`; recomputing variant: KEY_UNROLL gathers in flight
+// f(i, key) for every position i in [begin, end) with stride NT from `first`.  LDSK: the keys are in LDS.  Otherwise they are
+// in the row's global scratch (gk: written by pass 1, read back coalesced, KEY_UNROLL loads in flight)
 template <bool LDSK, class F>
-__device__ __forceinline__ void for_keys(const uint32_t *keys, const int32_t *__restrict__ nbr, const float *__restrict__ s0, float c,
-                                         int first, int end, int step, F f) {
+__device__ __forceinline__ void for_keys(const uint32_t *keys, const uint32_t *__restrict__ gk, int first, int end, int step, F f) {
     if constexpr (LDSK) {
         for (int i = first; i < end; i += step) f(i, keys[i]);
     } else {
         for (int base = first; base < end; base += step * KEY_UNROLL) {
-            uint32_t id[KEY_UNROLL];
-            float sc[KEY_UNROLL];
+            uint32_t kv[KEY_UNROLL];
 #pragma unroll
             for (int u = 0; u < KEY_UNROLL; ++u) {
                 const int i = base + u * step;
-                id[u] = (uint32_t)nbr[i < end ? i : end - 1];
+                kv[u] = gk[i < end ? i : end - 1];
             }
 #pragma unroll
-            for (int u = 0; u < KEY_UNROLL; ++u) sc[u] = s0[id[u]];
-#pragma unroll
             for (int u = 0; u < KEY_UNROLL; ++u) {
                 const int i = base + u * step;
-                if (i < end) f(i, dist_key(c, sc[u]));
+                if (i < end) f(i, kv[u]);
             }
         }
     }
@@ -595,7 +592,7 @@ __device__ __forceinline__ void for_keys(const uint32_t *keys, const int32_t *__
 // lds: WG_KEYCAP words (keys, later the kept ids) | hist HIST_WG | cand 64 | red
 template <bool LDSK>
 __device__ __forceinline__ void select_wg_row(const ChooseArgs &a, int row, uint32_t *keys, uint32_t *hist, uint32_t *cand,
-                                              int *red, int tid) {
+                                              int *red, int tid, uint32_t *gk = nullptr) {
     constexpr int NW = SEL_NW, NT = SEL_NW * PCG_WAVE;
     const int lane = tid & (PCG_WAVE - 1), wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (a.stamps && tid == 0) a.stamps[(size_t)row * 8] = wall_clock64() | ((unsigned long long)blockIdx.x << 54);
@@ -612,6 +609,7 @@ __device__ __forceinline__ void select_wg_row(const ChooseArgs &a, int row, uint
 
     uint32_t kstar = 0xFFFFFFFFu;
     int need = 0, n_equal = 0;
+    // (a row too long for the LDS keeps its keys in global scratch, gk: written by pass 1, read back coalesced by the later passes)
     if (!keep_all) {
         // ---- 1. distance keys (-> LDS), their range ----
         uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
@@ -631,6 +629,7 @@ __device__ __forceinline__ void select_wg_row(const ChooseArgs &a, int row, uint
                 if (i < d) {
                     const uint32_t key = dist_key(c, sc[u]);
                     if constexpr (LDSK) keys[i] = key;
+                    else if (gk) gk[i] = key;
                     kmin = key < kmin ? key : kmin;
                     kmax = key > kmax ? key : kmax;
                 }
@@ -642,7 +641,9 @@ __device__ __forceinline__ void select_wg_row(const ChooseArgs &a, int row, uint
             red[wave] = (int)kmin;
             red[NW + wave] = (int)kmax;
         }
+        if constexpr (!LDSK) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");    // (the scratch keys: same CU, same L1)
         __syncthreads();
+        if constexpr (!LDSK) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         for (int w = 0; w < NW; ++w) {
             const uint32_t x = (uint32_t)red[w], y = (uint32_t)red[NW + w];
             kmin = x < kmin ? x : kmin;
@@ -658,7 +659,7 @@ __device__ __forceinline__ void select_wg_row(const ChooseArgs &a, int row, uint
             const int shift = bits > 11 ? bits - 11 : 0;                    // (range >> shift) < HIST_WG
             *reinterpret_cast<uint4 *>(hist + 4 * tid) = make_uint4(0u, 0u, 0u, 0u);       // HIST_WG == 4 * NT
             __syncthreads();                                                 // (also: everybody is done with red / res)
-            for_keys<LDSK>(keys, nbr, s0, c, tid, d, NT, [&](int, uint32_t key) {
+            for_keys<LDSK>(keys, gk, tid, d, NT, [&](int, uint32_t key) {
                 if (key >= lo && key <= hi) atomicAdd(&hist[(key - lo) >> shift], 1u);
             });
             __syncthreads();
@@ -700,7 +701,7 @@ __device__ __forceinline__ void select_wg_row(const ChooseArgs &a, int row, uint
             __syncthreads();
             if (tid == 0) res[3] = 0;
             __syncthreads();
-            for_keys<LDSK>(keys, nbr, s0, c, tid, d, NT, [&](int, uint32_t key) {
+            for_keys<LDSK>(keys, gk, tid, d, NT, [&](int, uint32_t key) {
                 if (key >= lo && key <= hi) {
                     const int at = atomicAdd(&res[3], 1);
                     if (at < PCG_WAVE) cand[at] = key;          // (cnt <= 64 by construction; a counter never indexes unchecked)
@@ -723,7 +724,7 @@ __device__ __forceinline__ void select_wg_row(const ChooseArgs &a, int row, uint
     int tie_base = 0;
     if (ranked) {                                                            // ties before this wave's stretch
         int tc = 0;
-        for_keys<LDSK>(keys, nbr, s0, c, b0 + lane, e0, PCG_WAVE, [&](int, uint32_t key) { tc += key == kstar; });
+        for_keys<LDSK>(keys, gk, b0 + lane, e0, PCG_WAVE, [&](int, uint32_t key) { tc += key == kstar; });
         for (int o = 1; o < PCG_WAVE; o <<= 1) tc += __shfl_xor(tc, o);
         int ttot;
         grp_scan<NW>(tc, wave, lane, red, tie_base, ttot);
@@ -772,27 +773,28 @@ __device__ __forceinline__ void select_wg_row(const ChooseArgs &a, int row, uint
         __syncthreads();
     } else {
         // over-long row: count per stretch, scan, then the same pass again writing straight into the list region
-        int mine = 0, ties_seen = tie_base;
-        for (int i0 = b0; i0 < e0; i0 += PCG_WAVE * KEY_UNROLL) {
-            uint32_t id[KEY_UNROLL];
-            float sc[KEY_UNROLL];
+        // ids and keys of KEY_UNROLL positions of this wave's stretch (the keys from the row's scratch)
+        auto stretch_keys = [&](int i0, uint32_t (&id)[KEY_UNROLL], uint32_t (&key)[KEY_UNROLL]) __attribute__((always_inline)) {
 #pragma unroll
             for (int u = 0; u < KEY_UNROLL; ++u) {
                 const int i = i0 + u * PCG_WAVE + lane;
                 id[u] = (uint32_t)nbr[i < e0 ? i : d - 1];
+                key[u] = gk[i < e0 ? i : d - 1];
             }
-#pragma unroll
-            for (int u = 0; u < KEY_UNROLL; ++u) sc[u] = s0[id[u]];
+        };
+        int mine = 0, ties_seen = tie_base;
+        for (int i0 = b0; i0 < e0; i0 += PCG_WAVE * KEY_UNROLL) {
+            uint32_t id[KEY_UNROLL], key[KEY_UNROLL];
+            stretch_keys(i0, id, key);
 #pragma unroll
             for (int u = 0; u < KEY_UNROLL; ++u) {
                 const int i = i0 + u * PCG_WAVE + lane;
                 const bool in = i < e0;
-                const uint32_t key = dist_key(c, sc[u]);
-                bool s = in && (keep_all || key <= kstar);
+                bool s = in && (keep_all || key[u] <= kstar);
                 if (ranked) {
-                    const bool tie = in && key == kstar;
+                    const bool tie = in && key[u] == kstar;
                     const uint64_t tm = __ballot(tie);
-                    s = in && (key < kstar || (tie && ties_seen + __popcll(tm & lanemask_lt()) < need));
+                    s = in && (key[u] < kstar || (tie && ties_seen + __popcll(tm & lanemask_lt()) < need));
                     ties_seen += __popcll(tm);
                 }
                 mine += wave_count(s);
@@ -802,25 +804,17 @@ __device__ __forceinline__ void select_wg_row(const ChooseArgs &a, int row, uint
         grp_scan<NW>(mine, wave, lane, red, run, ns);
         ties_seen = tie_base;
         for (int i0 = b0; i0 < e0; i0 += PCG_WAVE * KEY_UNROLL) {
-            uint32_t id[KEY_UNROLL];
-            float sc[KEY_UNROLL];
-#pragma unroll
-            for (int u = 0; u < KEY_UNROLL; ++u) {
-                const int i = i0 + u * PCG_WAVE + lane;
-                id[u] = (uint32_t)nbr[i < e0 ? i : d - 1];
-            }
-#pragma unroll
-            for (int u = 0; u < KEY_UNROLL; ++u) sc[u] = s0[id[u]];
+            uint32_t id[KEY_UNROLL], key[KEY_UNROLL];
+            stretch_keys(i0, id, key);
 #pragma unroll
             for (int u = 0; u < KEY_UNROLL; ++u) {
                 const int i = i0 + u * PCG_WAVE + lane;
                 const bool in = i < e0;
-                const uint32_t key = dist_key(c, sc[u]);
-                bool s = in && (keep_all || key <= kstar);
+                bool s = in && (keep_all || key[u] <= kstar);
                 if (ranked) {
-                    const bool tie = in && key == kstar;
+                    const bool tie = in && key[u] == kstar;
                     const uint64_t tm = __ballot(tie);
-                    s = in && (key < kstar || (tie && ties_seen + __popcll(tm & lanemask_lt()) < need));
+                    s = in && (key[u] < kstar || (tie && ties_seen + __popcll(tm & lanemask_lt()) < need));
                     ties_seen += __popcll(tm);
                 }
                 const uint64_t sm = __ballot(s);
@@ -887,8 +881,7 @@ __global__ void __launch_bounds__(SEL_NW *PCG_WAVE) __attribute__((amdgpu_waves_
         if (u < n_wg) {
             const int row = __builtin_amdgcn_readfirstlane(u < n16 ? a.w.q16[u] : a.w.q4[u - n16]);     // one row per workgroup: scalar
             const int d = a.w.recs[row].d;
-            if (d <= WG_KEYCAP) select_wg_row<true>(a, row, lds, hist, cand, red, tid);
-            else select_wg_row<false>(a, row, lds, hist, cand, red, tid);
+            if (d <= WG_KEYCAP) select_wg_row<true>(a, row, lds, hist, cand, red, tid);      // (longer rows: select_long_rows)
         } else {
             const int j = wave < bs ? (u - n_wg) * bs + wave : n_items;
             if (j < n1) {
@@ -915,6 +908,27 @@ __global__ void __launch_bounds__(SEL_NW *PCG_WAVE) __attribute__((amdgpu_waves_
     }
 }
 
+// Rows beyond the LDS key capacity (> WG_KEYCAP neighbours), in a launch of their own: the multi-pass selection over keys kept
+// in global scratch needs more registers than select_rows' occupancy allows, and only hub-heavy graphs have such rows (the
+// launch is skipped when the graph's maximum degree rules them out).  Persistent workgroups walk the > 4096 queue and take
+// the rows that select_rows left alone; workgroup b keeps its keys in scratch[b * per_wg ..].
+constexpr int LONG_BLOCKS = 256;
+__global__ void __launch_bounds__(SEL_NW *PCG_WAVE) select_long_rows(const ChooseArgs a, int64_t per_wg) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t *lds = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *hist = lds + WG_KEYCAP;
+    uint32_t *cand = hist + HIST_WG;
+    int *red = reinterpret_cast<int *>(cand + PCG_WAVE);
+    const int n16 = (int)a.w.counters[C_N16];
+    uint32_t *gk = a.w.key_scratch + (size_t)blockIdx.x * per_wg;
+    for (int u = (int)blockIdx.x; u < n16; u += (int)gridDim.x) {
+        const int row = __builtin_amdgcn_readfirstlane(a.w.q16[u]);
+        if (a.w.recs[row].d <= WG_KEYCAP) continue;                         // (workgroup-uniform)
+        select_wg_row<false>(a, row, lds, hist, cand, red, (int)threadIdx.x, gk);
+        __syncthreads();
+    }
+}
+
 static size_t select_smem_bytes() {
     return sizeof(uint32_t) * (WG_KEYCAP + HIST_WG + PCG_WAVE) + sizeof(int) * (2 * SEL_NW + 8) + sizeof(void *) * PCG_MAX_REL;   // (claim[2] = red[22..23])
 }
@@ -933,6 +947,14 @@ int launch_select_rows(const ChooseArgs &a, hipStream_t st) {
     }
     hipLaunchKernelGGL(select_rows, dim3(blocks), dim3(SEL_NW * PCG_WAVE), select_smem_bytes(), st, a);
     PCG_LAUNCH_CHECK();
+    if (a.g.max_degree > WG_KEYCAP) {        // rows too long for the LDS keys: their own launch (hub-heavy graphs only)
+        const int64_t per_wg = a.g.max_degree;
+        int64_t nb = a.w.scratch_cap / per_wg;
+        nb = nb < LONG_BLOCKS ? nb : LONG_BLOCKS;
+        if (nb < 1) return PCG_E_ARG;
+        hipLaunchKernelGGL(select_long_rows, dim3((int)nb), dim3(SEL_NW * PCG_WAVE), select_smem_bytes(), st, a, per_wg);
+        PCG_LAUNCH_CHECK();
+    }
     return PCG_OK;
 }
 

@@ -64,13 +64,14 @@ def test(test_nodes, labels, model, batch_size: int, result=None, epoch: Optiona
     nodes = np.asarray(test_nodes)
     labels = np.asarray(labels)
     outs = []
+    fused = hasattr(model, "predict")                                       # FusedPCGNN: ids go to the device ONCE, batches are views
+    ids_dev = torch.as_tensor(nodes, dtype=torch.int32, device=model.dev) if fused else None
     with torch.no_grad():
         for start in range(0, len(nodes), batch_size):                      # :298-303 (no empty trailing batch)
             batch = nodes[start:start + batch_size]
             blab = labels[start:start + batch_size]
-            if hasattr(model, "predict"):                                   # FusedPCGNN
-                ids = torch.as_tensor(batch, dtype=torch.int32, device=model.dev)
-                outs.append(torch.sigmoid(model.predict(ids, None, False)[0]))
+            if fused:
+                outs.append(torch.sigmoid(model.predict(ids_dev[start:start + batch_size], None, False)[0]))
             else:
                 outs.append(model.to_prob(batch.tolist(), blab, train_flag=False)[0])   # :305
     prob = torch.cat(outs).float().cpu().numpy() if outs else np.zeros((0, 2), np.float32)
