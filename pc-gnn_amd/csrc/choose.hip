@@ -74,6 +74,7 @@ __device__ __forceinline__ void tier_finish(const Workspace &w, const TierCounts
     w.counters[C_N4] = overflow ? 0 : t.n4;
     w.counters[C_N16] = overflow ? 0 : t.n16;
     for (int i = 0; i < 8; ++i) w.heads[16 * i] = 0;      // the select kernel's work-queue heads
+    w.heads[13] = w.heads[14] = 0;                        // ... and the long-row kernel's (departures, cursor)
 }
 // exclusive scan of one value per thread over the block; returns the block total through `total`
 template <typename T>

@@ -730,7 +730,11 @@ __device__ __forceinline__ void select_wg_row(const ChooseArgs &a, int row, uint
         grp_scan<NW>(tc, wave, lane, red, tie_base, ttot);
     }
     int ns = 0;
-    uint32_t *selbuf = LDSK ? keys : reinterpret_cast<uint32_t *>(out);     // the keys are dead once every wave has its mask
+    // where the kept ids go: the keys' LDS (dead once every wave has its mask; a scratch-key row never used it) if they fit -
+    // the minority picks are de-duplicated against them by binary search, 13 dependent loads per pick: LDS, not global - else
+    // straight into the list region
+    const bool sel_in_lds = LDSK || k <= WG_KEYCAP;
+    uint32_t *selbuf = sel_in_lds ? keys : reinterpret_cast<uint32_t *>(out);
     if constexpr (LDSK) {
         // pass A: which positions stay (a bit per iteration in a register; seg <= 1280 -> <= 20 iterations), pass B: their
         // ids, re-read from the CSR row (coalesced, L2-hot), into the keys' own LDS
@@ -828,7 +832,7 @@ __device__ __forceinline__ void select_wg_row(const ChooseArgs &a, int row, uint
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
     PCG_STAMP(3);
-    finish_row<NW>(a, row, p, c, selbuf, ns, !LDSK, wave, lane, red);
+    finish_row<NW>(a, row, p, c, selbuf, ns, !sel_in_lds, wave, lane, red);
 }
 
 // One persistent launch selects every row of the batch, longest rows first.  The work is one queue of workgroup-sized units,
@@ -869,8 +873,11 @@ __global__ void __launch_bounds__(SEL_NW *PCG_WAVE) __attribute__((amdgpu_waves_
 
     int u = (int)blockIdx.x, pending = 0, slot = 0;
     while (u < n_units) {
-        // the unit after this one: its claim is in flight while this one runs
-        if (leader && pull) pending = shard + SEL_SHARDS * (grid / SEL_SHARDS + (int)atomicAdd(head, 1u));
+        // the unit after this one: behind a batch of single-wave items (a few microseconds) its claim is in flight while the
+        // batch runs; behind a workgroup row (up to tens of microseconds) it is made afterwards - a busy workgroup must not sit
+        // on a unit that an idle one could take
+        const bool ahead = u >= n_wg;
+        if (leader && pull && ahead) pending = shard + SEL_SHARDS * (grid / SEL_SHARDS + (int)atomicAdd(head, 1u));
         // the thread index goes through an opaque move once per unit: everything the row paths derive from it (lane masks,
         // quarter-wave indices, LDS offsets) is then recomputed per unit - a few VALU ops - instead of being hoisted out of
         // this loop and kept alive across every path, which costs more registers than the 80 the occupancy allows (spills)
@@ -893,7 +900,7 @@ __global__ void __launch_bounds__(SEL_NW *PCG_WAVE) __attribute__((amdgpu_waves_
             }
         }
         if (!pull) break;
-        if (leader) claim[slot] = pending;
+        if (leader) claim[slot] = ahead ? pending : shard + SEL_SHARDS * (grid / SEL_SHARDS + (int)atomicAdd(head, 1u));
         __syncthreads();
         u = claim[slot];
         slot ^= 1;
@@ -921,11 +928,31 @@ __global__ void __launch_bounds__(SEL_NW *PCG_WAVE) select_long_rows(const Choos
     int *red = reinterpret_cast<int *>(cand + PCG_WAVE);
     const int n16 = (int)a.w.counters[C_N16];
     uint32_t *gk = a.w.key_scratch + (size_t)blockIdx.x * per_wg;
-    for (int u = (int)blockIdx.x; u < n16; u += (int)gridDim.x) {
+    // The queue is in row order, the long rows are anywhere in it: a static stride would hand some workgroups three or four of
+    // them and most none.  Every workgroup therefore pulls queue positions from one cursor (heads[14]; a few hundred atomics
+    // in all) - AFTER it is done with its unit, not a unit ahead: units cost nothing or 60 us here, and a workgroup busy with
+    // a long row must not sit on a claim.  The last workgroup out puts the cursor back to zero.
+    int *claim = red + 2 * SEL_NW + 6;
+    uint32_t *cursor = a.w.heads + 14, *done = a.w.heads + 13;
+    const bool leader = threadIdx.x == 0;
+    int u = (int)blockIdx.x, slot = 0;
+    while (u < n16) {
         const int row = __builtin_amdgcn_readfirstlane(a.w.q16[u]);
-        if (a.w.recs[row].d <= WG_KEYCAP) continue;                         // (workgroup-uniform)
-        select_wg_row<false>(a, row, lds, hist, cand, red, (int)threadIdx.x, gk);
+        if (a.w.recs[row].d > WG_KEYCAP) {                                  // (workgroup-uniform)
+            select_wg_row<false>(a, row, lds, hist, cand, red, (int)threadIdx.x, gk);
+        }
         __syncthreads();
+        if (leader) claim[slot] = (int)gridDim.x + (int)atomicAdd(cursor, 1u);
+        __syncthreads();
+        u = claim[slot];
+        slot ^= 1;
+    }
+    if (leader) {
+        const unsigned fin = atomicAdd(done, 1u);
+        if (fin == gridDim.x - 1) {
+            atomicExch(cursor, 0u);
+            atomicExch(done, 0u);
+        }
     }
 }
 
