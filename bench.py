@@ -15,12 +15,13 @@ N=1 workload: BASELINE.json configs[1] - YelpChi-shaped synthetic graph
 (N=45,954, F=32, 3 relations with 49,315 / 573,616 / 3,402,743 undirected edges,
 14.53 % positives, 40 % train), emb 64, batch 1024, rho 0.5.
 
-Graph engine (default at N=1): an epoch - sampler + every batch's seven launches - is
-ONE hipGraph launch; the first epoch of the timed region and every `--event-every`-th
-after it are replayed batch by batch as [front graph] -> HIP event -> [select + gather
-+ combine graph] -> HIP event -> [dense + Adam graph] (same kernels, same order): those
-events give the `roofline` object (dominant launch = select + aggregate).  N>1: the
-destination-node partitioned path (pc-gnn_amd/dist.py), weak scaling.
+Graph engine (default at N=1): an epoch - sampler + every batch's five launches - is
+ONE hipGraph launch; in the first epoch of the timed region and every `--event-every`-th
+after it the first `--timed-per-epoch` batches are launched kernel by kernel with HIP
+events around the select + gather call (same kernels, same order; the rest of such an
+epoch is one graph replay per batch): those events give the `roofline` object (dominant
+launch = select_rows + gather_chunks).  N>1: the destination-node partitioned path
+(pc-gnn_amd/dist.py), weak scaling.
 
 Prints ONE JSON line (rank 0) with `roofline` and `cpu_baseline` (the oracle port timed
 on the host cores on the event-bracketed batches of the same run; rank 0, N=1 only).
@@ -61,7 +62,9 @@ def parse():
                     "so the remote rows of a window's centres are fetched once)")
     ap.add_argument("--timed-graphs", action="store_true", help="event-bracketed steps as three graph launches instead of five "
                     "kernel launches (the middle graph's launch latency then lands inside the bracket)")
-    ap.add_argument("--event-every", type=int, default=10,
+    ap.add_argument("--timed-per-epoch", type=int, default=2, help="batches of an event-bracketed epoch that are launched kernel by "
+                    "kernel with HIP events (the rest of that epoch: one graph replay per batch)")
+    ap.add_argument("--event-every", type=int, default=3,
                     help="graph engine: bracket the select+aggregate launch with HIP events on every step of every Nth epoch")
     ap.add_argument("--engine", default=None, choices=["graph", "fused", "torch", "dp"],
                     help="graph: fused HIP step replayed from a hipGraph (default at 1 GPU); fused: same kernels "
@@ -111,7 +114,7 @@ def cpu_baseline(w, trainer, cfg, batches, n_batches):
         spent += time.perf_counter() - t0
         nodes += len(ids)
     out = {"value": nodes / spent, "unit": "nodes/s", "cores": torch.get_num_threads(), "kind": "port",
-           "sample": f"{n_batches} batches ({nodes} nodes) of the same workload, same picked ids, "
+           "sample": f"{n_batches} batches ({nodes} nodes) of the same workload picked by the same sampler (the run's event-bracketed batches first), "
                      f"oracle/pcgnn_oracle.py train_step (dense-mask formulation as in the reference), {spent:.1f} s"}
     # calibration against the reference itself (tests/golden/make_cpu_calibration.py, run where the reference can be imported:
     # the build container, 8 cores): the port's speed relative to the reference on the same graph shape and batches
@@ -278,8 +281,10 @@ def main():
                     p.grad.copy_(flat[o:o + p.numel()].view_as(p))
                     o += p.numel()
             tr.opt.step()
-        elif epoch_graphs and timed:   # the staged batch as front | select + aggregate | dense + Adam graphs with events
+        elif epoch_graphs and timed:   # the staged batch launched kernel by kernel with HIP events around select + gather
             tr.fused.epoch_step_timed(state["b"] - 1, eager=not args.timed_graphs)
+        elif epoch_graphs:             # the staged batch as one graph replay (a batch that is not part of a whole-epoch replay)
+            tr.fused.epoch_step(state["b"] - 1)
         elif dist is None:        # (graph engine: the per-batch graphs; whole epochs go through run_epoch_one_graph below)
             tr.step(ids, timed)
         else:
@@ -315,9 +320,10 @@ def main():
     used_ev, counted = [], {"nodes": 0}
 
     def run_steps(n_steps, measure):
-        """n_steps training steps.  Graph engine: the steps of every `event_every`-th epoch are replayed as
-        [front graph] -> event -> [select + aggregate graph] -> event -> [dense + Adam graph] (the same kernels in the
-        same order); every other epoch that fits into the remaining steps is ONE graph launch."""
+        """n_steps training steps.  Graph engine: the first `timed_per_epoch` batches of every `event_every`-th epoch are
+        launched kernel by kernel with HIP events around select + gather (the same kernels in the same order), the other
+        batches of such an epoch are one graph replay each; every other epoch that fits into the remaining steps is ONE
+        graph launch."""
         k = 0
         phase = {"epochs": 0 if (state["ids"] is None or state["b"] == nb) else 1}
         while k < n_steps:
@@ -335,9 +341,10 @@ def main():
                 k += nb
                 continue
             ids = next_batch()
-            # (also during the warm-up, so that every graph is captured before the clock starts; with epoch graphs every
-            #  batch that is not part of a whole-epoch replay goes through the event-bracketed per-slot graphs)
-            timed = timed_epoch or epoch_graphs
+            # (also during the warm-up, so that every graph is captured before the clock starts.)  With epoch graphs the first
+            # `timed_per_epoch` batches of an event-bracketed epoch are launched kernel by kernel with events; every other batch
+            # that is not part of a whole-epoch replay is one per-batch graph replay
+            timed = timed_epoch and (not epoch_graphs or state["b"] <= args.timed_per_epoch)
             one_step(ids, timed)
             if measure:
                 if timed:
@@ -350,6 +357,10 @@ def main():
     while epoch_graphs and state["b"] != nb:   # the warm-up may end mid-epoch; whole-epoch graphs start at an epoch boundary
         one_step(next_batch())
         warmup += 1
+    if epoch_graphs:                           # one more epoch, every batch as its own graph replay: captures all of them
+        for _ in range(nb):
+            one_step(next_batch())
+            warmup += 1
     prof._prof = []                                    # (start, end) HIP events around the select + aggregate launch
     barrier()
     t0 = time.perf_counter()
@@ -404,6 +415,13 @@ def main():
                          "launches_timed": len(kern_ms)},
         }
         if world == 1 and args.cpu_batches > 0:
+            # the CPU sample: the event-bracketed batches of the run, topped up with further epochs of the same sampler (same
+            # weights, same batch size) when a short run has bracketed fewer than --cpu-batches
+            ep = 1 << 20
+            while len(batches_host) < args.cpu_batches:
+                extra = tr.start_epoch(ep).cpu().numpy().astype(np.int64)
+                batches_host += [extra[i:i + B] for i in range(0, len(extra), B)]
+                ep += 1
             out["cpu_baseline"] = cpu_baseline(w, tr, cfg, batches_host, args.cpu_batches)
             out["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))

@@ -354,16 +354,11 @@ class FusedPCGNN:
         if eager:
             agg = self.agg.view(-1)[:g.R * B * g.feat_dim].view(g.R, B, g.feat_dim)
             keys = self.keys if g.n_pos else None
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             self._enqueue_front_train(ids, lab, B)
-            ev[0].record()
-            self._enqueue_choose(ids, lab, B, keys, True, planned=True, combine=False)
-            ev[1].record()
+            self._enqueue_choose(ids, lab, B, keys, True, planned=True, combine=False)     # (records the two events itself)
             self._enqueue_tail(ids, lab, B, agg, True)
             if lo + B >= self._ep_n:              # the epoch's last batch: nothing follows that would apply the deferred update
                 self.flush()
-            if self._prof is not None:
-                self._prof.append(ev)
             self.last_counts = self.cnt.view(-1)[:g.R * B].view(g.R, B)
             return
         if grs is None:
