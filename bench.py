@@ -284,7 +284,7 @@ def main():
         elif epoch_graphs and timed:   # the staged batch launched kernel by kernel with HIP events around select + gather
             tr.fused.epoch_step_timed(state["b"] - 1, eager=not args.timed_graphs)
         elif epoch_graphs:             # the staged batch as one graph replay (a batch that is not part of a whole-epoch replay)
-            tr.fused.epoch_step(state["b"] - 1)
+            tr.fused.epoch_step(state["b"] - 1, defer=True)
         elif dist is None:        # (graph engine: the per-batch graphs; whole epochs go through run_epoch_one_graph below)
             tr.step(ids, timed)
         else:

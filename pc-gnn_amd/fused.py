@@ -322,17 +322,21 @@ class FusedPCGNN:
         ep_ids.copy_(ids)
         ep_lab.copy_(labels)
 
-    def epoch_step(self, b: int):
+    def epoch_step(self, b: int, defer: bool = False):
+        """Batch b of the staged epoch as one graph replay.  defer: as inside epoch_run - the Adam update of everything but
+        the label classifier is left to the next batch's front launch (the epoch's last batch flushes it), so the
+        parameters are complete only after the last batch or a flush()."""
         lo = b * self._ep_bs
         B = min(self._ep_bs, self._ep_n - lo)
         if B <= 0:
             return
         self._lastB = B
-        key = (lo, B)
+        defer = defer and lo + B < self._ep_n
+        key = (lo, B, "deferred") if defer else (lo, B)
         gr = self._ep_graphs.get(key)
         if gr is None:
             ids, lab = self._ep_ids[lo:lo + B], self._ep_lab[lo:lo + B]
-            gr = self._capture_graphs([lambda: self.train_step(ids, lab)])[0]
+            gr = self._capture_graphs([lambda: self.train_step(ids, lab, defer=defer)])[0]
             self._ep_graphs[key] = gr
         gr.replay()
 
