@@ -712,21 +712,32 @@ def test_epoch_as_one_graph_equals_step_by_step(P):
     from pcgnn_amd.handler import PCGNNTrainer
     w = synth.make_workload("mini", 6000, 32, (4000, 30000, 90000), 0.12, seed=3)
     cfg = dict(engine="graph", batch_size=256, seed=5)
-    a, b = PCGNNTrainer(w, cfg, dev()), PCGNNTrainer(w, cfg, dev())
+    a, b, c = PCGNNTrainer(w, cfg, dev()), PCGNNTrainer(w, cfg, dev()), PCGNNTrainer(w, cfg, dev())
     b.fused.theta.copy_(a.fused.theta)
+    c.fused.theta.copy_(a.fused.theta)
     nb = a.batches_per_epoch()
     assert a.pick_size % a.batch_size != 0 and nb >= 3
-    for _ in range(3):
+    for ep in range(3):
         a.run_epoch_one_graph()
         ids = b.start_epoch_staged()
         for k in range(nb):
             sl = slice(k * b.batch_size, min((k + 1) * b.batch_size, b.pick_size))
             b.fused.train_step(ids[sl], b.fused._ep_lab[sl])
+        # the same epoch as one graph replay per batch with the Adam update deferred inside the epoch (what bench.py does for
+        # batches that are not part of a whole-epoch replay), the first batch of the second epoch launched kernel by kernel
+        c.start_epoch_staged()
+        for k in range(nb):
+            if ep == 1 and k == 0:
+                c.fused.epoch_step_timed(k)
+            else:
+                c.fused.epoch_step(k, defer=True)
     torch.cuda.synchronize()
-    assert int(a._epoch_dev[0]) == int(b._epoch_dev[0]) == 3
+    assert int(a._epoch_dev[0]) == int(b._epoch_dev[0]) == int(c._epoch_dev[0]) == 3
     assert torch.equal(a.fused._ep_ids[:a.pick_size], b.fused._ep_ids[:b.pick_size])
+    assert torch.equal(a.fused._ep_ids[:a.pick_size], c.fused._ep_ids[:c.pick_size])
     for name in ("theta", "m", "v", "step_counter"):
         assert torch.equal(getattr(a.fused, name), getattr(b.fused, name)), name
+        assert torch.equal(getattr(a.fused, name), getattr(c.fused, name)), name + " (per-batch graphs, deferred Adam)"
     assert torch.isfinite(a.fused.theta).all() and not torch.equal(a.fused.theta, torch.zeros_like(a.fused.theta))
 
 
