@@ -100,6 +100,19 @@ __device__ __forceinline__ bool halo_insert(const HaloArgs &a, const int32_t *s_
     return false;
 }
 
+// is the id in the table already?  (while inserts are going on a "no" may be stale - the caller then takes the insert path,
+// which copes with duplicates)
+__device__ __forceinline__ bool halo_has(const HaloArgs &a, uint32_t id) {
+    uint32_t h = halo_hash(id) & a.mask;
+    for (uint32_t probe = 0; probe <= a.mask; ++probe) {
+        const uint32_t key = __hip_atomic_load(&a.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (key == id) return true;
+        if (key == HALO_EMPTY) return false;
+        h = (h + 1) & a.mask;
+    }
+    return false;
+}
+
 // slot of a remote id, or HALO_EMPTY
 __device__ __forceinline__ uint32_t halo_find(const HaloArgs &a, uint32_t id) {
     uint32_t h = halo_hash(id) & a.mask;
@@ -178,11 +191,25 @@ __global__ void __launch_bounds__(256) halo_collect_kernel(const HaloArgs a) {
         if (c < 0 || c >= a.n_local) continue;               // (not a row this rank owns: nothing to walk)
         const int64_t beg = a.indptr[r][c], end = a.indptr[r][c + 1];
         const int32_t *__restrict__ nbr = a.indices[r];
-        for (int64_t i = beg + lane; i < end; i += PCG_WAVE) {
-            const int32_t id = nbr[i];
-            if (id < 0 || (id >= a.lo && id < a.hi)) continue;
-            if (pos_find(a.pos_ids, a.n_pos, id) >= 0) continue;
-            full |= !halo_insert(a, s_bounds, id);
+        // four loads of 64 ids in flight (unconditional: index clamped, the extra lanes masked out afterwards)
+        constexpr int CU = 4;
+        for (int64_t i0 = beg; i0 < end; i0 += CU * PCG_WAVE) {
+            int32_t idv[CU];
+#pragma unroll
+            for (int u = 0; u < CU; ++u) {
+                const int64_t i = i0 + u * PCG_WAVE + lane;
+                idv[u] = nbr[i < end ? i : end - 1] | (i < end ? 0 : (int32_t)0x80000000);
+            }
+#pragma unroll
+            for (int u = 0; u < CU; ++u) {
+                const int32_t id = idv[u];
+                if (id < 0 || (id >= a.lo && id < a.hi)) continue;
+                // most remote neighbours have been seen before: one or two probes settle them; only a new id pays for the
+                // binary search among the train positives (which are never inserted)
+                if (halo_has(a, (uint32_t)id)) continue;
+                if (pos_find(a.pos_ids, a.n_pos, id) >= 0) continue;
+                full |= !halo_insert(a, s_bounds, id);
+            }
         }
     }
     if (full) atomicOr(a.overflow, 1u);
@@ -205,12 +232,14 @@ __global__ void __launch_bounds__(256) halo_lookup_kernel(const HaloArgs a) {
             if (id >= a.lo && id < a.hi) {
                 out = id - a.lo;
             } else {
-                const int at = pos_find(a.pos_ids, a.n_pos, id);
-                if (at >= 0) {
-                    out = a.n_local + a.pos_idx[at];
+                // the table first (one or two probes for a fetched row, and for a train positive - never in the table - a
+                // probe to the first empty slot), the binary search among the train positives only after a miss
+                const uint32_t slot = halo_find(a, (uint32_t)id);
+                if (slot < (uint32_t)a.halo_cap) {
+                    out = a.halo_base + (int32_t)slot;
                 } else {
-                    const uint32_t slot = halo_find(a, (uint32_t)id);
-                    out = slot < (uint32_t)a.halo_cap ? a.halo_base + (int32_t)slot : -1;
+                    const int at = pos_find(a.pos_ids, a.n_pos, id);
+                    out = at >= 0 ? a.n_local + a.pos_idx[at] : -1;
                     miss |= out < 0;
                 }
             }
