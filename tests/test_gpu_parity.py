@@ -266,7 +266,9 @@ def hub_graph(seed, n, hub_degs, base_deg=6.0, feat=32):
 def test_hub_rows_block_and_scratch_paths(P, quantize):
     ops = P.ops
     n = 60000
-    hub_degs = [30000, 13000, 8193, 8192, 8191, 6000, 4097, 4096, 4095, 2500, 513, 512, 511, 257, 256, 255, 65, 64, 63]
+    # (> 10240: the long-row launch - 30000 keeps its kept ids in the list region, 20480 / 10241 as positive centres in LDS)
+    hub_degs = [30000, 13000, 8193, 8192, 8191, 6000, 4097, 4096, 4095, 2500, 513, 512, 511, 257, 256, 255, 65, 64, 63, 20480, 10241,
+                10240]
     X, labels, csr = hub_graph(11, n, hub_degs)
     if quantize:   # many exact distance ties: the positional tie-break must match the oracle
         X = np.round(X * 2) / 2
