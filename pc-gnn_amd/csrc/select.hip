@@ -613,18 +613,19 @@ __device__ __forceinline__ void select_wg_row(const ChooseArgs &a, int row, uint
     if (!keep_all) {
         // ---- 1. distance keys (-> LDS), their range ----
         uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
-        for (int base = tid; base < d; base += NT * KEY_UNROLL) {
-            uint32_t id[KEY_UNROLL];
-            float sc[KEY_UNROLL];
+        constexpr int KU1 = 16;     // pass 1 of a workgroup row: sixteen gathers in flight per lane (a 6 000-neighbour row: one round)
+        for (int base = tid; base < d; base += NT * KU1) {
+            uint32_t id[KU1];
+            float sc[KU1];
 #pragma unroll
-            for (int u = 0; u < KEY_UNROLL; ++u) {
+            for (int u = 0; u < KU1; ++u) {
                 const int i = base + u * NT;
                 id[u] = (uint32_t)nbr[i < d ? i : d - 1];
             }
 #pragma unroll
-            for (int u = 0; u < KEY_UNROLL; ++u) sc[u] = s0[id[u]];
+            for (int u = 0; u < KU1; ++u) sc[u] = s0[id[u]];
 #pragma unroll
-            for (int u = 0; u < KEY_UNROLL; ++u) {
+            for (int u = 0; u < KU1; ++u) {
                 const int i = base + u * NT;
                 if (i < d) {
                     const uint32_t key = dist_key(c, sc[u]);
