@@ -301,13 +301,15 @@ __global__ void __launch_bounds__(DENSE_THREADS) dense_step_kernel(const DenseAr
                 float acc = 0.f;
                 const float *pp = a.partial + (size_t)agg_cb[u] * a.partial_stride + agg_f[u];
                 const int nch = agg_nch[u];
-                int jx = 0;
-                for (; jx + 4 <= nch; jx += 4) {
-                    const float p0 = pp[(size_t)(jx + 0) * a.partial_stride], p1 = pp[(size_t)(jx + 1) * a.partial_stride];
-                    const float p2 = pp[(size_t)(jx + 2) * a.partial_stride], p3 = pp[(size_t)(jx + 3) * a.partial_stride];
-                    acc += p0; acc += p1; acc += p2; acc += p3;
+                // (eight loads in flight - clamped index, the extra values not added -, the adds in chunk order: a hub row has
+                //  dozens of chunks, and this loop sits in front of everything else the workgroup stages)
+                for (int jx = 0; jx < nch; jx += 8) {
+                    float pv[8];
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) pv[x] = pp[(size_t)(jx + x < nch ? jx + x : nch - 1) * a.partial_stride];
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) acc = jx + x < nch ? acc + pv[x] : acc;
                 }
-                for (; jx < nch; ++jx) acc += pp[(size_t)jx * a.partial_stride];
                 v_agg[u] = acc / (float)a.cnt[agg_row[u]];
             }
         }
