@@ -33,6 +33,7 @@ from src.model import PCALayer  # noqa: E402
 from src.utils import pick_step  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = sys.argv[1] if len(sys.argv) > 1 else HERE       # `python make_golden.py /tmp/check` regenerates elsewhere (to compare)
 torch.set_num_threads(1)
 
 
@@ -276,7 +277,7 @@ def pcgnn_case(name, seed, n, f, rel_deg, pos_rate, emb, batch, rhos, nonneg=Fal
         fsets = [set(sorted(homo[int(v)])) for v in sub]
         out[key] = MeanAggregator(features, cuda=False, gcn=gcn_flag).forward(sub, fsets, num_sample=fan_k).detach().numpy()
 
-    path = os.path.join(HERE, name + ".npz")
+    path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **out)
     print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB, min gap at any cut = {min_gap:.3e}, "
           f"B={len(nodes)} P={len(train_pos)} pos-in-batch={int(blab.sum())}")
@@ -309,7 +310,7 @@ def kat_case():
         sets, _ = RL.choose_step_test(torch.tensor([[0.0, 0.0]]), ns, [list(range(100, 100 + deg))], [k])
         kept.append(len(sets[0]))
     out["kat3_deg"], out["kat3_kept"] = list(range(1, 13)), kept
-    np.savez_compressed(os.path.join(HERE, "kat.npz"), **{k: np.asarray(v) for k, v in out.items()})
+    np.savez_compressed(os.path.join(OUT, "kat.npz"), **{k: np.asarray(v) for k, v in out.items()})
     print("kat:", {k: (v if not hasattr(v, "shape") else v.tolist()) for k, v in out.items() if "out" in k or "kept" in k})
 
 
@@ -328,7 +329,7 @@ def split_case():
         out[f"{tag}_labels"], out[f"{tag}_first"], out[f"{tag}_train_ratio"], out[f"{tag}_seed"] = labels, first, train_ratio, seed
         out[f"{tag}_idx_train"], out[f"{tag}_idx_valid"], out[f"{tag}_idx_test"] = np.array(a[0]), np.array(b[0]), np.array(b[1])
         out[f"{tag}_y_train"], out[f"{tag}_y_valid"], out[f"{tag}_y_test"] = a[2], b[2], b[3]
-    np.savez_compressed(os.path.join(HERE, "split.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "split.npz"), **out)
     print("split:", {k: len(v) for k, v in out.items() if k.endswith("idx_train")})
 
 
