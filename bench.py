@@ -136,8 +136,18 @@ def run_partitioned(args, w, B, lr, wd, dev, dist, world, rank):
     from pcgnn_amd.dist import DistributedPCGNN
     cfg = dict(emb_size=args.emb, rho=args.rho, alpha=2.0, lr=lr, weight_decay=wd, batch_size=B, seed=args.seed)
     W = max(1, args.window)
-    d = DistributedPCGNN(w, cfg, dev, window=W)
+    gloo = dist.get_backend() == "gloo"          # rehearsal of the N > 1 flow on one GPU (PCG_BENCH_BACKEND=gloo): collectives staged through the host
+    d = DistributedPCGNN(w, cfg, dev, window=W, stage_host=gloo)
     n_nodes, feat, n_rel = w.n, d.F, d.R
+
+    def all_reduce(t, op=None):
+        kw = {} if op is None else {"op": op}
+        if gloo:
+            c = t.cpu()
+            dist.all_reduce(c, **kw)
+            t.copy_(c)
+        else:
+            dist.all_reduce(t, **kw)
 
     def run_steps(first, n):
         """n steps in windows of W: one pick + one halo prefetch (two all-to-alls) per window, then per step one graph
@@ -169,9 +179,9 @@ def run_partitioned(args, w, B, lr, wd, dev, dist, world, rank):
                          dtype=torch.float64, device=dev)
     mem = torch.tensor([fr["owned"] + fr["train_pos"] + fr["halo"], seen["halo_rows"], fr["halo"], seen["rows_from_one_owner"],
                         fr["halo_pitch"]], dtype=torch.float64, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dist.all_reduce(stats)
-    dist.all_reduce(mem, op=dist.ReduceOp.MAX)
+    all_reduce(t, dist.ReduceOp.MAX)
+    all_reduce(stats)
+    all_reduce(mem, dist.ReduceOp.MAX)
     elapsed = float(t.item())
     nodes_total = args.steps * B * world
     if rank == 0:
@@ -225,6 +235,11 @@ def main():
         # (before any GPU call) a multi-GPU line must come from one process per GPU under torch.distributed.run
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with `python -m torch.distributed.run "
                          f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...`")
+    # PCG_BENCH_BACKEND=gloo: rehearsal of the N > 1 flow on a box with fewer GPUs than ranks (ranks share GPUs, collectives
+    # are staged through the host) - a correctness rehearsal, its numbers mean nothing
+    backend = os.environ.get("PCG_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -232,7 +247,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import pcgnn_amd  # noqa: F401  (raises if libpcgnn_hip.so is missing - no fallback)
     from pcgnn_amd.handler import PCGNNTrainer
