@@ -24,5 +24,6 @@ echo "[collect] partitioned path, world size 1"; python3 $R/bench.py --force-par
 if [ "$2" != "quick" ]; then
 echo "[collect] partitioned path, world size 1, sharded power-law 10M / 200M"; python3 $R/bench.py --force-partitioned --workload powerlaw --nodes 10000000 --edges 200000000 --batch-size 4096 --steps 40 --cpu-batches 0 > $O/bench_partitioned_w1_powerlaw_10m.log 2>&1 || exit 1
 echo "[collect] bench powerlaw 10M / 200M"; python3 $R/bench.py --workload powerlaw --nodes 10000000 --edges 200000000 --batch-size 4096 --steps 60 --cpu-batches 0 > $O/bench_powerlaw_10m_200m.log 2>&1 || exit 1
+echo "[collect] kernel trace powerlaw 10M / 200M"; rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_pl10m -o y -- python3 $R/bench.py --workload powerlaw --nodes 10000000 --edges 200000000 --batch-size 4096 --steps 40 --cpu-batches 0 > $O/trace_pl10m.log 2>&1 || exit 1
 fi
 ls $O
