@@ -154,3 +154,27 @@ def test_interagg_arities_and_state_dict_of_the_five_relation_model():
         P.InterAgg5(feats, f, e, [1], adj[:3], intra[:3], cuda=False)
     with pytest.raises(ValueError):
         P.InterAgg1(feats, f, e, [1], adj[:3], intra[:3], cuda=False)
+
+
+def test_bench_refuses_multi_gpu_without_launcher():
+    """`bench.py --gpus N` must come from one process per GPU (torch.distributed.run sets WORLD_SIZE): run alone it exits
+    non-zero before any GPU call instead of silently measuring one GPU; and algorithmic_bytes follows SURVEY 8(d)'s terms."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env,
+                       timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+    sys.path.insert(0, root)
+    import bench
+
+    class G:
+        R, feat_dim = 2, 8
+        deg_host = [np.array([3, 5, 0]), np.array([1, 1, 4])]
+    ids = np.array([0, 2])
+    counts = [np.array([2, 0]), np.array([1, 2])]
+    # per relation: 4 * (2B + D) CSR + 4 * D scores + 4 * F * S rows + 4 * B * F output
+    want = (4 * (4 + 3) + 4 * 3 + 4 * 8 * 2 + 4 * 2 * 8) + (4 * (4 + 5) + 4 * 5 + 4 * 8 * 3 + 4 * 2 * 8)
+    assert bench.algorithmic_bytes(G, ids, counts) == want
