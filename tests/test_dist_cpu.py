@@ -109,7 +109,7 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_halo_exchange_gloo(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
