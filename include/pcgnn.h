@@ -88,7 +88,7 @@ int pcg_score_rows(const pcg_graph_desc *g, const float *W, const float *b,
  * per-centre torch.sort over all of pos_scores (layers.py:683-688).
  * keys [pcg_pos_sort_capacity(n_pos)] uint64; on return its first ceil_pow2(max(n_pos, 4096)) entries hold
  * (orderable(s0[train_pos[p]]) << 32) | p ascending, padded with UINT64_MAX; the capacity is twice that: the second
- * half is scratch (the chunk-sort path for n_pos > 16384; the unsorted keys pcg_step_front forms beside the score pass). */
+ * half is scratch (the bucket sort's scatter buffer and splitters for n_pos > 16384; the unsorted keys pcg_step_front forms beside the score pass). */
 int64_t pcg_pos_sort_capacity(int32_t n_pos);
 int pcg_pos_sort(const pcg_graph_desc *g, const float *s0, uint64_t *keys, void *stream);
 

@@ -608,7 +608,7 @@ static int front_b(const pcg_graph_desc *g, const float *s0, uint64_t *pos_keys,
     hipLaunchKernelGGL(pcg::front_b_kernel, dim3(n_write + n_sort), dim3(pcg::PLAN_THREADS), 0, static_cast<hipStream_t>(stream), a,
                        tot, n_write, n_count, pos_keys, (int)cap, raw_keys, pending, center_out, center_id_offset);
     PCG_LAUNCH_CHECK();
-    if (sort && !rank) return pcg_pos_sort(g, s0, pos_keys, stream);    // many positives: the chunk sort's own launches
+    if (sort && !rank) return pcg_pos_sort(g, s0, pos_keys, stream);    // many positives: the bucket sort's own launches
     return PCG_OK;
 }
 

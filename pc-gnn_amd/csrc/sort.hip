@@ -3,15 +3,11 @@
 // sorted once, every positive centre then finds its m nearest by a window search.
 // Keys are unique 64-bit (orderable(score) << 32 | position in train_pos), so the
 // result is a total order: equal scores stay in list order.  Small P: one-launch rank sort;
-// large P: LDS bitonic sort of 2048-key chunks + one merge-by-ranks pass.
+// large P: bucket sort (sampled splitters, scatter, rank sort inside the buckets).
 #include "common.h"
 
 namespace pcg {
 
-#ifndef PCG_SORT_CHUNK
-#define PCG_SORT_CHUNK 2048     // (measured at 20 K / 40 K / 100 K keys: 48.7 / 67.9 / 108 us; 4096: 67.5 / 79.7 / 105; 1024: 53.7 / 87.0 / 155)
-#endif
-constexpr int SORT_CHUNK = PCG_SORT_CHUNK;   // keys sorted per workgroup in LDS
 constexpr int SORT_MIN_CAP = 4096;           // smallest key buffer (entries)
 constexpr int SORT_THREADS = 1024;
 
@@ -23,30 +19,6 @@ __device__ __forceinline__ void cmp_swap(uint64_t &a, uint64_t &b, bool ascendin
     }
 }
 
-// LDS bitonic steps j = j_start .. 1 of merge size k on this block's chunk
-__device__ __forceinline__ void lds_steps(uint64_t *sh, int chunk_base, int k, int j_start) {
-    for (int j = j_start; j > 0; j >>= 1) {
-        for (int p = threadIdx.x; p < SORT_CHUNK / 2; p += SORT_THREADS) {
-            const int i = 2 * j * (p / j) + (p % j);
-            const bool asc = (((chunk_base + i) & k) == 0);
-            cmp_swap(sh[i], sh[i + j], asc);
-        }
-        __syncthreads();
-    }
-}
-
-// build the keys and fully sort each SORT_CHUNK-sized chunk (alternating directions)
-__global__ void __launch_bounds__(SORT_THREADS) pos_sort_local(const float *__restrict__ s0,
-                                                               const int32_t *__restrict__ train_pos, int n_pos,
-                                                               uint64_t *__restrict__ keys, int all_ascending) {
-    __shared__ uint64_t sh[SORT_CHUNK];
-    const int base = blockIdx.x * SORT_CHUNK;
-    for (int t = threadIdx.x; t < SORT_CHUNK; t += SORT_THREADS) sh[t] = make_pos_key(s0, train_pos, base + t, n_pos);
-    __syncthreads();
-    for (int k = 2; k <= SORT_CHUNK; k <<= 1) lds_steps(sh, all_ascending ? 0 : base, k, k >> 1);
-    for (int t = threadIdx.x; t < SORT_CHUNK; t += SORT_THREADS) keys[base + t] = sh[t];
-}
-
 // ---- rank sort (n_pos <= RANK_MAX): rank_sort_body in common.h, shared with the fused step-front kernel ----
 __global__ void __launch_bounds__(RANK_WAVES *PCG_WAVE) pos_rank_sort(const float *__restrict__ s0,
                                                                       const int32_t *__restrict__ train_pos,
@@ -56,40 +28,169 @@ __global__ void __launch_bounds__(RANK_WAVES *PCG_WAVE) pos_rank_sort(const floa
     rank_sort_body(s0, train_pos, n_pos, cap, keys, (int)blockIdx.x, sh, part);
 }
 
-// ---- large n_pos: every 2048-key chunk sorted in LDS, then one "merge by ranks" pass ----------------------
-// rank(e) = its index in its own chunk + sum over the other chunks of #keys smaller than e (binary search in
-// an LDS copy of that chunk).  Keys are unique, so the ranks are a permutation.  Work P * (P/4096) * 12 LDS
-// steps instead of the rank sort's P^2 compares.
-__global__ void __launch_bounds__(SORT_THREADS) pos_merge_rank(const uint64_t *__restrict__ chunks, int n_pos, int cap,
-                                                               uint64_t *__restrict__ out) {
-    __shared__ uint64_t sh[SORT_CHUNK];
-    const int n_chunks = cap / SORT_CHUNK;
-    const int e = blockIdx.x * SORT_THREADS + threadIdx.x;       // element handled by this thread
-    const bool real = e < cap;
-    const uint64_t mine = real ? chunks[e] : ~0ull;
-    const int my_chunk = e / SORT_CHUNK;
-    int rank = e - my_chunk * SORT_CHUNK;
-    for (int c = 0; c < n_chunks; ++c) {
-        __syncthreads();
-        for (int t = threadIdx.x; t < SORT_CHUNK; t += SORT_THREADS) sh[t] = chunks[(size_t)c * SORT_CHUNK + t];
-        __syncthreads();
-        if (c == my_chunk) continue;
-        int lo = 0, hi = SORT_CHUNK;                              // #keys of chunk c smaller than mine
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (sh[mid] < mine) lo = mid + 1;
-            else hi = mid;
-        }
-        rank += lo;
-    }
-    if (real && mine != ~0ull) out[rank] = mine;                  // padding keys are not scattered ...
-    if (real && e >= n_pos) out[e] = ~0ull;                       // ... the tail [n_pos, cap) is filled directly
-}
-
+constexpr int BK_MAX = 1024;          // buckets of the bucket sort (n_pos > RANK_MAX)
+constexpr int BK_SCRATCH = 2 * BK_MAX; // uint64 entries behind the bucketed keys: splitters | counts, cursors
 static int64_t sort_capacity(int32_t n_pos) {
     int64_t c = SORT_MIN_CAP;
-    while (c < n_pos) c <<= 1;
+    const int64_t need = n_pos > RANK_MAX ? (int64_t)n_pos + BK_SCRATCH : n_pos;
+    while (c < need) c <<= 1;
     return c;
+}
+
+// ---- n_pos > RANK_MAX: bucket sort -------------------------------------------------------------------------------------------
+// splitters from a sorted sample -> every key's bucket (binary search among the splitters in LDS) -> counts -> scatter into
+// bucket-major order -> rank sort inside every bucket (rank_sort_body: 64 keys per workgroup against the bucket's keys).  Four
+// launches, every one over all CUs (the chunk sort kept P / 2048 workgroups busy for 78 bitonic stages); keys are unique, so
+// the buckets' ranges are disjoint and the result is the same total order.
+struct BucketArgs {
+    const float *s0;
+    const int32_t *train_pos;
+    int n_pos, n_buckets, n_sample;   // n_sample: a power of two <= SORT_MAX_SAMPLE, a multiple of n_buckets
+    uint64_t *keys;                   // [cap]: raw keys (count) -> read by scatter -> final order (sort)
+    uint64_t *tmp;                    // [n_pos] bucket-major keys
+    uint64_t *splitters;              // [n_buckets] splitters[0] = 0
+    uint32_t *counts, *cursors;       // [n_buckets] each
+    int cap;
+};
+constexpr int SORT_MAX_SAMPLE = 4096;
+
+// largest b with spl[b] <= key (spl[0] = 0)
+__device__ __forceinline__ int bucket_of(const uint64_t *spl, int nb, uint64_t key) {
+    int lo = 0, hi = nb;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (spl[mid] <= key) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// one workgroup: sample, sort it, every (n_sample / n_buckets)-th sample is a splitter; zero the counts
+__global__ void __launch_bounds__(SORT_THREADS) bk_splitters(const BucketArgs a) {
+    __shared__ uint64_t sh[SORT_MAX_SAMPLE];
+    for (int j = threadIdx.x; j < a.n_sample; j += SORT_THREADS)
+        sh[j] = make_pos_key(a.s0, a.train_pos, (int)(((int64_t)j * a.n_pos) / a.n_sample), a.n_pos);
+    __syncthreads();
+    if (a.n_sample <= SORT_THREADS) {
+        // a small sample: every thread ranks its key against all of them (broadcast reads, no stage barriers)
+        __shared__ uint64_t sorted[SORT_THREADS];
+        const int t = threadIdx.x;
+        if (t < a.n_sample) {
+            const uint64_t mine = sh[t];
+            int rank = 0;
+            for (int j = 0; j < a.n_sample; j += 4)
+                rank += (sh[j] < mine) + (sh[j + 1] < mine) + (sh[j + 2] < mine) + (sh[j + 3] < mine);
+            sorted[rank] = mine;       // (sample positions are distinct, so the keys - and the ranks - are)
+        }
+        __syncthreads();
+        if (t < a.n_sample) sh[t] = sorted[t];
+        __syncthreads();
+    } else {
+        for (int k = 2; k <= a.n_sample; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int p = threadIdx.x; p < a.n_sample / 2; p += SORT_THREADS) {
+                    const int i = 2 * j * (p / j) + (p % j);
+                    cmp_swap(sh[i], sh[i + j], (i & k) == 0);
+                }
+                __syncthreads();
+            }
+    }
+    const int per = a.n_sample / a.n_buckets;
+    for (int b = threadIdx.x; b < a.n_buckets; b += SORT_THREADS) {
+        a.splitters[b] = b == 0 ? 0ull : sh[b * per];
+        a.counts[b] = 0u;
+        a.cursors[b] = 0u;
+    }
+}
+
+// raw keys -> keys[i]; per-bucket counts (LDS histogram per workgroup, then one global add per bucket)
+__global__ void __launch_bounds__(SORT_THREADS) bk_count(const BucketArgs a) {
+    __shared__ uint64_t spl[BK_MAX];
+    __shared__ uint32_t hist[BK_MAX];
+    for (int b = threadIdx.x; b < a.n_buckets; b += SORT_THREADS) {
+        spl[b] = a.splitters[b];
+        hist[b] = 0u;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * SORT_THREADS + threadIdx.x;
+    if (i < a.n_pos) {
+        const uint64_t key = make_pos_key(a.s0, a.train_pos, i, a.n_pos);
+        a.keys[i] = key;
+        atomicAdd(&hist[bucket_of(spl, a.n_buckets, key)], 1u);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < a.n_buckets; b += SORT_THREADS)
+        if (hist[b]) atomicAdd(&a.counts[b], hist[b]);
+}
+
+// exclusive prefix of v[0 .. n) (n <= BK_MAX <= SORT_THREADS) into out[0 .. n], out[n] = total; all threads call
+__device__ __forceinline__ void block_prefix(const uint32_t *v, int n, uint32_t *out, uint32_t *wsum) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t x = t < n ? v[t] : 0u;
+    uint32_t inc = x;
+    for (int o = 1; o < PCG_WAVE; o <<= 1) {
+        const uint32_t y = __shfl_up(inc, o);
+        if (lane >= o) inc += y;
+    }
+    if (lane == PCG_WAVE - 1) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t pre = 0;
+    for (int w = 0; w < wave; ++w) pre += wsum[w];
+    if (t < n) out[t] = pre + inc - x;
+    if (t == n - 1) out[n] = pre + inc;
+    __syncthreads();
+}
+
+// keys[i] -> tmp[bucket-major]: a workgroup reserves its share of every bucket with one global atomic per bucket
+__global__ void __launch_bounds__(SORT_THREADS) bk_scatter(const BucketArgs a) {
+    __shared__ uint64_t spl[BK_MAX];
+    __shared__ uint32_t hist[BK_MAX], off[BK_MAX + 1], base[BK_MAX], wsum[SORT_THREADS / PCG_WAVE];
+    for (int b = threadIdx.x; b < a.n_buckets; b += SORT_THREADS) {
+        spl[b] = a.splitters[b];
+        hist[b] = 0u;
+    }
+    __syncthreads();
+    block_prefix(a.counts, a.n_buckets, off, wsum);
+    const int i = blockIdx.x * SORT_THREADS + threadIdx.x;
+    uint64_t key = 0;
+    int b = 0;
+    uint32_t r = 0;
+    if (i < a.n_pos) {
+        key = a.keys[i];
+        b = bucket_of(spl, a.n_buckets, key);
+        r = atomicAdd(&hist[b], 1u);
+    }
+    __syncthreads();
+    for (int bb = threadIdx.x; bb < a.n_buckets; bb += SORT_THREADS)
+        if (hist[bb]) base[bb] = off[bb] + atomicAdd(&a.cursors[bb], hist[bb]);
+    __syncthreads();
+    if (i < a.n_pos) a.tmp[base[b] + r] = key;
+}
+
+// workgroup -> (bucket, group of 64 of its keys): rank sort inside the bucket; the padding [n_pos, cap) by the last workgroups
+__global__ void __launch_bounds__(RANK_WAVES *PCG_WAVE) bk_sort(const BucketArgs a) {
+    __shared__ __align__(16) uint64_t sh[RANK_TILE];
+    __shared__ int part[RANK_WAVES * PCG_WAVE];
+    __shared__ uint32_t off[BK_MAX + 1], grp[BK_MAX + 1], gcount[BK_MAX], wsum[SORT_THREADS / PCG_WAVE];
+    static_assert(RANK_WAVES * PCG_WAVE == SORT_THREADS, "block_prefix assumes SORT_THREADS threads");
+    block_prefix(a.counts, a.n_buckets, off, wsum);
+    for (int b = threadIdx.x; b < a.n_buckets; b += SORT_THREADS) gcount[b] = (a.counts[b] + PCG_WAVE - 1) / PCG_WAVE;
+    __syncthreads();
+    block_prefix(gcount, a.n_buckets, grp, wsum);
+    const uint32_t me = blockIdx.x;
+    if (me >= grp[a.n_buckets]) {                       // spare workgroups: the padding behind the keys
+        const uint32_t spare = gridDim.x - grp[a.n_buckets], k = me - grp[a.n_buckets];
+        for (int64_t t = a.n_pos + (int64_t)k * SORT_THREADS + threadIdx.x; t < a.cap; t += (int64_t)spare * SORT_THREADS) a.keys[t] = ~0ull;
+        return;
+    }
+    int lo = 0, hi = a.n_buckets;                       // largest b with grp[b] <= me
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (grp[mid] <= me) lo = mid;
+        else hi = mid;
+    }
+    const int b = lo, n_b = (int)a.counts[b];
+    rank_sort_body(nullptr, nullptr, n_b, n_b, a.keys + off[b], (int)(me - grp[b]), sh, part, a.tmp + off[b]);
 }
 
 }  // namespace pcg
@@ -99,7 +200,7 @@ extern "C" {
 int64_t pcg_pos_sort_capacity(int32_t n_pos) {
     if (n_pos < 0) return PCG_E_ARG;
     const int64_t cap = pcg::sort_capacity(n_pos);
-    return 2 * cap;     // second half: the chunk-sort path's buffer / the unsorted keys pcg_step_front forms beside the score pass
+    return 2 * cap;     // second half: the bucket sort's scatter buffer + splitters / the unsorted keys pcg_step_front forms beside the score pass
 }
 
 int pcg_pos_sort(const pcg_graph_desc *g, const float *s0, uint64_t *keys, void *stream) {
@@ -114,12 +215,31 @@ int pcg_pos_sort(const pcg_graph_desc *g, const float *s0, uint64_t *keys, void 
         PCG_LAUNCH_CHECK();
         return PCG_OK;
     }
-    uint64_t *tmp = keys + cap;                         // second half of the caller's buffer
-    const int chunks = (int)(cap / pcg::SORT_CHUNK);
-    hipLaunchKernelGGL(pcg::pos_sort_local, dim3(chunks), dim3(pcg::SORT_THREADS), 0, st, s0, g->train_pos, g->n_pos, tmp, 1);
+    // bucket sort: [cap .. cap + n_pos) bucket-major keys | splitters | counts | cursors (sort_capacity left room for them)
+    pcg::BucketArgs b;
+    b.s0 = s0;
+    b.train_pos = g->train_pos;
+    b.n_pos = g->n_pos;
+    int nb = 16;
+    while (nb < pcg::BK_MAX && (int64_t)nb * 1024 < g->n_pos) nb <<= 1;          // ~1024 keys per bucket
+    b.n_buckets = nb;
+    int ns = nb * 16;                         // (<= 1024 samples are rank-sorted by one workgroup in ~2 us)
+    b.n_sample = ns > pcg::SORT_MAX_SAMPLE ? pcg::SORT_MAX_SAMPLE : ns;
+    b.keys = keys;
+    b.tmp = keys + cap;
+    b.splitters = b.tmp + g->n_pos;
+    b.counts = reinterpret_cast<uint32_t *>(b.splitters + pcg::BK_MAX);
+    b.cursors = b.counts + pcg::BK_MAX;
+    b.cap = (int)cap;
+    const int nblk = (g->n_pos + pcg::SORT_THREADS - 1) / pcg::SORT_THREADS;
+    hipLaunchKernelGGL(pcg::bk_splitters, dim3(1), dim3(pcg::SORT_THREADS), 0, st, b);
     PCG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(pcg::pos_merge_rank, dim3((unsigned)(cap / pcg::SORT_THREADS)), dim3(pcg::SORT_THREADS), 0, st, tmp,
-                       g->n_pos, (int)cap, keys);
+    hipLaunchKernelGGL(pcg::bk_count, dim3(nblk), dim3(pcg::SORT_THREADS), 0, st, b);
+    PCG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(pcg::bk_scatter, dim3(nblk), dim3(pcg::SORT_THREADS), 0, st, b);
+    PCG_LAUNCH_CHECK();
+    // a workgroup per 64 keys of a bucket (at most n_pos / 64 + one per bucket), + a few for the padding
+    hipLaunchKernelGGL(pcg::bk_sort, dim3((g->n_pos + PCG_WAVE - 1) / PCG_WAVE + nb + 8), dim3(pcg::RANK_WAVES * PCG_WAVE), 0, st, b);
     PCG_LAUNCH_CHECK();
     return PCG_OK;
 }
