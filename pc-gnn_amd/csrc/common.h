@@ -237,9 +237,10 @@ constexpr int RANK_MAX = 16384;
 constexpr int RANK_TILE = 8192;
 constexpr int RANK_WAVES = 16;
 
-// sh: RANK_TILE uint64, part: RANK_WAVES * 64 ints (LDS); workgroup `block` of ceil(n_pos / 64), 1024 threads
+// sh: TILE (default RANK_TILE) uint64, part: RANK_WAVES * 64 ints (LDS); workgroup `block` of ceil(n_pos / 64), 1024 threads
 // raw: the unsorted keys (make_pos_key of every i < n_pos), if somebody has formed them already (pos_key_body) - then a
 // tile is staged with coalesced 8-byte loads instead of two dependent loads and a random 4-byte gather per key
+template <int TILE = RANK_TILE>
 __device__ __forceinline__ void rank_sort_body(const float *__restrict__ s0, const int32_t *__restrict__ train_pos, int n_pos,
                                                int cap, uint64_t *__restrict__ keys, int block, uint64_t *sh, int *part,
                                                const uint64_t *__restrict__ raw = nullptr) {
@@ -247,7 +248,7 @@ __device__ __forceinline__ void rank_sort_body(const float *__restrict__ s0, con
     const int i = block * PCG_WAVE + lane;
     // a key costs two dependent loads (train_pos[i], then s0 of it): this thread's own key and its share of a tile's keys
     // are requested level by level, so the staging of a tile costs two load latencies in all
-    constexpr int PER = RANK_TILE / (RANK_WAVES * PCG_WAVE);
+    constexpr int PER = TILE / (RANK_WAVES * PCG_WAVE);
     // (every load here is unconditional - index clamped, the value OR-ed with all-ones where it must not count: a load inside
     //  a conditional is compiled into a branch that waits for every load in flight, and a tile's PER loads per thread would
     //  go out one at a time)
@@ -255,8 +256,8 @@ __device__ __forceinline__ void rank_sort_body(const float *__restrict__ s0, con
     const int id_mine = raw ? 0 : train_pos[ic];
     uint64_t mine = (raw ? raw[ic] : 0ull) | (i < n_pos ? 0ull : ~0ull);   // ~0 when i >= n_pos
     int c = 0;
-    for (int t0 = 0; t0 < n_pos; t0 += RANK_TILE) {
-        const int nt = (n_pos - t0 < RANK_TILE) ? n_pos - t0 : RANK_TILE;
+    for (int t0 = 0; t0 < n_pos; t0 += TILE) {
+        const int nt = (n_pos - t0 < TILE) ? n_pos - t0 : TILE;
         if (raw) {
             uint64_t kt[PER];
 #pragma unroll

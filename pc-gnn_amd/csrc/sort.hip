@@ -168,8 +168,9 @@ __global__ void __launch_bounds__(SORT_THREADS) bk_scatter(const BucketArgs a) {
 }
 
 // workgroup -> (bucket, group of 64 of its keys): rank sort inside the bucket; the padding [n_pos, cap) by the last workgroups
+constexpr int BK_TILE = 4096;         // (buckets hold ~1 K keys: a 32-KB tile lets three workgroups share a CU)
 __global__ void __launch_bounds__(RANK_WAVES *PCG_WAVE) bk_sort(const BucketArgs a) {
-    __shared__ __align__(16) uint64_t sh[RANK_TILE];
+    __shared__ __align__(16) uint64_t sh[BK_TILE];
     __shared__ int part[RANK_WAVES * PCG_WAVE];
     __shared__ uint32_t off[BK_MAX + 1], grp[BK_MAX + 1], gcount[BK_MAX], wsum[SORT_THREADS / PCG_WAVE];
     static_assert(RANK_WAVES * PCG_WAVE == SORT_THREADS, "block_prefix assumes SORT_THREADS threads");
@@ -190,7 +191,7 @@ __global__ void __launch_bounds__(RANK_WAVES *PCG_WAVE) bk_sort(const BucketArgs
         else hi = mid;
     }
     const int b = lo, n_b = (int)a.counts[b];
-    rank_sort_body(nullptr, nullptr, n_b, n_b, a.keys + off[b], (int)(me - grp[b]), sh, part, a.tmp + off[b]);
+    rank_sort_body<BK_TILE>(nullptr, nullptr, n_b, n_b, a.keys + off[b], (int)(me - grp[b]), sh, part, a.tmp + off[b]);
 }
 
 }  // namespace pcg
