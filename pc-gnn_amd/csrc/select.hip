@@ -590,10 +590,12 @@ __device__ __forceinline__ void for_keys(const uint32_t *keys, const uint32_t *_
 }
 
 // lds: WG_KEYCAP words (keys, later the kept ids) | hist HIST_WG | cand 64 | red
-template <bool LDSK>
+template <bool LDSK, int NW = SEL_NW>
 __device__ __forceinline__ void select_wg_row(const ChooseArgs &a, int row, uint32_t *keys, uint32_t *hist, uint32_t *cand,
                                               int *red, int tid, uint32_t *gk = nullptr) {
-    constexpr int NW = SEL_NW, NT = SEL_NW * PCG_WAVE;
+    constexpr int NT = NW * PCG_WAVE;
+    constexpr int HBITS = NW == 8 ? 11 : 12;                 // 4 * NT histogram bins: one uint4 of them per thread
+    static_assert(4 * NT == (1 << HBITS), "NW is 8 or 16");
     const int lane = tid & (PCG_WAVE - 1), wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (a.stamps && tid == 0) a.stamps[(size_t)row * 8] = wall_clock64() | ((unsigned long long)blockIdx.x << 54);
     const RowRec p = a.w.recs[row];
@@ -657,8 +659,8 @@ __device__ __forceinline__ void select_wg_row(const ChooseArgs &a, int row, uint
         while (lo < hi && cnt > PCG_WAVE) {
             const uint32_t range = hi - lo;
             const int bits = 32 - __clz((int)range);
-            const int shift = bits > 11 ? bits - 11 : 0;                    // (range >> shift) < HIST_WG
-            *reinterpret_cast<uint4 *>(hist + 4 * tid) = make_uint4(0u, 0u, 0u, 0u);       // HIST_WG == 4 * NT
+            const int shift = bits > HBITS ? bits - HBITS : 0;              // (range >> shift) < 4 * NT bins
+            *reinterpret_cast<uint4 *>(hist + 4 * tid) = make_uint4(0u, 0u, 0u, 0u);
             __syncthreads();                                                 // (also: everybody is done with red / res)
             for_keys<LDSK>(keys, gk, tid, d, NT, [&](int, uint32_t key) {
                 if (key >= lo && key <= hi) atomicAdd(&hist[(key - lo) >> shift], 1u);
@@ -921,11 +923,12 @@ __global__ void __launch_bounds__(SEL_NW *PCG_WAVE) __attribute__((amdgpu_waves_
 // launch is skipped when the graph's maximum degree rules them out).  Persistent workgroups walk the > 4096 queue and take
 // the rows that select_rows left alone; workgroup b keeps its keys in scratch[b * per_wg ..].
 constexpr int LONG_BLOCKS = 256;
-__global__ void __launch_bounds__(SEL_NW *PCG_WAVE) select_long_rows(const ChooseArgs a, int64_t per_wg) {
+constexpr int LONG_NW = 16;              // sixteen waves per long row: half the gathers / scratch reads per lane
+__global__ void __launch_bounds__(LONG_NW *PCG_WAVE) select_long_rows(const ChooseArgs a, int64_t per_wg) {
     extern __shared__ __align__(16) unsigned char smem[];
-    uint32_t *lds = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *lds = reinterpret_cast<uint32_t *>(smem);                   // WG_KEYCAP words: the kept ids | 4096 bins | cand | red
     uint32_t *hist = lds + WG_KEYCAP;
-    uint32_t *cand = hist + HIST_WG;
+    uint32_t *cand = hist + 4 * LONG_NW * PCG_WAVE;
     int *red = reinterpret_cast<int *>(cand + PCG_WAVE);
     const int n16 = (int)a.w.counters[C_N16];
     uint32_t *gk = a.w.key_scratch + (size_t)blockIdx.x * per_wg;
@@ -933,14 +936,14 @@ __global__ void __launch_bounds__(SEL_NW *PCG_WAVE) select_long_rows(const Choos
     // them and most none.  Every workgroup therefore pulls queue positions from one cursor (heads[14]; a few hundred atomics
     // in all) - AFTER it is done with its unit, not a unit ahead: units cost nothing or 60 us here, and a workgroup busy with
     // a long row must not sit on a claim.  The last workgroup out puts the cursor back to zero.
-    int *claim = red + 2 * SEL_NW + 6;
+    int *claim = red + 2 * LONG_NW + 6;
     uint32_t *cursor = a.w.heads + 14, *done = a.w.heads + 13;
     const bool leader = threadIdx.x == 0;
     int u = (int)blockIdx.x, slot = 0;
     while (u < n16) {
         const int row = __builtin_amdgcn_readfirstlane(a.w.q16[u]);
         if (a.w.recs[row].d > WG_KEYCAP) {                                  // (workgroup-uniform)
-            select_wg_row<false>(a, row, lds, hist, cand, red, (int)threadIdx.x, gk);
+            select_wg_row<false, LONG_NW>(a, row, lds, hist, cand, red, (int)threadIdx.x, gk);
         }
         __syncthreads();
         if (leader) claim[slot] = (int)gridDim.x + (int)atomicAdd(cursor, 1u);
@@ -980,7 +983,8 @@ int launch_select_rows(const ChooseArgs &a, hipStream_t st) {
         int64_t nb = a.w.scratch_cap / per_wg;
         nb = nb < LONG_BLOCKS ? nb : LONG_BLOCKS;
         if (nb < 1) return PCG_E_ARG;
-        hipLaunchKernelGGL(select_long_rows, dim3((int)nb), dim3(SEL_NW * PCG_WAVE), select_smem_bytes(), st, a, per_wg);
+        const size_t long_smem = sizeof(uint32_t) * (WG_KEYCAP + 4 * LONG_NW * PCG_WAVE + PCG_WAVE) + sizeof(int) * (2 * LONG_NW + 8);
+        hipLaunchKernelGGL(select_long_rows, dim3((int)nb), dim3(LONG_NW * PCG_WAVE), long_smem, st, a, per_wg);
         PCG_LAUNCH_CHECK();
     }
     return PCG_OK;

@@ -67,7 +67,7 @@ __device__ __forceinline__ int bucket_of(const uint64_t *spl, int nb, uint64_t k
 
 // one workgroup: sample, sort it, every (n_sample / n_buckets)-th sample is a splitter; zero the counts
 __global__ void __launch_bounds__(SORT_THREADS) bk_splitters(const BucketArgs a) {
-    __shared__ uint64_t sh[SORT_MAX_SAMPLE];
+    __shared__ __align__(16) uint64_t sh[SORT_MAX_SAMPLE];
     for (int j = threadIdx.x; j < a.n_sample; j += SORT_THREADS)
         sh[j] = make_pos_key(a.s0, a.train_pos, (int)(((int64_t)j * a.n_pos) / a.n_sample), a.n_pos);
     __syncthreads();
@@ -78,8 +78,14 @@ __global__ void __launch_bounds__(SORT_THREADS) bk_splitters(const BucketArgs a)
         if (t < a.n_sample) {
             const uint64_t mine = sh[t];
             int rank = 0;
-            for (int j = 0; j < a.n_sample; j += 4)
-                rank += (sh[j] < mine) + (sh[j + 1] < mine) + (sh[j + 2] < mine) + (sh[j + 3] < mine);
+            const uint4 *sh4 = reinterpret_cast<const uint4 *>(sh);       // (n_sample is a multiple of 8; two keys per 16-byte read)
+            for (int j = 0; j < a.n_sample; j += 8) {
+                const uint4 q0 = sh4[(j >> 1) + 0], q1 = sh4[(j >> 1) + 1], q2 = sh4[(j >> 1) + 2], q3 = sh4[(j >> 1) + 3];
+                rank += ((((uint64_t)q0.y << 32) | q0.x) < mine) + ((((uint64_t)q0.w << 32) | q0.z) < mine) +
+                        ((((uint64_t)q1.y << 32) | q1.x) < mine) + ((((uint64_t)q1.w << 32) | q1.z) < mine) +
+                        ((((uint64_t)q2.y << 32) | q2.x) < mine) + ((((uint64_t)q2.w << 32) | q2.z) < mine) +
+                        ((((uint64_t)q3.y << 32) | q3.x) < mine) + ((((uint64_t)q3.w << 32) | q3.z) < mine);
+            }
             sorted[rank] = mine;       // (sample positions are distinct, so the keys - and the ranks - are)
         }
         __syncthreads();
@@ -224,7 +230,7 @@ int pcg_pos_sort(const pcg_graph_desc *g, const float *s0, uint64_t *keys, void 
     int nb = 16;
     while (nb < pcg::BK_MAX && (int64_t)nb * 1024 < g->n_pos) nb <<= 1;          // ~1024 keys per bucket
     b.n_buckets = nb;
-    int ns = nb * 16;                         // (<= 1024 samples are rank-sorted by one workgroup in ~2 us)
+    int ns = nb * 8;                          // (<= 1024 samples are rank-sorted by one workgroup in a few microseconds)
     b.n_sample = ns > pcg::SORT_MAX_SAMPLE ? pcg::SORT_MAX_SAMPLE : ns;
     b.keys = keys;
     b.tmp = keys + cap;
