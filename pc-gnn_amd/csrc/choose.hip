@@ -304,6 +304,10 @@ __device__ __forceinline__ void plan_write_body(const ChooseArgs &a, const PlanT
     // across lanes; everybody picks the 14 sums up from LDS
     const int before = block * (THREADS / COUNT_THREADS);
     __shared__ long long s_sum[2][8];
+    // this thread's row record is requested first (unconditionally, index clamped): its latency hides behind the totals
+    const int rows_ = a.g.n_rel * a.B;
+    const int row_ = block * THREADS + (int)threadIdx.x;
+    const RowRec rec_early = a.w.recs[row_ < rows_ ? row_ : rows_ - 1];
     if (threadIdx.x < PCG_WAVE) {
         long long v[2][7] = {{0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0}};
         for (int bk = (int)threadIdx.x; bk < n_count_blocks; bk += PCG_WAVE) {
@@ -331,13 +335,8 @@ __device__ __forceinline__ void plan_write_body(const ChooseArgs &a, const PlanT
     all = {(int)s_sum[1][2], (int)s_sum[1][3], (int)s_sum[1][4], (int)s_sum[1][5], (int)s_sum[1][6]};
     const bool overflow = all_cap > a.w.list_capacity || (long long)all_chunk > a.w.chunk_cap;
     const int row = block * THREADS + (int)threadIdx.x;
-    RowRec rec;
-    rec.d = 0;
-    int cap = 0;
-    if (row < rows) {
-        rec = a.w.recs[row];
-        cap = rec_cap(rec, a.add_self);
-    }
+    const RowRec rec = rec_early;
+    const int cap = row < rows ? rec_cap(rec, a.add_self) : 0;
     const int nch = (cap + CHUNK - 1) / CHUNK;
     const int tier = row < rows ? row_tier(rec.d, rec.m > 0 || a.add_self) : -1;
     PlanScan pre, tot;
