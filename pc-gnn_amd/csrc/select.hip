@@ -736,7 +736,10 @@ __device__ __forceinline__ void select_wg_row(const ChooseArgs &a, int row, uint
     // where the kept ids go: the keys' LDS (dead once every wave has its mask; a scratch-key row never used it) if they fit -
     // the minority picks are de-duplicated against them by binary search, 13 dependent loads per pick: LDS, not global - else
     // straight into the list region
-    const bool sel_in_lds = LDSK || k <= WG_KEYCAP;
+    // A row with nothing to do after the selection (no minority picks, no self union) writes its kept ids straight into its
+    // list region and reports itself: no LDS staging, no copy.
+    const bool plain = p.m == 0 && !a.add_self;                              // (the same for every thread)
+    const bool sel_in_lds = (LDSK || k <= WG_KEYCAP) && !plain;
     uint32_t *selbuf = sel_in_lds ? keys : reinterpret_cast<uint32_t *>(out);
     if constexpr (LDSK) {
         // pass A: which positions stay (a bit per iteration in a register; seg <= 1280 -> <= 20 iterations), pass B: their
@@ -773,7 +776,11 @@ __device__ __forceinline__ void select_wg_row(const ChooseArgs &a, int row, uint
             for (int u = 0; u < CU; ++u) {
                 const bool s = (mask >> (it + u)) & 1u;
                 const uint64_t sm = __ballot(s);
-                if (s) selbuf[run + __popcll(sm & lanemask_lt())] = idv[u];
+                const int at = run + __popcll(sm & lanemask_lt());
+                if (s) {                                                     // (two typed stores instead of one through a generic pointer)
+                    if (plain) out[at] = (int32_t)idv[u];
+                    else keys[at] = idv[u];
+                }
                 run += __popcll(sm);
             }
         }
@@ -835,7 +842,23 @@ __device__ __forceinline__ void select_wg_row(const ChooseArgs &a, int row, uint
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
     PCG_STAMP(3);
-    finish_row<NW>(a, row, p, c, selbuf, ns, !sel_in_lds, wave, lane, red);
+    if (plain) {                                                             // everything the row has to report, by wave 0
+        if (wave == 0) {
+            if (lane == 0) {
+                a.w.len[row] = ns;
+                a.cnt[row] = ns;
+            }
+            const int nch = (rec_cap(p, 0) + CHUNK - 1) / CHUNK;
+            for (int j = lane; j < nch; j += PCG_WAVE) {
+                const int left = ns - j * CHUNK;
+                a.w.chunk_desc[p.chunk0 + j].z = left < 0 ? 0 : (left > CHUNK ? CHUNK : left);
+            }
+        }
+        PCG_STAMP(6);
+        return;
+    }
+    if constexpr (LDSK) finish_row<NW>(a, row, p, c, keys, ns, false, wave, lane, red);
+    else finish_row<NW>(a, row, p, c, selbuf, ns, !sel_in_lds, wave, lane, red);
 }
 
 // One persistent launch selects every row of the batch, longest rows first.  The work is one queue of workgroup-sized units,
