@@ -222,11 +222,25 @@ __global__ void __launch_bounds__(256) halo_lookup_kernel(const HaloArgs a) {
     const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
     const uint32_t total = *a.n_chunks < a.chunk_cap ? *a.n_chunks : a.chunk_cap;
     bool miss = false;
-    for (uint32_t ch = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); ch < total; ch += nwaves) {
-        const int4 desc = a.chunk_desc[ch];
-        for (int i = lane; i < desc.z; i += PCG_WAVE) {
-            int32_t *e = a.list + desc.y + i;
-            const int32_t id = *e;
+    // a chunk has at most 128 entries: both halves are loaded at once (unconditionally: index clamped, the lanes beyond the
+    // chunk marked as holes), and the next chunk's descriptor is requested before this chunk is worked on
+    uint32_t ch = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int4 desc = a.chunk_desc[ch < total ? ch : 0u];
+    for (; ch < total; ch += nwaves) {
+        const int4 next = a.chunk_desc[ch + nwaves < total ? ch + nwaves : ch];
+        const int n = desc.z;
+        int32_t *base = a.list + desc.y;
+        int32_t idv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = lane + u * PCG_WAVE;
+            idv[u] = base[i < n ? i : (n > 0 ? n - 1 : 0)] | (i < n ? 0 : (int32_t)0x80000000);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = lane + u * PCG_WAVE;
+            int32_t *e = base + i;
+            const int32_t id = idv[u];
             if (id < 0) continue;
             int32_t out;
             if (id >= a.lo && id < a.hi) {
@@ -245,6 +259,7 @@ __global__ void __launch_bounds__(256) halo_lookup_kernel(const HaloArgs a) {
             }
             *e = out;
         }
+        desc = next;
     }
     if (miss) atomicOr(a.overflow, 4u);
 }
