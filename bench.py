@@ -66,6 +66,13 @@ def parse():
                     "kernel with HIP events (the rest of that epoch: one graph replay per batch)")
     ap.add_argument("--event-every", type=int, default=3,
                     help="graph engine: bracket the select+aggregate launch with HIP events on every step of every Nth epoch")
+    ap.add_argument("--list-capacity", type=int, default=None, help="entries of the selection list (default: the graph's worst case); "
+                    "a value too small for a batch makes the run exit non-zero (the status word is checked after the timed region)")
+    ap.add_argument("--report-epochs", type=int, default=7, help="graph engine: epochs timed one by one AFTER the timed region "
+                    "(sampler and batches as two graph launches with events in between) for the reference-window / pick-inclusive "
+                    "medians (SURVEY 8d); 0 = skip")
+    ap.add_argument("--verify-batches", type=int, default=1, help="batches whose chosen sets are checked after the clock stops "
+                    "(count law on every row, the oracle's sets on a strided sample); 0 = skip")
     ap.add_argument("--engine", default=None, choices=["graph", "fused", "torch", "dp"],
                     help="graph: fused HIP step replayed from a hipGraph (default at 1 GPU); fused: same kernels "
                          "launched eagerly (default at N>1, gradient all-reduce in between); torch: torch dense tail")
@@ -130,6 +137,76 @@ def cpu_baseline(w, trainer, cfg, batches, n_batches):
     return out
 
 
+def epoch_report(tr, n_epochs):
+    """SURVEY 8(d)'s reporting form, measured AFTER the timed region: every epoch as two graph launches - the sampler (pick +
+    shuffle + labels, src/model_handler.py:130-133) and the epoch's batches (the reference's per-batch window :143-155, summed
+    as the reference sums it) - with HIP events before, between and after; medians over the epochs."""
+    fz = tr.fused
+    fz.stage_epoch(tr.pick_size, tr.batch_size)
+    evs = []
+    for e in range(n_epochs + 1):                # (the first one captures the batches-only graph: not counted)
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        tr.start_epoch_staged()
+        e1.record()
+        fz.epoch_run()
+        e2.record()
+        evs.append((e0, e1, e2))
+    torch.cuda.synchronize(tr.device)
+    fz.check()
+    win = np.array([a.elapsed_time(b) for _, a, b in evs[1:]]) * 1e-3
+    inc = np.array([a.elapsed_time(b) for a, _, b in evs[1:]]) * 1e-3
+    n = tr.pick_size
+    return {"epochs": n_epochs, "nodes_per_epoch": n, "batches_per_epoch": tr.batches_per_epoch(),
+            "reference_window_nodes_per_s_median": float(n / np.median(win)), "pick_inclusive_nodes_per_s_median": float(n / np.median(inc)),
+            "reference_window_ms_per_epoch_median": float(np.median(win) * 1e3), "pick_inclusive_ms_per_epoch_median": float(np.median(inc) * 1e3),
+            "how": "after the timed region; per epoch: event | sampler launch | event | one graph launch of all batches | event"}
+
+
+def verify_rows(w, tr, cfg, batches, stride=61):
+    """After the clock has stopped: the chosen sets of event-bracketed batches of the run, recomputed by the product path with
+    the final parameters and read back - the count law on every row (kept = deg > k + 1 ? k : deg neighbours, plus at most
+    m = int(k * rho) train positives for a positive centre, src/layers.py:662-694) and, on a strided sample of rows, the
+    oracle's sets for the same device scores (bit-exact).  The oracle is the checker here, nothing it computes is timed
+    or fed back."""
+    from oracle import pcgnn_oracle as O
+    from pcgnn_amd import ops
+    g, fz = tr.graph, tr.fused
+    fz.flush()
+    s0 = ops.score_table(g, fz.w_clf, fz.b_clf)
+    keys = ops.pos_sort(g, s0)
+    s0_h = torch.from_numpy(s0.cpu().numpy())
+    pos = list(w.train_pos)
+    pos_s = s0_h[torch.as_tensor(pos, dtype=torch.long)]
+    rho, thr = float(cfg["rho"]), 0.5
+    rows_law = rows_oracle = 0
+    for ids in batches:
+        B = int(ids.numel())
+        lab = tr.labels_i32[ids.long()]
+        sets, _, cnt = ops.chosen_sets(g, ids, lab, s0, keys, [thr] * g.R, rho, True)
+        ids_h, lab_h, cnt_h = ids.cpu().numpy().astype(np.int64), lab.cpu().numpy(), cnt.cpu().numpy()
+        for r in range(g.R):
+            deg = g.deg_host[r][ids_h].astype(np.int64)
+            k = np.ceil(deg * thr).astype(np.int64)
+            kept = np.where(deg > k + 1, k, deg)
+            m = np.where(lab_h == 1, np.minimum((k * rho).astype(np.int64), len(pos)), 0)
+            sizes = np.array([len(x) for x in sets[r]])
+            if not (np.array_equal(sizes, cnt_h[r]) and (sizes >= kept).all() and (sizes <= kept + m).all()):
+                raise SystemExit(f"verify_rows: the count law fails in relation {r}")
+            rows_law += B
+            probe = list(range(0, B, stride))
+            indptr, idx = w.csr[r]
+            lists = [idx[indptr[v]:indptr[v + 1]].tolist() for v in ids_h[probe]]
+            want = O.choose_sets(s0_h[torch.as_tensor(ids_h[probe], dtype=torch.long)], [int(lab_h[b]) for b in probe], lists,
+                                 [s0_h[torch.as_tensor(l, dtype=torch.long)] for l in lists], pos, pos_s, thr, rho, True)
+            for b, ws_ in zip(probe, want):
+                if sets[r][b] != ws_:
+                    raise SystemExit(f"verify_rows: relation {r} row {b} (node {ids_h[b]}, degree {deg[b]}) differs from the oracle's set")
+            rows_oracle += len(probe)
+    return {"batches": len(batches), "rows_count_law": rows_law, "rows_vs_oracle": rows_oracle,
+            "how": "after the timed region, final parameters, product path re-run on the run's event-bracketed batches"}
+
+
 def run_partitioned(args, w, B, lr, wd, dev, dist, world, rank):
     """N > 1: destination-node partition, RCCL all-to-all of remote neighbour rows (once per window of steps) +
     gradient all-reduce (pc-gnn_amd/dist.py).  Weak scaling: every rank trains batches of B centres it owns."""
@@ -185,6 +262,10 @@ def run_partitioned(args, w, B, lr, wd, dev, dist, world, rank):
     all_reduce(t, dist.ReduceOp.MAX)
     all_reduce(stats)
     all_reduce(mem, dist.ReduceOp.MAX)
+    # what every rank believes the job to be: the smallest and the largest world size any rank's process group reports
+    seen = torch.tensor([dist.get_world_size(), -dist.get_world_size()], dtype=torch.float64, device=dev)
+    all_reduce(seen, dist.ReduceOp.MAX)
+    world_seen = {"max": int(seen[0].item()), "min": int(-seen[1].item()), "backend": dist.get_backend()}
     elapsed = float(t.item())
     nodes_total = args.steps * B * world
     if rank == 0:
@@ -210,6 +291,8 @@ def run_partitioned(args, w, B, lr, wd, dev, dist, world, rank):
             "n_gpus": world, "steps": args.steps, "warmup": warmup, "warmup_requested": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "status_clean": True,             # d.check() above raised on every rank otherwise
+            "world_size_seen": world_seen,
             "config": {"workload": f"{w.name} N={n_nodes} F={feat} R={n_rel} "
                                    f"edges={'/'.join(str(e) for e in w.meta['rel_edges'])}, PCGNN emb={args.emb} "
                                    f"batch={B}/GPU rho={args.rho}",
@@ -229,15 +312,50 @@ def run_partitioned(args, w, B, lr, wd, dev, dist, world, rank):
     dist.destroy_process_group()
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: start N fresh processes - one per GPU - under
+    torch.distributed.run and hand back their exit status.  This parent never touches the GPU (importing torch does not
+    initialise it), it only waits; rank 0's JSON line goes straight to the inherited stdout."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(world, rank):
+    """PCG_BENCH_DRY=1: the launch plumbing alone (process group up, one all-reduce, one line) - no GPU, no library; what
+    the CPU test of `--gpus N` exercises."""
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.ones(1)
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": int(t.item())}))
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    launched = "WORLD_SIZE" in os.environ
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and (world > 1 or args.gpus > 1):
-        # (before any GPU call) a multi-GPU line must come from one process per GPU under torch.distributed.run
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with `python -m torch.distributed.run "
-                         f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...`")
+    if args.gpus > 1 and not launched:
+        raise SystemExit(self_launch(args))          # (before any GPU call)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's process count and --gpus disagree")
+    if os.environ.get("PCG_BENCH_DRY") == "1":
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        return dry_run(world, rank)
     # PCG_BENCH_BACKEND=gloo: rehearsal of the N > 1 flow on a box with fewer GPUs than ranks (ranks share GPUs, collectives
     # are staged through the host) - a correctness rehearsal, its numbers mean nothing
     backend = os.environ.get("PCG_BENCH_BACKEND", "nccl")
@@ -273,7 +391,7 @@ def main():
         engine = "fused"
     cfg = dict(emb_size=args.emb, rho=args.rho, alpha=2.0, lr=lr, weight_decay=wd, batch_size=B,
                seed=args.seed + 1000 * rank, engine=engine, world_size=world,
-               workload_key=args.workload if (B == default_b and args.emb == 64) else "")
+               workload_key=args.workload if (B == default_b and args.emb == 64) else "", list_capacity=args.list_capacity)
     tr = PCGNNTrainer(w, cfg, dev)
     torch.manual_seed(args.seed)                     # identical initial weights on every rank
     with torch.no_grad():
@@ -389,6 +507,13 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     events, prof._prof = prof._prof, None
+    # the status word, once, after the clock has stopped: a batch that did not fit its selection list makes the kernels select
+    # nothing - a throughput for empty work must not be printed (raises -> non-zero exit)
+    status_clean = None
+    if tr.fused is not None:
+        tr.fused.check()
+        status_clean = True
+    report = epoch_report(tr, args.report_epochs) if (epoch_graphs and args.report_epochs > 0 and rank == 0) else None
 
     nodes_local = counted["nodes"]
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -418,7 +543,7 @@ def main():
             "metric": "sampled-nodes/sec", "value": nodes_total / elapsed, "unit": "nodes/s",
             "n_gpus": world, "steps": args.steps, "warmup": warmup, "warmup_requested": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "status_clean": status_clean,
             "timed_window": "every step = the reference's per-batch window (src/model_handler.py:143-155); the sampler - pick + "
                             "shuffle + label lookup (:130-133), one launch per epoch - runs INSIDE the timed region at every "
                             "epoch start, so `value` is the pick-inclusive figure (there is no separate pick-exclusive one); "
@@ -435,6 +560,10 @@ def main():
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": float(np.mean(abytes)),
                          "launches_timed": len(kern_ms)},
         }
+        if report is not None:
+            out["epoch_report"] = report
+        if world == 1 and args.verify_batches > 0 and tr.fused is not None and used_ev:
+            out["verified"] = verify_rows(w, tr, cfg, [i for i, _ in used_ev][:args.verify_batches])
         if world == 1 and args.cpu_batches > 0:
             # the CPU sample: the event-bracketed batches of the run, topped up with further epochs of the same sampler (same
             # weights, same batch size) when a short run has bracketed fewer than --cpu-batches

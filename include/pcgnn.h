@@ -47,7 +47,8 @@ enum {
 
 /* bits of the device-side status word */
 enum {
-    PCG_ST_SEL_OVERFLOW = 1   /* sel_indices capacity too small; nothing was written past it */
+    PCG_ST_SEL_OVERFLOW = 1,  /* sel_indices capacity too small; nothing was written past it */
+    PCG_ST_LIST_ID_RANGE = 2  /* a selection-list entry named no row of the table handed to the gather; it was skipped (a hole) */
 };
 
 enum { PCG_NORM_COUNT = 0, PCG_NORM_SQRT_COUNT = 1 };
@@ -135,9 +136,14 @@ int pcg_choose_select(const pcg_graph_desc *g, const int32_t *nodes, const int32
                       const float *s0, const float *center_s0, const uint64_t *pos_keys,
                       const double *thresholds, const double *rho, int32_t train_flag, int32_t add_self,
                       int32_t *cnt, void *workspace, int64_t list_capacity, uint32_t *status, void *stream);
-int pcg_aggregate_lists(const float *X, int32_t feat_dim, int32_t feat_stride, int32_t n_rows, const int32_t *cnt,
-                        const pcg_graph_desc *g, int32_t B, void *workspace, int64_t list_capacity,
-                        int32_t norm, float *agg, int32_t agg_stride, void *stream);
+/* pcg_aggregate_lists: the gather + mean half on its own, over the lists (and the plan) a pcg_choose_select* call left in
+ * `workspace`, reading feature rows from X [table_rows, feat_stride] - g->X, or a table with further rows behind it (the
+ * partitioned path's [owned | train-pos | halo] table, whose lists pcg_halo_lookup has re-indexed).  n_rows = the rows of the
+ * plan = g->n_rel * B (anything else is rejected).  A list entry outside [0, table_rows) is skipped like a hole and
+ * PCG_ST_LIST_ID_RANGE is OR-ed into *status (may be NULL: then only skipped). */
+int pcg_aggregate_lists(const float *X, int32_t feat_dim, int32_t feat_stride, int64_t table_rows, int32_t n_rows,
+                        const int32_t *cnt, const pcg_graph_desc *g, int32_t B, void *workspace, int64_t list_capacity,
+                        int32_t norm, float *agg, int32_t agg_stride, uint32_t *status, void *stream);
 int pcg_choose_aggregate(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B,
                          const float *s0, const float *center_s0, const uint64_t *pos_keys,
                          const double *thresholds, const double *rho, int32_t train_flag,
@@ -189,9 +195,9 @@ int pcg_choose_gather_planned(const pcg_graph_desc *g, const int32_t *nodes, con
                               const double *thresholds, const double *rho, int32_t train_flag, int32_t add_self,
                               float *agg, int32_t agg_stride, int32_t *cnt, void *workspace, int64_t list_capacity,
                               uint32_t *status, void *stream);
-int pcg_gather_lists(const float *X, int32_t feat_dim, int32_t feat_stride, int32_t n_rows, const int32_t *cnt,
-                     const pcg_graph_desc *g, int32_t B, void *workspace, int64_t list_capacity, float *agg,
-                     int32_t agg_stride, void *stream);
+int pcg_gather_lists(const float *X, int32_t feat_dim, int32_t feat_stride, int64_t table_rows, int32_t n_rows,
+                     const int32_t *cnt, const pcg_graph_desc *g, int32_t B, void *workspace, int64_t list_capacity, float *agg,
+                     int32_t agg_stride, uint32_t *status, void *stream);
 int pcg_choose_aggregate_planned(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B,
                                  const float *s0, const float *center_s0, const uint64_t *pos_keys,
                                  const double *thresholds, const double *rho, int32_t train_flag,

@@ -12,6 +12,7 @@ from .build import lib_path
 PCG_MAX_REL = 8
 PCG_OK, PCG_E_ARG, PCG_E_UNSUPPORTED, PCG_E_LAUNCH = 0, -1, -2, -3
 PCG_ST_SEL_OVERFLOW = 1
+PCG_ST_LIST_ID_RANGE = 2
 PCG_NORM_COUNT, PCG_NORM_SQRT_COUNT = 0, 1
 ABI_VERSION = 1
 
@@ -47,7 +48,7 @@ PROTOTYPES = {
     "pcg_choose_workspace_offset": (_I64, [_G, _I32, _I64, _I32]),
     "pcg_choose_select": (C.c_int, [_G, _P, _P, _I32, _P, _P, _P, C.POINTER(_F64), C.POINTER(_F64), _I32, _I32,
                                     _P, _P, _I64, _P, _P]),
-    "pcg_aggregate_lists": (C.c_int, [_P, _I32, _I32, _I32, _P, _G, _I32, _P, _I64, _I32, _P, _I32, _P]),
+    "pcg_aggregate_lists": (C.c_int, [_P, _I32, _I32, _I64, _I32, _P, _G, _I32, _P, _I64, _I32, _P, _I32, _P, _P]),
     "pcg_choose_aggregate": (C.c_int, [_G, _P, _P, _I32, _P, _P, _P, C.POINTER(_F64), C.POINTER(_F64), _I32, _I32,
                                        _I32, _P, _I32, _P, _P, _I64, _P, _P]),
     "pcg_step_front": (C.c_int, [_G, _P, _P, _P, _P, _P, _P, _I32, C.POINTER(_F64), C.POINTER(_F64), _I32, _I32, _P, _I64,
@@ -62,7 +63,7 @@ PROTOTYPES = {
                                                _I32, _P, _I32, _P, _P, _I64, _P, _P]),
     "pcg_choose_gather_planned": (C.c_int, [_G, _P, _P, _I32, _P, _P, _P, C.POINTER(_F64), C.POINTER(_F64), _I32, _I32,
                                             _P, _I32, _P, _P, _I64, _P, _P]),
-    "pcg_gather_lists": (C.c_int, [_P, _I32, _I32, _I32, _P, _G, _I32, _P, _I64, _P, _I32, _P]),
+    "pcg_gather_lists": (C.c_int, [_P, _I32, _I32, _I64, _I32, _P, _G, _I32, _P, _I64, _P, _I32, _P, _P]),
     "pcg_train_dense": (C.c_int, [_G, _P, _P, _P, _I32, _P, _P, _I32, _P, _I32, _P, _P, _I64, C.c_float, C.c_float, _P, _P, _P,
                                   _P, _P, _P, _P, _F64, _F64, _F64, _F64, _F64, _I32, _P]),
     "pcg_step_front_train": (C.c_int, [_G, _P, _P, _P, _I32, _P, _P, _P, _P, _I32, C.POINTER(_F64), C.POINTER(_F64), _I32, _P,

@@ -667,8 +667,8 @@ int pcg_choose_aggregate(const pcg_graph_desc *g, const int32_t *nodes, const in
     const int rc = pcg_choose_select(g, nodes, labels, B, s0, center_s0, pos_keys, thresholds, rho, train_flag,
                                      add_self, cnt, workspace, list_capacity, status, stream);
     if (rc != PCG_OK) return rc;
-    return pcg_aggregate_lists(g->X, g->feat_dim, g->feat_stride, g->n_rel * B, cnt, g, B, workspace, list_capacity,
-                               norm, agg, agg_stride, stream);
+    return pcg_aggregate_lists(g->X, g->feat_dim, g->feat_stride, g->n_nodes, g->n_rel * B, cnt, g, B, workspace, list_capacity,
+                               norm, agg, agg_stride, status, stream);
 }
 
 int pcg_choose_gather_planned(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B, const float *s0,
@@ -681,8 +681,8 @@ int pcg_choose_gather_planned(const pcg_graph_desc *g, const int32_t *nodes, con
     const int rc = pcg_choose_select_planned(g, nodes, labels, B, s0, center_s0, pos_keys, thresholds, rho, train_flag,
                                              add_self, cnt, workspace, list_capacity, status, stream);
     if (rc != PCG_OK) return rc;
-    return pcg_gather_lists(g->X, g->feat_dim, g->feat_stride, g->n_rel * B, cnt, g, B, workspace, list_capacity, agg, agg_stride,
-                            stream);
+    return pcg_gather_lists(g->X, g->feat_dim, g->feat_stride, g->n_nodes, g->n_rel * B, cnt, g, B, workspace, list_capacity, agg,
+                            agg_stride, status, stream);
 }
 
 int pcg_choose_aggregate_planned(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B,
@@ -696,8 +696,8 @@ int pcg_choose_aggregate_planned(const pcg_graph_desc *g, const int32_t *nodes, 
     const int rc = pcg_choose_select_planned(g, nodes, labels, B, s0, center_s0, pos_keys, thresholds, rho, train_flag,
                                              add_self, cnt, workspace, list_capacity, status, stream);
     if (rc != PCG_OK) return rc;
-    return pcg_aggregate_lists(g->X, g->feat_dim, g->feat_stride, g->n_rel * B, cnt, g, B, workspace, list_capacity,
-                               norm, agg, agg_stride, stream);
+    return pcg_aggregate_lists(g->X, g->feat_dim, g->feat_stride, g->n_nodes, g->n_rel * B, cnt, g, B, workspace, list_capacity,
+                               norm, agg, agg_stride, status, stream);
 }
 
 }  // extern "C"

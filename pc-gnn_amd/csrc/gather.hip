@@ -27,6 +27,8 @@ struct AggArgs {
     float *partial;
     float *agg;                 // [n_rows, agg_stride]
     int32_t agg_stride, norm;
+    int64_t table_rows;         // rows of X: a list entry outside [0, table_rows) is not gathered (a hole) and reported
+    uint32_t *status;           // device status word (PCG_ST_LIST_ID_RANGE), or null
 };
 
 struct RowGeom {  // how one wave-instruction covers feature rows
@@ -84,6 +86,7 @@ __global__ void __launch_bounds__(256) gather_chunks(const AggArgs a) {
         // coalesced load, dealt out to the row slots by cross-lane reads; the next iteration's ids are requested before
         // this iteration's rows.
         const int per_iter = q.rpw * UNROLL;
+        bool bad = false;                                              // an entry that names no row of the table
         // (negative = nothing there, or a hole left by a duplicate.  The sign bit is OR-ed in rather than the value replaced:
         //  a value that is only used under a condition gets its load sunk into a branch again)
         int my = list[lane < n ? lane : (n > 0 ? n - 1 : 0)];
@@ -97,6 +100,11 @@ __global__ void __launch_bounds__(256) gather_chunks(const AggArgs a) {
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
                 ids[u] = __shfl(my, u * q.rpw + q.slot);
+                // (an id beyond the table is turned into a hole before it can form an address; the check is two VALU ops
+                //  in front of a load that is unconditional either way)
+                const bool beyond = ids[u] >= 0 && (int64_t)ids[u] >= a.table_rows;
+                bad |= beyond;
+                ids[u] |= beyond ? (int)0x80000000 : 0;
                 const float *rowp = a.X + (size_t)(ids[u] >= 0 ? ids[u] : 0) * a.feat_stride;
 #pragma unroll
                 for (int x = 0; x < NACC; ++x) {
@@ -124,6 +132,7 @@ __global__ void __launch_bounds__(256) gather_chunks(const AggArgs a) {
                 acc[x].z += __shfl_xor(acc[x].z, o);
                 acc[x].w += __shfl_xor(acc[x].w, o);
             }
+        if (bad && a.status) atomicOr(a.status, (uint32_t)PCG_ST_LIST_ID_RANGE);
         if (lane < q.lpr) {
             if (nch_row == 1) {
                 const float den = a.norm == PCG_NORM_SQRT_COUNT ? sqrtf((float)cnt) : (float)cnt;
@@ -202,10 +211,11 @@ static int launch_aggregate(const AggArgs &g, hipStream_t st, bool combine) {
 
 extern "C" {
 
-static int aggregate(const float *X, int32_t feat_dim, int32_t feat_stride, int32_t n_rows, const int32_t *cnt,
+static int aggregate(const float *X, int32_t feat_dim, int32_t feat_stride, int64_t table_rows, int32_t n_rows, const int32_t *cnt,
                      const pcg_graph_desc *g, int32_t B, void *workspace, int64_t list_capacity, int32_t norm,
-                     float *agg, int32_t agg_stride, bool combine, void *stream) {
-    if (!X || !cnt || !g || !workspace || !agg || n_rows < 0 || B < 0) return PCG_E_ARG;
+                     float *agg, int32_t agg_stride, bool combine, uint32_t *status, void *stream) {
+    if (!X || !cnt || !g || !workspace || !agg || n_rows < 0 || B < 0 || table_rows < 1) return PCG_E_ARG;
+    if (n_rows != g->n_rel * B) return PCG_E_ARG;       // the lists are those of the plan in `workspace`: n_rel * B rows
     if (n_rows == 0) return PCG_OK;
     if (feat_stride % 4 != 0 || feat_stride < feat_dim || agg_stride < feat_dim) return PCG_E_ARG;
     if (feat_stride > 512) return PCG_E_UNSUPPORTED;
@@ -229,23 +239,26 @@ static int aggregate(const float *X, int32_t feat_dim, int32_t feat_stride, int3
     a.agg = agg;
     a.agg_stride = agg_stride;
     a.norm = norm;
+    a.table_rows = table_rows;
+    a.status = status;
     hipStream_t st = static_cast<hipStream_t>(stream);
     return feat_stride <= 256 ? pcg::launch_aggregate<1>(a, st, combine) : pcg::launch_aggregate<2>(a, st, combine);
 }
 
-int pcg_aggregate_lists(const float *X, int32_t feat_dim, int32_t feat_stride, int32_t n_rows, const int32_t *cnt,
-                        const pcg_graph_desc *g, int32_t B, void *workspace, int64_t list_capacity, int32_t norm,
-                        float *agg, int32_t agg_stride, void *stream) {
-    return aggregate(X, feat_dim, feat_stride, n_rows, cnt, g, B, workspace, list_capacity, norm, agg, agg_stride, true, stream);
+int pcg_aggregate_lists(const float *X, int32_t feat_dim, int32_t feat_stride, int64_t table_rows, int32_t n_rows,
+                        const int32_t *cnt, const pcg_graph_desc *g, int32_t B, void *workspace, int64_t list_capacity,
+                        int32_t norm, float *agg, int32_t agg_stride, uint32_t *status, void *stream) {
+    return aggregate(X, feat_dim, feat_stride, table_rows, n_rows, cnt, g, B, workspace, list_capacity, norm, agg, agg_stride, true,
+                     status, stream);
 }
 
 /* gather only: rows of one chunk are finished (mean in agg), rows of several are left as per-chunk partial sums in the
  * workspace for pcg_train_dense to add up while it stages its tile (no combine launch) */
-int pcg_gather_lists(const float *X, int32_t feat_dim, int32_t feat_stride, int32_t n_rows, const int32_t *cnt,
-                     const pcg_graph_desc *g, int32_t B, void *workspace, int64_t list_capacity, float *agg, int32_t agg_stride,
-                     void *stream) {
-    return aggregate(X, feat_dim, feat_stride, n_rows, cnt, g, B, workspace, list_capacity, PCG_NORM_COUNT, agg, agg_stride, false,
-                     stream);
+int pcg_gather_lists(const float *X, int32_t feat_dim, int32_t feat_stride, int64_t table_rows, int32_t n_rows,
+                     const int32_t *cnt, const pcg_graph_desc *g, int32_t B, void *workspace, int64_t list_capacity, float *agg,
+                     int32_t agg_stride, uint32_t *status, void *stream) {
+    return aggregate(X, feat_dim, feat_stride, table_rows, n_rows, cnt, g, B, workspace, list_capacity, PCG_NORM_COUNT, agg,
+                     agg_stride, false, status, stream);
 }
 
 }  // extern "C"

@@ -22,6 +22,11 @@ namespace pcg {
 
 constexpr uint32_t HALO_EMPTY = 0xFFFFFFFFu;
 constexpr int HALO_MAX_WORLD = 64;
+// Longest probe sequence any table operation walks.  The table has at least two slots per halo row, so a run of 128 occupied
+// slots means it is over-full (a capacity error): the insert then reports "full" (overflow bit 1) instead of walking the whole
+// table for every later neighbour - O(ids x slots) probes would look like a hang.  An id that WAS inserted sits within this many
+// probes of its hash slot (no deletions), so look-ups bounded the same way find everything that is there.
+constexpr uint32_t HALO_MAX_PROBE = 128;
 
 __device__ __forceinline__ uint32_t halo_hash(uint32_t x) {
     x ^= x >> 16;
@@ -84,7 +89,7 @@ __device__ __forceinline__ int pos_find(const int32_t *__restrict__ pos_ids, int
 // insert a remote id (first insert counts it for its owner); false: the table is full
 __device__ __forceinline__ bool halo_insert(const HaloArgs &a, const int32_t *s_bounds, int32_t id) {
     uint32_t h = halo_hash((uint32_t)id) & a.mask;
-    for (uint32_t probe = 0; probe <= a.mask; ++probe) {
+    for (uint32_t probe = 0; probe <= a.mask && probe < HALO_MAX_PROBE; ++probe) {
         const uint32_t seen = __hip_atomic_load(&a.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (seen == (uint32_t)id) return true;
         if (seen == HALO_EMPTY) {
@@ -104,7 +109,7 @@ __device__ __forceinline__ bool halo_insert(const HaloArgs &a, const int32_t *s_
 // which copes with duplicates)
 __device__ __forceinline__ bool halo_has(const HaloArgs &a, uint32_t id) {
     uint32_t h = halo_hash(id) & a.mask;
-    for (uint32_t probe = 0; probe <= a.mask; ++probe) {
+    for (uint32_t probe = 0; probe <= a.mask && probe < HALO_MAX_PROBE; ++probe) {
         const uint32_t key = __hip_atomic_load(&a.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (key == id) return true;
         if (key == HALO_EMPTY) return false;
@@ -116,7 +121,7 @@ __device__ __forceinline__ bool halo_has(const HaloArgs &a, uint32_t id) {
 // slot of a remote id, or HALO_EMPTY
 __device__ __forceinline__ uint32_t halo_find(const HaloArgs &a, uint32_t id) {
     uint32_t h = halo_hash(id) & a.mask;
-    for (uint32_t probe = 0; probe <= a.mask; ++probe) {
+    for (uint32_t probe = 0; probe <= a.mask && probe < HALO_MAX_PROBE; ++probe) {
         const uint32_t key = a.keys[h];
         if (key == id) return a.vals[h];
         if (key == HALO_EMPTY) break;
@@ -186,6 +191,8 @@ __global__ void __launch_bounds__(256) halo_collect_kernel(const HaloArgs a) {
     const int64_t rows = (int64_t)a.n_centres * a.n_rel;
     bool full = false;
     for (int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); row < rows; row += nwaves) {
+        // the table has been reported full (by this wave or any other): the window is lost anyway, stop walking
+        if (full || (__hip_atomic_load(a.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u)) break;
         const int r = (int)(row / a.n_centres);
         const int32_t c = a.centres[row - (int64_t)r * a.n_centres];
         if (c < 0 || c >= a.n_local) continue;               // (not a row this rank owns: nothing to walk)
@@ -210,9 +217,13 @@ __global__ void __launch_bounds__(256) halo_collect_kernel(const HaloArgs a) {
                 if (pos_find(a.pos_ids, a.n_pos, id) >= 0) continue;
                 full |= !halo_insert(a, s_bounds, id);
             }
+            full = __any(full);                              // (wave-uniform from here on)
+            if (full) {
+                if (lane == 0) atomicOr(a.overflow, 1u);
+                break;
+            }
         }
     }
-    if (full) atomicOr(a.overflow, 1u);
 }
 
 // per step: list entries (global ids) -> rows of the extended table; a remote id the window did not collect (or

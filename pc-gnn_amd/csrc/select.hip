@@ -739,7 +739,8 @@ __device__ __forceinline__ void select_wg_row(const ChooseArgs &a, int row, uint
     // A row with nothing to do after the selection (no minority picks, no self union) writes its kept ids straight into its
     // list region and reports itself: no LDS staging, no copy.
     const bool plain = p.m == 0 && !a.add_self;                              // (the same for every thread)
-    const bool sel_in_lds = (LDSK || k <= WG_KEYCAP) && !plain;
+    // (a keep-all row keeps d ids, not k: what must fit is the kept count)
+    const bool sel_in_lds = (LDSK || (keep_all ? d : k) <= WG_KEYCAP) && !plain;
     uint32_t *selbuf = sel_in_lds ? keys : reinterpret_cast<uint32_t *>(out);
     if constexpr (LDSK) {
         // pass A: which positions stay (a bit per iteration in a register; seg <= 1280 -> <= 20 iterations), pass B: their

@@ -478,8 +478,8 @@ class DistributedPCGNN:
         st = ops._stream(self.dev)
         check, c = self._libmod.check, self.cfg
         agg = self.agg.view(-1)[:g.R * B * self.F].view(g.R, B, self.F)
-        check(lib.pcg_gather_lists(_p(g.X), g.feat_dim, g.X.stride(0), g.X.shape[0], _p(self.cnt), g.desc_ref(), B, _p(ws.buf),
-                                   ws.list_capacity, _p(agg), agg.stride(1), st), "pcg_gather_lists")
+        check(lib.pcg_gather_lists(_p(g.X), g.feat_dim, g.X.stride(0), g.X.shape[0], g.R * B, _p(self.cnt), g.desc_ref(), B, _p(ws.buf),
+                                   ws.list_capacity, _p(agg), agg.stride(1), _p(ws.status), st), "pcg_gather_lists")
         check(lib.pcg_train_dense(g.desc_ref(), _p(self.theta), None, None, self.E, _p(ids_local), _p(labels), B, _p(agg),
                                   agg.stride(1), _p(self.cnt), _p(ws.buf), ws.list_capacity, float(c["alpha"]),
                                   1.0 / (B * self.world), _p(self.logits), _p(self.center), None, _p(self.row_loss),
@@ -591,7 +591,11 @@ class DistributedPCGNN:
         """COLLECTIVE.  Raise - on every rank, or on none - if any rank's exchange or selection list went over capacity, or a
         step met an id outside its window, since the last check (those steps worked on lists with holes).  One small
         all-reduce and one host read: call it per epoch, not per step."""
-        flags = torch.stack([self.halo.overflow_word[0], self.status[0]]).to(torch.int64)
+        # the two words are bit fields: every bit travels as a 0/1 entry of its own, so that MAX over the ranks is a bitwise OR
+        # (rank A's pitch overflow and rank B's id-outside-window would otherwise collapse into the larger number; NCCL has no BOR)
+        words = torch.stack([self.halo.overflow_word[0], self.status[0]]).to(torch.int64)
+        bits = torch.arange(16, device=words.device, dtype=torch.int64)
+        flags = (words[:, None] >> bits[None, :]) & 1
         if self.world > 1:
             if self.stage_host:
                 c = flags.cpu()
@@ -599,6 +603,7 @@ class DistributedPCGNN:
                 flags = c
             else:
                 dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)
+        flags = (flags.to(bits.device) << bits[None, :]).sum(1)
         halo, lists = (int(x) for x in flags.cpu().tolist())
         self.halo.overflow_word.zero_()
         self.status.zero_()

@@ -49,7 +49,7 @@ class PCGNNTrainer:
         else:
             from .fused import FusedPCGNN
             self.fused = FusedPCGNN(self.model, cfg["lr"], cfg["weight_decay"], max_batch=cfg["batch_size"],
-                                    global_batch_scale=cfg.get("world_size", 1))
+                                    global_batch_scale=cfg.get("world_size", 1), list_capacity=cfg.get("list_capacity"))
         self.labels_dev = torch.from_numpy(w.labels).to(self.device)
         self.labels_i32 = self.labels_dev.to(torch.int32)
         self.sampler = PickSampler(w.idx_train, w.labels[w.idx_train], w.homo_deg[w.idx_train], self.device,

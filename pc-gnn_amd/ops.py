@@ -150,8 +150,8 @@ def aggregate_lists(g: DeviceGraph, X: torch.Tensor, B: int, ws: ChooseWorkspace
                     norm: int = _lib.PCG_NORM_COUNT):
     """gather + mean of the lists ws holds, from feature table X [*, feat_stride] (g.X or an extended table)."""
     lib = _lib.load()
-    _lib.check(lib.pcg_aggregate_lists(_p(X), g.feat_dim, X.stride(0), g.R * B, _p(cnt), g.desc_ref(), B, _p(ws.buf),
-                                       ws.list_capacity, norm, _p(agg), agg.stride(-2), _stream(g.device)),
+    _lib.check(lib.pcg_aggregate_lists(_p(X), g.feat_dim, X.stride(0), X.shape[0], g.R * B, _p(cnt), g.desc_ref(), B, _p(ws.buf),
+                                       ws.list_capacity, norm, _p(agg), agg.stride(-2), _p(ws.status), _stream(g.device)),
                "pcg_aggregate_lists")
 
 

@@ -156,15 +156,24 @@ def test_interagg_arities_and_state_dict_of_the_five_relation_model():
         P.InterAgg1(feats, f, e, [1], adj[:3], intra[:3], cuda=False)
 
 
-def test_bench_refuses_multi_gpu_without_launcher():
-    """`bench.py --gpus N` must come from one process per GPU (torch.distributed.run sets WORLD_SIZE): run alone it exits
-    non-zero before any GPU call instead of silently measuring one GPU; and algorithmic_bytes follows SURVEY 8(d)'s terms."""
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` outside a launcher starts N ranks itself (torch.distributed.run, before any GPU call) and
+    hands back their exit status; PCG_BENCH_DRY=1 stops every rank after the process group is up (no GPU here).  A launcher
+    whose process count disagrees with --gpus is an error; and algorithmic_bytes follows SURVEY 8(d)'s terms."""
+    import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env,
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["PCG_BENCH_DRY"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"dry_run": True, "n_gpus": 2, "ranks_seen": 2}
+    env2 = dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env2,
                        timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
     sys.path.insert(0, root)
