@@ -472,7 +472,9 @@ def main():
             # the first epoch of a phase (warm-up, measurement) and every event_every-th after it are event-bracketed
             timed_epoch = engine != "graph" or (phase["epochs"] - 1) % args.event_every == 0
             if epoch_graphs and at_epoch_start and not timed_epoch and k + nb <= n_steps:
-                tr.run_epoch_one_graph()             # pick + shuffle + labels + every batch's step: one graph launch
+                tr.run_epoch_one_graph(flush=False)  # pick + shuffle + labels + plans + every batch's step: one graph launch (the
+                                                     # last batch's deferred Adam update is applied by the next front launch, or
+                                                     # by the flush that ends the timed region)
                 state["ids"], state["b"] = tr.fused._ep_ids[:tr.pick_size], nb
                 state["epoch"] += 1
                 if measure:
@@ -504,6 +506,8 @@ def main():
     barrier()
     t0 = time.perf_counter()
     run_steps(args.steps, True)
+    if tr.fused is not None:
+        tr.fused.flush()                               # every step's update is applied inside the timed region
     barrier()
     elapsed = time.perf_counter() - t0
     events, prof._prof = prof._prof, None

@@ -48,7 +48,8 @@ enum {
 /* bits of the device-side status word */
 enum {
     PCG_ST_SEL_OVERFLOW = 1,  /* sel_indices capacity too small; nothing was written past it */
-    PCG_ST_LIST_ID_RANGE = 2  /* a selection-list entry named no row of the table handed to the gather; it was skipped (a hole) */
+    PCG_ST_LIST_ID_RANGE = 2, /* a selection-list entry named no row of the table handed to the gather; it was skipped (a hole) */
+    PCG_ST_SYNC_TIMEOUT = 4   /* a bounded in-kernel wait (the select kernel's wait for its own train-pos sort) ran out */
 };
 
 enum { PCG_NORM_COUNT = 0, PCG_NORM_SQRT_COUNT = 1 };
@@ -129,8 +130,16 @@ int pcg_pos_sort(const pcg_graph_desc *g, const float *s0, uint64_t *keys, void 
  *           PCG_ST_SEL_OVERFLOW is OR-ed into *status (uint32 device word; zero it yourself).
  *   pcg_choose_workspace_offset(..., which): byte offset inside the workspace of
  *           0 row_begin int64 [rows+1] | 1 len int32 [rows] | 2 list int32 [list_capacity]
- *           (3 chunk_begin, 4 chunk descriptors, 5 counters, 6 partial: internal, exposed for tests). */
+ *           (3 chunk_begin, 4 chunk descriptors, 5 counters, 6 partial: internal, exposed for tests).
+ *
+ * The workspace has two parts: the PLAN part (what the plan works out for one batch: row records, list / chunk offsets, tier
+ * queues, the gather's chunk table - a function of the batch's ids, labels and CSR degrees only) and the DATA part (what a
+ * step writes: selection list, per-chunk partial sums, key scratch).  pcg_choose_workspace_bytes = both, the plan part first
+ * (the single-buffer layout every entry point without a `plan` argument uses).  pcg_choose_plan_bytes / _data_bytes: the
+ * parts on their own, for callers that keep one plan part per batch of an epoch (pcg_plan_batches) and ONE data part. */
 int64_t pcg_choose_workspace_bytes(const pcg_graph_desc *g, int32_t B, int64_t list_capacity);
+int64_t pcg_choose_plan_bytes(const pcg_graph_desc *g, int32_t B, int64_t list_capacity);
+int64_t pcg_choose_data_bytes(const pcg_graph_desc *g, int32_t B, int64_t list_capacity);
 int64_t pcg_choose_workspace_offset(const pcg_graph_desc *g, int32_t B, int64_t list_capacity, int32_t which);
 int pcg_choose_select(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B,
                       const float *s0, const float *center_s0, const uint64_t *pos_keys,
@@ -182,19 +191,45 @@ int pcg_step_front_b(const pcg_graph_desc *g, const float *s0, uint64_t *pos_key
                      const int32_t *nodes, const int32_t *labels, int32_t B, const double *thresholds,
                      const double *rho, int32_t train_flag, int32_t add_self, void *workspace, int64_t list_capacity,
                      uint32_t *status, float *center_s0_out, int64_t center_id_offset, void *stream);
+/* `plan` (here and below): NULL = the plan part lies inside `workspace` (pcg_step_front / _a + _b made it); else `workspace`
+ * is a DATA part (pcg_choose_data_bytes) and `plan` the batch's plan part (a slot pcg_plan_batches filled). */
 int pcg_choose_select_planned(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B,
                               const float *s0, const float *center_s0, const uint64_t *pos_keys,
                               const double *thresholds, const double *rho, int32_t train_flag, int32_t add_self,
-                              int32_t *cnt, void *workspace, int64_t list_capacity, uint32_t *status, void *stream);
+                              int32_t *cnt, void *workspace, const void *plan, int64_t list_capacity, uint32_t *status,
+                              void *stream);
+/* The plans of ALL batches of an epoch in one launch - off every step's critical path (a plan depends on the picked ids, their
+ * labels and the CSR degrees, never on a parameter; the reference does this bookkeeping per batch, src/layers.py:217-219,
+ * 246-262).  Batch s = nodes[s * B, min((s + 1) * B, n_total)) (the last one may be shorter) is planned into
+ * plans + s * plan_stride (plan_stride >= pcg_choose_plan_bytes(g, B, list_capacity), a multiple of 256); thresholds .. add_self
+ * and list_capacity as the *_planned calls that follow will be given.  An overflowing batch sets PCG_ST_SEL_OVERFLOW and
+ * selects nothing.  bump_counter (may be NULL): a device uint64 incremented by the launch (the sampler's epoch number -
+ * pcg_pick_shuffled with bump = 0 in front of it). */
+int pcg_plan_batches(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t n_total, int32_t B,
+                     const double *thresholds, const double *rho, int32_t train_flag, int32_t add_self, void *plans,
+                     int64_t plan_stride, int64_t list_capacity, uint32_t *status, uint64_t *bump_counter, void *stream);
 /* select + gather WITHOUT the combine launch (two launches): rows whose list fits one 128-entry gather chunk are finished
  * (their mean is in agg), longer rows are left as per-chunk partial sums in the workspace; pcg_train_dense, given the same
  * workspace and cnt, adds them up in chunk order (bit-identical to pcg_choose_aggregate_planned's agg) while it stages its
- * tile.  pcg_gather_lists is the gather half on its own (norm = PCG_NORM_COUNT). */
+ * tile.  pcg_gather_lists is the gather half on its own (norm = PCG_NORM_COUNT), pcg_gather_lists_planned the same with the
+ * plan part outside the workspace.
+ * sync_words != NULL (the four words of pcg_train_dense / pcg_step_scores_train): pos_keys' scratch half holds the UNSORTED
+ * train-pos keys of this step (pcg_step_scores_train) and - if pcg_pos_sort_in_select(n_pos) - the select kernel sorts them
+ * itself, the work shared by its workgroups before they start on the rows (ranks accumulated in the words behind sync_words[3],
+ * key groups counted in sync_words[3] - zero on entry; pcg_step_scores_train zeroes it); only a row with minority picks waits
+ * for that count (a bounded wait: PCG_ST_SYNC_TIMEOUT if it ever ran out).  The launch also clears sync_words[1].  Results are bit-identical
+ * to sorting first (pcg_pos_sort) and passing sync_words = NULL. */
 int pcg_choose_gather_planned(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B,
                               const float *s0, const float *center_s0, const uint64_t *pos_keys,
                               const double *thresholds, const double *rho, int32_t train_flag, int32_t add_self,
-                              float *agg, int32_t agg_stride, int32_t *cnt, void *workspace, int64_t list_capacity,
-                              uint32_t *status, void *stream);
+                              float *agg, int32_t agg_stride, int32_t *cnt, void *workspace, const void *plan,
+                              int64_t list_capacity, uint32_t *status, uint32_t *sync_words, void *stream);
+int32_t pcg_pos_sort_in_select(int32_t n_pos);      /* 1: 0 < n_pos <= 16384 (host helper) */
+int32_t pcg_sync_words_count(void);                 /* uint32 words of a `sync_words` buffer (zero-initialised ONCE by the caller; the
+                                                        kernels leave every word but [1], [2] zero between launches) */
+int pcg_gather_lists_planned(const float *X, int32_t feat_dim, int32_t feat_stride, int64_t table_rows, int32_t n_rows,
+                             const int32_t *cnt, const pcg_graph_desc *g, int32_t B, void *workspace, const void *plan,
+                             int64_t list_capacity, float *agg, int32_t agg_stride, uint32_t *status, void *stream);
 int pcg_gather_lists(const float *X, int32_t feat_dim, int32_t feat_stride, int64_t table_rows, int32_t n_rows,
                      const int32_t *cnt, const pcg_graph_desc *g, int32_t B, void *workspace, int64_t list_capacity, float *agg,
                      int32_t agg_stride, uint32_t *status, void *stream);
@@ -278,20 +313,28 @@ int pcg_adam_step(float *theta, float *m, float *v, const float *slabs, int32_t 
 /* The training step's tail and front with Adam taken off the critical path (src/model_handler.py:149-153).
  *
  * pcg_train_dense = pcg_dense_step, plus
- *   - workspace != NULL (with cnt, list_capacity as given to pcg_choose_gather_planned): aggregates of rows the gather left
- *     as partial sums are added up here (no combine launch);
+ *   - workspace != NULL (with cnt, plan, list_capacity as given to pcg_choose_gather_planned): aggregates of rows the gather
+ *     left as partial sums are added up here (no combine launch);
  *   - adam_clf != 0 (training: slabs, m, v, sync_words required): the workgroup that arrives last (device-scope ticket,
  *     write-through partial gradients) sums the label classifier's gradient over the tiles in tile order and applies
  *     Adam to those 2 * feat_dim + 2 parameters - the only ones the next step's score pass reads - and the launch marks the
  *     slabs as holding a gradient the OTHER parameters have not seen yet: sync_words[1] = 1, sync_words[2] = #slabs.
- *   sync_words: FOUR zero-initialised uint32 device words owned by the caller ([0] arrival ticket, 0 between launches).
+ *   sync_words: pcg_sync_words_count() zero-initialised uint32 device words owned by the caller ([0] arrival ticket, 0 between
+ *     launches; [3] and the words behind it belong to pcg_choose_gather_planned's in-kernel sort).
  * pcg_step_front_train = pcg_step_front(train_flag = 1) reading the label classifier from theta, with that deferred update
  *   (parameters [0, offset of label_clf.weight), same arithmetic and summation order as pcg_adam_step) applied by extra
  *   workgroups beside the score pass when sync_words[1] is set; its second launch clears sync_words[1].
+ * pcg_step_scores_train = the front of a training step whose plan exists already (pcg_plan_batches), ONE launch:
+ *   [train-pos keys from their feature rows -> pos_keys' scratch half || that deferred update || score pass -> s0]; it zeroes
+ *   sync_words[3]; the sort is left to pcg_choose_gather_planned(..., sync_words) (n_pos > 16384: the bucket sort's launches
+ *   follow here instead and pos_keys is sorted on return).  Replaces src/layers.py:230-237.
  * pcg_adam_flush applies a still-deferred update now (two small launches) - before parameters are read or saved. */
+int pcg_step_scores_train(const pcg_graph_desc *g, float *theta, float *m, float *v, int32_t emb, float *s0,
+                          uint64_t *pos_keys, const float *slabs, const int32_t *step_counter, uint32_t *sync_words,
+                          double lr, double beta1, double beta2, double eps, double weight_decay, void *stream);
 int pcg_train_dense(const pcg_graph_desc *g, float *theta, float *m, float *v, int32_t emb, const int32_t *ids,
                     const int32_t *labels, int32_t B, const float *agg, int32_t agg_stride, const int32_t *cnt,
-                    const void *workspace, int64_t list_capacity, float lambda_1, float inv_count, float *logits,
+                    const void *workspace, const void *plan, int64_t list_capacity, float lambda_1, float inv_count, float *logits,
                     float *center, float *combined, float *row_loss, float *slabs, int32_t *step_counter,
                     uint32_t *sync_words, double lr, double beta1, double beta2, double eps, double weight_decay,
                     int32_t adam_clf, void *stream);

@@ -13,8 +13,9 @@ PCG_MAX_REL = 8
 PCG_OK, PCG_E_ARG, PCG_E_UNSUPPORTED, PCG_E_LAUNCH = 0, -1, -2, -3
 PCG_ST_SEL_OVERFLOW = 1
 PCG_ST_LIST_ID_RANGE = 2
+PCG_ST_SYNC_TIMEOUT = 4
 PCG_NORM_COUNT, PCG_NORM_SQRT_COUNT = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class GraphDesc(C.Structure):
@@ -58,13 +59,21 @@ PROTOTYPES = {
     "pcg_step_front_b": (C.c_int, [_G, _P, _P, _I32, _P, _P, _I32, C.POINTER(_F64), C.POINTER(_F64), _I32, _I32, _P, _I64, _P,
                                    _P, _I64, _P]),
     "pcg_choose_select_planned": (C.c_int, [_G, _P, _P, _I32, _P, _P, _P, C.POINTER(_F64), C.POINTER(_F64), _I32, _I32,
-                                            _P, _P, _I64, _P, _P]),
+                                            _P, _P, _P, _I64, _P, _P]),
+    "pcg_choose_plan_bytes": (_I64, [_G, _I32, _I64]),
+    "pcg_choose_data_bytes": (_I64, [_G, _I32, _I64]),
+    "pcg_plan_batches": (C.c_int, [_G, _P, _P, _I32, _I32, C.POINTER(_F64), C.POINTER(_F64), _I32, _I32, _P, _I64, _I64, _P, _P,
+                                   _P]),
+    "pcg_pos_sort_in_select": (_I32, [_I32]),
+    "pcg_sync_words_count": (_I32, []),
+    "pcg_gather_lists_planned": (C.c_int, [_P, _I32, _I32, _I64, _I32, _P, _G, _I32, _P, _P, _I64, _P, _I32, _P, _P]),
+    "pcg_step_scores_train": (C.c_int, [_G, _P, _P, _P, _I32, _P, _P, _P, _P, _P, _F64, _F64, _F64, _F64, _F64, _P]),
     "pcg_choose_aggregate_planned": (C.c_int, [_G, _P, _P, _I32, _P, _P, _P, C.POINTER(_F64), C.POINTER(_F64), _I32, _I32,
                                                _I32, _P, _I32, _P, _P, _I64, _P, _P]),
     "pcg_choose_gather_planned": (C.c_int, [_G, _P, _P, _I32, _P, _P, _P, C.POINTER(_F64), C.POINTER(_F64), _I32, _I32,
-                                            _P, _I32, _P, _P, _I64, _P, _P]),
+                                            _P, _I32, _P, _P, _P, _I64, _P, _P, _P]),
     "pcg_gather_lists": (C.c_int, [_P, _I32, _I32, _I64, _I32, _P, _G, _I32, _P, _I64, _P, _I32, _P, _P]),
-    "pcg_train_dense": (C.c_int, [_G, _P, _P, _P, _I32, _P, _P, _I32, _P, _I32, _P, _P, _I64, C.c_float, C.c_float, _P, _P, _P,
+    "pcg_train_dense": (C.c_int, [_G, _P, _P, _P, _I32, _P, _P, _I32, _P, _I32, _P, _P, _P, _I64, C.c_float, C.c_float, _P, _P, _P,
                                   _P, _P, _P, _P, _F64, _F64, _F64, _F64, _F64, _I32, _P]),
     "pcg_step_front_train": (C.c_int, [_G, _P, _P, _P, _I32, _P, _P, _P, _P, _I32, C.POINTER(_F64), C.POINTER(_F64), _I32, _P,
                                        _I64, _P, _P, _P, _P, _F64, _F64, _F64, _F64, _F64, _P]),

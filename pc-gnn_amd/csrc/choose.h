@@ -55,7 +55,15 @@ struct Workspace {
 
 static inline int64_t align256(int64_t x) { return (x + 255) / 256 * 256; }
 
-static inline int64_t carve(const pcg_graph_desc *g, int32_t B, int64_t list_capacity, unsigned char *base, Workspace *w) {
+// The workspace is two parts.  PLAN part: what the plan writes for one batch (counters, row records, offsets, tier queues, the
+// gather's chunk table) - it depends only on the batch's ids / labels and the CSR degrees, so an epoch's batches are planned
+// together, one plan part ("slot") each.  DATA part: what a step writes (selection list, per-chunk partial sums, key scratch) -
+// one per engine, shared by every slot.  A legacy single-buffer workspace is [plan | data] (carve1).
+struct CarveSizes {
+    int64_t plan_bytes, data_bytes;
+};
+static inline CarveSizes carve(const pcg_graph_desc *g, int32_t B, int64_t list_capacity, unsigned char *plan_base,
+                               unsigned char *data_base, Workspace *w) {
     const int64_t rows = (int64_t)g->n_rel * B;
     const int64_t chunk_cap = list_capacity / CHUNK + rows + 1;
     // key scratch: only graphs with rows beyond the LDS key capacity need it; max_degree entries for each workgroup of
@@ -67,6 +75,7 @@ static inline int64_t carve(const pcg_graph_desc *g, int32_t B, int64_t list_cap
         scratch_cap = nb * (int64_t)g->max_degree;
     }
     int64_t off = 0;
+    unsigned char *base = plan_base;
     auto take = [&](int64_t bytes) {
         const int64_t o = off;
         off += align256(bytes);
@@ -86,16 +95,39 @@ static inline int64_t carve(const pcg_graph_desc *g, int32_t B, int64_t list_cap
     p = take(32 * rows);                           if (w) w->recs = reinterpret_cast<RowRec *>(p);
     p = take(64 * (rows / 256 + 2));               if (w) w->plan_totals = p;   // PlanTotals (<= 64 B) per 256 rows
     p = take(16 * chunk_cap);                      if (w) w->chunk_desc = reinterpret_cast<int4 *>(p);
+    CarveSizes sz;
+    sz.plan_bytes = off;
+    off = 0;
+    base = data_base;
     p = take(4 * chunk_cap * g->feat_stride);      if (w) w->partial = reinterpret_cast<float *>(p);
     p = take(4 * rows);                            if (w) w->row_ticket = reinterpret_cast<uint32_t *>(p);
     p = take(4 * list_capacity);                   if (w) w->list = reinterpret_cast<int32_t *>(p);
     p = take(4 * scratch_cap);                     if (w) w->key_scratch = reinterpret_cast<uint32_t *>(p);
+    sz.data_bytes = off;
     if (w) {
         w->list_capacity = list_capacity;
         w->chunk_cap = chunk_cap;
         w->scratch_cap = scratch_cap;
     }
-    return off;
+    return sz;
+}
+// plan == null: the single-buffer layout [plan | data] at `workspace`; else the plan part at `plan`, the data part at `workspace`
+static inline int64_t carve1(const pcg_graph_desc *g, int32_t B, int64_t list_capacity, unsigned char *workspace, Workspace *w,
+                             unsigned char *plan = nullptr) {
+    const CarveSizes sz = carve(g, B, list_capacity, nullptr, nullptr, nullptr);
+    if (plan) carve(g, B, list_capacity, plan, workspace, w);
+    else carve(g, B, list_capacity, workspace, workspace ? workspace + sz.plan_bytes : nullptr, w);
+    return sz.plan_bytes + sz.data_bytes;
+}
+// move the plan part of a carved workspace by `bytes` (slot s of an epoch's plans lies s * stride behind slot 0)
+template <typename T>
+__host__ __device__ __forceinline__ void shift_ptr(T *&ptr, int64_t bytes) {
+    ptr = reinterpret_cast<T *>(reinterpret_cast<unsigned char *>(ptr) + bytes);
+}
+__host__ __device__ __forceinline__ void shift_plan(Workspace &w, int64_t bytes) {
+    shift_ptr(w.counters, bytes); shift_ptr(w.heads, bytes); shift_ptr(w.row_begin, bytes); shift_ptr(w.chunk_begin, bytes);
+    shift_ptr(w.len, bytes); shift_ptr(w.q0, bytes); shift_ptr(w.q1, bytes); shift_ptr(w.q4, bytes); shift_ptr(w.q16, bytes);
+    shift_ptr(w.qa, bytes); shift_ptr(w.recs, bytes); shift_ptr(w.plan_totals, bytes); shift_ptr(w.chunk_desc, bytes);
 }
 
 struct ChooseArgs {
@@ -106,6 +138,16 @@ struct ChooseArgs {
     const float *s0;
     const float *center_s0;
     const uint64_t *pos_keys;
+    // in-kernel sort of the train positives (select_rows; null / 0 = pos_keys is sorted already): the keys come in groups of 64
+    // (n_sort groups); group g's ranks are worked out by sort_slices workgroups, each against its share of all the keys, added
+    // up in rank_acc; the group's last workgroup (group_ticket) stores the group's keys at their ranks in sort_out (= pos_keys,
+    // sort_cap entries) and counts the group in sort_done (zero at launch); a row with minority picks waits for
+    // sort_done == n_sort.  rank_acc [n_sort * 64] and group_ticket [n_sort]: zero at launch, left zero.
+    const uint64_t *raw_keys;
+    uint64_t *sort_out;
+    uint32_t *sort_done, *rank_acc, *group_ticket;
+    int32_t n_sort, sort_cap, sort_slices, sort_slice_len;
+    uint32_t *pending_clear;   // device word the select kernel zeroes ("the deferred Adam update has been applied"), or null
     double thr[PCG_MAX_REL];
     double rho[PCG_MAX_REL];
     int32_t train_flag, add_self;

@@ -15,9 +15,10 @@
 
 namespace pcg {
 
-__device__ __forceinline__ RowRec row_plan(const ChooseArgs &a, int row) {
+__device__ __forceinline__ RowRec row_plan(const ChooseArgs &a, int row, int64_t node_off = 0) {
     RowRec p;
-    const int r = row / a.B, b = row - r * a.B;
+    const int r = row / a.B;
+    const int64_t b = node_off + (row - r * a.B);
     p.node = a.nodes[b];
     p.start = a.g.indptr[r][p.node];
     p.d = (int)(a.g.indptr[r][p.node + 1] - p.start);
@@ -140,7 +141,8 @@ __device__ __forceinline__ void write_chunk_desc(const Workspace &w, int row, in
         w.chunk_desc[o_chunk + j] = make_int4(row, (int)o_cap + j * CHUNK, cap - j * CHUNK < CHUNK ? cap - j * CHUNK : CHUNK, nch);
 }
 
-__global__ void __launch_bounds__(PLAN_THREADS) plan_kernel(const ChooseArgs a) {
+// the whole plan of one batch by ONE workgroup of PLAN_THREADS threads (tiles of PLAN_THREADS * PLAN_PER rows)
+__device__ __forceinline__ void plan_block_body(const ChooseArgs &a) {
     __shared__ int lds[PLAN_THREADS / PCG_WAVE];
     __shared__ long long lds64[PLAN_THREADS / PCG_WAVE];
     // per-relation constants in LDS: a per-lane relation index then costs one ds_read instead of a
@@ -252,7 +254,10 @@ __global__ void __launch_bounds__(PLAN_THREADS) plan_kernel(const ChooseArgs a) 
         a.w.counters[C_NCHUNK] = overflow ? 0 : run_chunk;
         if (overflow && a.status) atomicOr(a.status, (uint32_t)PCG_ST_SEL_OVERFLOW);
     }
+#undef PLAN_STAMP
 }
+
+__global__ void __launch_bounds__(PLAN_THREADS) plan_kernel(const ChooseArgs a) { plan_block_body(a); }
 
 // Large batches (rows > PLAN_THREADS * PLAN_PER): the same plan in two launches of many workgroups.
 //   plan_count : every block works out the records of its rows and their totals
@@ -266,15 +271,17 @@ struct PlanTotals {
 static_assert(sizeof(PlanTotals) <= 64, "the workspace carve reserves 64 bytes per plan block");
 
 // pass 1, workgroup `block` of THREADS threads, one row per thread
+// (w: the workspace the plan goes to - a.w, or a plan slot behind it; node_off: where the batch starts in a.nodes / a.labels)
 template <int THREADS>
-__device__ __forceinline__ void plan_count_body(const ChooseArgs &a, PlanTotals *totals, int block) {
+__device__ __forceinline__ void plan_count_body(const ChooseArgs &a, const Workspace &w, PlanTotals *totals, int block,
+                                                int64_t node_off = 0) {
     __shared__ int4 lds4[THREADS / PCG_WAVE];
     const int rows = a.g.n_rel * a.B;
     const int row = block * THREADS + (int)threadIdx.x;
     int cap = 0, tier = -1;
     if (row < rows) {
-        const RowRec p = row_plan(a, row);
-        a.w.recs[row] = p;
+        const RowRec p = row_plan(a, row, node_off);
+        w.recs[row] = p;
         cap = rec_cap(p, a.add_self);
         tier = row_tier(p.d, p.m > 0 || a.add_self);
     }
@@ -293,7 +300,8 @@ __device__ __forceinline__ void plan_count_body(const ChooseArgs &a, PlanTotals 
 // pass 2, workgroup `block` of THREADS threads (one row per thread); pass 1 ran n_count_blocks workgroups of
 // COUNT_THREADS rows each (THREADS is a multiple of COUNT_THREADS)
 template <int THREADS, int COUNT_THREADS>
-__device__ __forceinline__ void plan_write_body(const ChooseArgs &a, const PlanTotals *totals, int block, int n_count_blocks) {
+__device__ __forceinline__ void plan_write_body(const ChooseArgs &a, const Workspace &w, const PlanTotals *totals, int block,
+                                                int n_count_blocks) {
     __shared__ int4 lds4[THREADS / PCG_WAVE];
     const int rows = a.g.n_rel * a.B;
     long long run_cap = 0, all_cap = 0;
@@ -307,7 +315,7 @@ __device__ __forceinline__ void plan_write_body(const ChooseArgs &a, const PlanT
     // this thread's row record is requested first (unconditionally, index clamped): its latency hides behind the totals
     const int rows_ = a.g.n_rel * a.B;
     const int row_ = block * THREADS + (int)threadIdx.x;
-    const RowRec rec_early = a.w.recs[row_ < rows_ ? row_ : rows_ - 1];
+    const RowRec rec_early = w.recs[row_ < rows_ ? row_ : rows_ - 1];
     if (threadIdx.x < PCG_WAVE) {
         long long v[2][7] = {{0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0}};
         for (int bk = (int)threadIdx.x; bk < n_count_blocks; bk += PCG_WAVE) {
@@ -333,7 +341,7 @@ __device__ __forceinline__ void plan_write_body(const ChooseArgs &a, const PlanT
     run = {(int)s_sum[0][2], (int)s_sum[0][3], (int)s_sum[0][4], (int)s_sum[0][5], (int)s_sum[0][6]};
     all_cap = s_sum[1][0]; all_chunk = (int)s_sum[1][1];
     all = {(int)s_sum[1][2], (int)s_sum[1][3], (int)s_sum[1][4], (int)s_sum[1][5], (int)s_sum[1][6]};
-    const bool overflow = all_cap > a.w.list_capacity || (long long)all_chunk > a.w.chunk_cap;
+    const bool overflow = all_cap > w.list_capacity || (long long)all_chunk > w.chunk_cap;
     const int row = block * THREADS + (int)threadIdx.x;
     const RowRec rec = rec_early;
     const int cap = row < rows ? rec_cap(rec, a.add_self) : 0;
@@ -346,29 +354,63 @@ __device__ __forceinline__ void plan_write_body(const ChooseArgs &a, const PlanT
     TierCounts o = pre.t;
     tier_add(o, run);
     if (row < rows) {
-        a.w.row_begin[row] = o_cap;
-        a.w.chunk_begin[row] = o_chunk;
-        a.w.recs[row].lbeg = (int)o_cap;
-        a.w.recs[row].chunk0 = o_chunk;
+        w.row_begin[row] = o_cap;
+        w.chunk_begin[row] = o_chunk;
+        w.recs[row].lbeg = (int)o_cap;
+        w.recs[row].chunk0 = o_chunk;
         if (!overflow) {
-            write_chunk_desc(a.w, row, o_chunk, o_cap, cap);
-            tier_push(a.w, tier, row, o);
+            write_chunk_desc(w, row, o_chunk, o_cap, cap);
+            tier_push(w, tier, row, o);
         }
     }
     if (block == 0 && threadIdx.x == 0) {
-        a.w.row_begin[rows] = all_cap;
-        a.w.chunk_begin[rows] = all_chunk;
-        tier_finish(a.w, all, overflow);
-        a.w.counters[C_NCHUNK] = overflow ? 0 : all_chunk;
+        w.row_begin[rows] = all_cap;
+        w.chunk_begin[rows] = all_chunk;
+        tier_finish(w, all, overflow);
+        w.counters[C_NCHUNK] = overflow ? 0 : all_chunk;
         if (overflow && a.status) atomicOr(a.status, (uint32_t)PCG_ST_SEL_OVERFLOW);
     }
 }
 
 __global__ void __launch_bounds__(PLAN_THREADS) plan_count(const ChooseArgs a, PlanTotals *totals) {
-    plan_count_body<PLAN_THREADS>(a, totals, (int)blockIdx.x);
+    plan_count_body<PLAN_THREADS>(a, a.w, totals, (int)blockIdx.x);
 }
 __global__ void __launch_bounds__(PLAN_THREADS) plan_write(const ChooseArgs a, const PlanTotals *totals) {
-    plan_write_body<PLAN_THREADS, PLAN_THREADS>(a, totals, (int)blockIdx.x, (int)gridDim.x);
+    plan_write_body<PLAN_THREADS, PLAN_THREADS>(a, a.w, totals, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// The plans of ALL batches of an epoch in two launches (they depend on the picked ids, their labels and the CSR degrees only -
+// not on any parameter - so they do not belong on a step's critical path): batch s = nodes[s * B_full, min((s + 1) * B_full,
+// n_total)) is planned into plan slot s (slot 0's plan part + s * stride bytes) by its own nb_full workgroups - the same two
+// passes, one row per thread, as plan_count / plan_write.  `full` is carved for B_full rows per relation, `tail` for the last,
+// shorter batch (its layout differs; same slot pitch).
+// bump: a device counter incremented once per epoch (the sampler's epoch number: the picks were made before this launch).
+// (the arguments are used in place - no per-slot copy, no pointer to them: the relation arrays inside are indexed per lane, and
+//  a copy, or an argument whose address is taken, lives in scratch)
+template <bool WRITE>
+__device__ __forceinline__ void plan_slot(const ChooseArgs &a, int s, int block, int64_t stride, int64_t full_B) {
+    const int nb = (a.g.n_rel * a.B + PLAN_THREADS - 1) / PLAN_THREADS;
+    if (block >= nb) return;
+    Workspace w = a.w;                       // the slot's plan part (pointers only)
+    shift_plan(w, (int64_t)s * stride);
+    if constexpr (WRITE) plan_write_body<PLAN_THREADS, PLAN_THREADS>(a, w, reinterpret_cast<const PlanTotals *>(w.plan_totals), block, nb);
+    else plan_count_body<PLAN_THREADS>(a, w, reinterpret_cast<PlanTotals *>(w.plan_totals), block, (int64_t)s * full_B);
+}
+__global__ void __launch_bounds__(PLAN_THREADS) plan_batches_count(const ChooseArgs full, const ChooseArgs tail, int n_slots,
+                                                                   int tail_slot, int64_t stride, int nb_full,
+                                                                   unsigned long long *__restrict__ bump) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && bump) bump[0] += 1ull;
+    const int s = (int)blockIdx.x / nb_full, block = (int)blockIdx.x - s * nb_full;
+    if (s >= n_slots) return;
+    if (s == tail_slot) plan_slot<false>(tail, s, block, stride, full.B);
+    else plan_slot<false>(full, s, block, stride, full.B);
+}
+__global__ void __launch_bounds__(PLAN_THREADS) plan_batches_write(const ChooseArgs full, const ChooseArgs tail, int n_slots,
+                                                                   int tail_slot, int64_t stride, int nb_full) {
+    const int s = (int)blockIdx.x / nb_full, block = (int)blockIdx.x - s * nb_full;
+    if (s >= n_slots) return;
+    if (s == tail_slot) plan_slot<true>(tail, s, block, stride, full.B);
+    else plan_slot<true>(full, s, block, stride, full.B);
 }
 
 // The front of a training step in two launches instead of four: the plan's two passes ride along the score pass
@@ -385,8 +427,9 @@ __global__ void __launch_bounds__(FRONT_COUNT_THREADS) front_a_kernel(const Choo
                                                                       const int32_t *__restrict__ row_ids) {
     __shared__ float part[4][PCG_WAVE];
     const int b = (int)blockIdx.x;
+    if (a.sort_done && b == 0 && threadIdx.x == 0) a.sort_done[0] = 0u;
     if (b < n_plan_blocks)
-        plan_count_body<FRONT_COUNT_THREADS>(a, totals, b);
+        plan_count_body<FRONT_COUNT_THREADS>(a, a.w, totals, b);
     else if (b < n_plan_blocks + n_key_blocks)      // the train positives' sort keys, from their feature rows
         pos_key_body(a.g.X, a.g.feat_dim, a.g.feat_stride, W, bias, a.g.train_pos, a.g.n_pos, raw_keys, b - n_plan_blocks,
                      n_key_blocks);
@@ -411,7 +454,7 @@ __global__ void __launch_bounds__(PLAN_THREADS) front_b_kernel(const ChooseArgs 
         // (partitioned path) the centres' own scores, looked up by global id: center_out[b] = s0[nodes[b] + offset]
         const int b = (int)blockIdx.x * PLAN_THREADS + (int)threadIdx.x;
         if (center_out && b < a.B) center_out[b] = a.s0[(int64_t)a.nodes[b] + center_id_offset];
-        plan_write_body<PLAN_THREADS, FRONT_COUNT_THREADS>(a, totals, (int)blockIdx.x, n_count_blocks);
+        plan_write_body<PLAN_THREADS, FRONT_COUNT_THREADS>(a, a.w, totals, (int)blockIdx.x, n_count_blocks);
     } else
         rank_sort_body(a.s0, a.g.train_pos, a.g.n_pos, cap, keys, (int)blockIdx.x - n_write_blocks, sh, part, raw_keys);
 }
@@ -447,14 +490,24 @@ void pcg_debug_set_stamps(void *ptr) { pcg::g_stamps = static_cast<unsigned long
 
 int64_t pcg_choose_workspace_bytes(const pcg_graph_desc *g, int32_t B, int64_t list_capacity) {
     if (!g || B < 0 || list_capacity < 0 || list_capacity >= (1ll << 31)) return PCG_E_ARG;
-    return pcg::carve(g, B, list_capacity, nullptr, nullptr);
+    return pcg::carve1(g, B, list_capacity, nullptr, nullptr);
+}
+
+int64_t pcg_choose_plan_bytes(const pcg_graph_desc *g, int32_t B, int64_t list_capacity) {
+    if (!g || B < 0 || list_capacity < 0 || list_capacity >= (1ll << 31)) return PCG_E_ARG;
+    return pcg::carve(g, B, list_capacity, nullptr, nullptr, nullptr).plan_bytes;
+}
+
+int64_t pcg_choose_data_bytes(const pcg_graph_desc *g, int32_t B, int64_t list_capacity) {
+    if (!g || B < 0 || list_capacity < 0 || list_capacity >= (1ll << 31)) return PCG_E_ARG;
+    return pcg::carve(g, B, list_capacity, nullptr, nullptr, nullptr).data_bytes;
 }
 
 int64_t pcg_choose_workspace_offset(const pcg_graph_desc *g, int32_t B, int64_t list_capacity, int32_t which) {
     if (!g || B < 0 || list_capacity < 0) return PCG_E_ARG;
     pcg::Workspace w;
     unsigned char *base = reinterpret_cast<unsigned char *>(4096);   // fake base, only differences are used
-    pcg::carve(g, B, list_capacity, base, &w);
+    pcg::carve1(g, B, list_capacity, base, &w);
     switch (which) {
         case 0: return reinterpret_cast<unsigned char *>(w.row_begin) - base;
         case 1: return reinterpret_cast<unsigned char *>(w.len) - base;
@@ -483,7 +536,7 @@ int64_t pcg_sel_capacity_row(int64_t deg, double threshold, double rho, int32_t 
 static int choose_args(pcg::ChooseArgs &a, const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B,
                        const float *s0, const float *center_s0, const uint64_t *pos_keys, const double *thresholds,
                        const double *rho, int32_t train_flag, int32_t add_self, int32_t *cnt, void *workspace,
-                       int64_t list_capacity, uint32_t *status, bool plan_only = false) {
+                       int64_t list_capacity, uint32_t *status, bool plan_only = false, const void *plan = nullptr) {
     if (!nodes || !thresholds || !workspace || !status) return PCG_E_ARG;
     if (!plan_only && !s0) return PCG_E_ARG;      // (the plan reads neither the scores nor the sorted keys)
     if (list_capacity < 1 || list_capacity >= (1ll << 31)) return PCG_E_ARG;
@@ -506,21 +559,48 @@ static int choose_args(pcg::ChooseArgs &a, const pcg_graph_desc *g, const int32_
     a.cnt = cnt;
     a.status = status;
     a.stamps = pcg::g_stamps;
-    pcg::carve(g, B, list_capacity, static_cast<unsigned char *>(workspace), &a.w);
+    a.raw_keys = nullptr;
+    a.sort_out = nullptr;
+    a.sort_done = a.rank_acc = a.group_ticket = nullptr;
+    a.n_sort = a.sort_cap = a.sort_slices = a.sort_slice_len = 0;
+    a.pending_clear = nullptr;
+    pcg::carve1(g, B, list_capacity, static_cast<unsigned char *>(workspace), &a.w,
+                static_cast<unsigned char *>(const_cast<void *>(plan)));
     return PCG_OK;
 }
+
+// what a *_planned call may add: where the plan lives (null: inside `workspace`), and the in-kernel train-pos sort
+struct PlannedExtra {
+    const void *plan = nullptr;
+    uint32_t *sync_words = nullptr;     // non-null: pos_keys' scratch half holds the UNSORTED keys (pcg_step_scores_train); the
+                                        // select kernel sorts them itself ([3] = arrival counter, zero on entry) and clears [1]
+};
 
 static int choose_select(bool planned, const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B,
                          const float *s0, const float *center_s0, const uint64_t *pos_keys, const double *thresholds,
                          const double *rho, int32_t train_flag, int32_t add_self, int32_t *cnt, void *workspace,
-                         int64_t list_capacity, uint32_t *status, void *stream) {
+                         int64_t list_capacity, uint32_t *status, void *stream, const PlannedExtra &x = PlannedExtra()) {
     if (!g || B < 0) return PCG_E_ARG;
     if (B == 0) return PCG_OK;  // empty trailing batch (model_handler.py:134 produces one): nothing to do
     if (!cnt) return PCG_E_ARG;
+    if (x.plan && !planned) return PCG_E_ARG;
     pcg::ChooseArgs a;
     const int rc = choose_args(a, g, nodes, labels, B, s0, center_s0, pos_keys, thresholds, rho, train_flag, add_self, cnt,
-                               workspace, list_capacity, status);
+                               workspace, list_capacity, status, false, x.plan);
     if (rc != PCG_OK) return rc;
+    if (x.sync_words) {
+        a.pending_clear = x.sync_words + 1;
+        if (train_flag && g->n_pos > 0 && g->n_pos <= pcg::RANK_MAX) {
+            const int64_t cap = pcg_pos_sort_capacity(g->n_pos) / 2;
+            a.sort_out = const_cast<uint64_t *>(pos_keys);
+            a.raw_keys = pos_keys + cap;
+            a.sort_cap = (int32_t)cap;
+            a.n_sort = (g->n_pos + PCG_WAVE - 1) / PCG_WAVE;
+            a.sort_done = x.sync_words + 3;
+            a.rank_acc = x.sync_words + 4;
+            a.group_ticket = x.sync_words + 4 + pcg::RANK_MAX;
+        }
+    }
     return pcg::launch_select(a, static_cast<hipStream_t>(stream), planned);
 }
 
@@ -535,28 +615,68 @@ int pcg_choose_select(const pcg_graph_desc *g, const int32_t *nodes, const int32
 int pcg_choose_select_planned(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B,
                               const float *s0, const float *center_s0, const uint64_t *pos_keys, const double *thresholds,
                               const double *rho, int32_t train_flag, int32_t add_self, int32_t *cnt, void *workspace,
-                              int64_t list_capacity, uint32_t *status, void *stream) {
+                              const void *plan, int64_t list_capacity, uint32_t *status, void *stream) {
+    PlannedExtra x;
+    x.plan = plan;
     return choose_select(true, g, nodes, labels, B, s0, center_s0, pos_keys, thresholds, rho, train_flag, add_self, cnt,
-                         workspace, list_capacity, status, stream);
+                         workspace, list_capacity, status, stream, x);
+}
+
+/* The plans of all batches of an epoch (or of one batch: n_total <= B): two launches per EPOCH, off every step's critical path. */
+int pcg_plan_batches(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t n_total, int32_t B,
+                     const double *thresholds, const double *rho, int32_t train_flag, int32_t add_self, void *plans,
+                     int64_t plan_stride, int64_t list_capacity, uint32_t *status, uint64_t *bump_counter, void *stream) {
+    if (!g || n_total < 0 || B < 1 || !plans || plan_stride < 0 || (plan_stride & 255) != 0) return PCG_E_ARG;
+    if (n_total == 0) return PCG_OK;
+    const int n_slots = (n_total + B - 1) / B;
+    const int B_tail = n_total - (n_slots - 1) * B;
+    if (n_slots > 1 && plan_stride < pcg::carve(g, B, list_capacity, nullptr, nullptr, nullptr).plan_bytes) return PCG_E_ARG;
+    // (the data part is not touched by the plan: any non-null base will do for the argument check)
+    pcg::ChooseArgs full, tail;
+    int rc = choose_args(full, g, nodes, labels, B, nullptr, nullptr, nullptr, thresholds, rho, train_flag, add_self, nullptr, plans,
+                         list_capacity, status, true, plans);
+    if (rc != PCG_OK) return rc;
+    rc = choose_args(tail, g, nodes, labels, B_tail, nullptr, nullptr, nullptr, thresholds, rho, train_flag, add_self, nullptr, plans,
+                     list_capacity, status, true, plans);
+    if (rc != PCG_OK) return rc;
+    const int nb_full = (g->n_rel * B + pcg::PLAN_THREADS - 1) / pcg::PLAN_THREADS;
+    const int tail_slot = B_tail == B ? -1 : n_slots - 1;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(pcg::plan_batches_count, dim3(n_slots * nb_full), dim3(pcg::PLAN_THREADS), 0, st, full, tail, n_slots, tail_slot,
+                       plan_stride, nb_full, reinterpret_cast<unsigned long long *>(bump_counter));
+    PCG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(pcg::plan_batches_write, dim3(n_slots * nb_full), dim3(pcg::PLAN_THREADS), 0, st, full, tail, n_slots, tail_slot,
+                       plan_stride, nb_full);
+    PCG_LAUNCH_CHECK();
+    return PCG_OK;
 }
 
 /* first half: class-0 logits of rows [row_begin, row_end) -> s0_out[row]  ||  plan pass 1  (|| a deferred Adam update) */
+// no_plan: the launch is [train-pos keys || deferred Adam || score pass] only (the batch's plan was made elsewhere: pcg_plan_batches)
 static int front_a(const pcg_graph_desc *g, const float *W, const float *b, int64_t row_begin, int64_t row_end,
                    float *s0_out, const int32_t *row_ids, uint64_t *pos_keys, const int32_t *nodes, const int32_t *labels, int32_t B,
                    const double *thresholds, const double *rho, int32_t train_flag, int32_t add_self, void *workspace,
-                   int64_t list_capacity, uint32_t *status, const pcg::DeferredAdam *ad, void *stream) {
+                   int64_t list_capacity, uint32_t *status, const pcg::DeferredAdam *ad, void *stream, bool no_plan = false,
+                   uint32_t *zero_word = nullptr) {
     if (!g || !g->X || !W || !b || !s0_out || B < 0) return PCG_E_ARG;
     if (g->feat_dim < 1 || g->feat_stride < g->feat_dim || g->feat_stride % 4 != 0) return PCG_E_ARG;
     if ((reinterpret_cast<uintptr_t>(g->X) & 15u) != 0) return PCG_E_ARG;
     if (row_begin < 0 || row_end > g->n_nodes || row_begin > row_end) return PCG_E_ARG;
     if (B == 0 && row_ids) return PCG_E_ARG;
-    if (B == 0) return pcg_score_table(g, W, b, row_begin, row_end, s0_out, stream);   // (then _b gathers its keys itself)
+    if (B == 0 && !no_plan) return pcg_score_table(g, W, b, row_begin, row_end, s0_out, stream);   // (then _b gathers its keys itself)
     pcg::ChooseArgs a;
-    const int rc = choose_args(a, g, nodes, labels, B, nullptr, nullptr, nullptr, thresholds, rho, train_flag, add_self, nullptr,
-                               workspace, list_capacity, status, true);
-    if (rc != PCG_OK) return rc;
+    if (no_plan) {
+        a = pcg::ChooseArgs();
+        a.g = *g;
+        a.B = 0;
+    } else {
+        const int rc = choose_args(a, g, nodes, labels, B, nullptr, nullptr, nullptr, thresholds, rho, train_flag, add_self, nullptr,
+                                   workspace, list_capacity, status, true);
+        if (rc != PCG_OK) return rc;
+    }
+    a.sort_done = zero_word;                 // (front_a_kernel zeroes it: the select kernel's arrival counter)
     const int rows = g->n_rel * B;
-    pcg::PlanTotals *tot = reinterpret_cast<pcg::PlanTotals *>(a.w.plan_totals);
+    pcg::PlanTotals *tot = no_plan ? nullptr : reinterpret_cast<pcg::PlanTotals *>(a.w.plan_totals);
     const int n_count = (rows + pcg::FRONT_COUNT_THREADS - 1) / pcg::FRONT_COUNT_THREADS;
     const int n_score = (int)pcg::score_table_blocks(row_end - row_begin, g->feat_stride);
     // the train positives' unsorted keys go to the scratch half of pos_keys (rank-sort sizes only)
@@ -644,6 +764,39 @@ int pcg_step_front_train(const pcg_graph_desc *g, float *theta, float *m, float 
                    sync_words + 1, nullptr, 0, stream);
 }
 
+/* The front of a training step whose plan exists already (pcg_plan_batches): ONE launch
+ *   [train-pos keys from their feature rows || the previous step's deferred Adam update || score pass over the table]
+ * and no sort: pcg_choose_gather_planned(..., sync_words) sorts the keys inside the select kernel.  More than RANK_MAX train
+ * positives: the bucket sort's own launches follow here and the keys are sorted on return. */
+int pcg_step_scores_train(const pcg_graph_desc *g, float *theta, float *m, float *v, int32_t emb, float *s0, uint64_t *pos_keys,
+                          const float *slabs, const int32_t *step_counter, uint32_t *sync_words, double lr, double beta1,
+                          double beta2, double eps, double weight_decay, void *stream) {
+    if (!g || !theta || !m || !v || !slabs || !step_counter || !sync_words) return PCG_E_ARG;
+    if (g->n_pos > 0 && (!pos_keys || !g->train_pos)) return PCG_E_ARG;
+    const int64_t n_params = pcg_dense_n_params(g->feat_dim, emb, g->n_rel);
+    const int64_t o_clf = pcg_dense_param_offset(g->feat_dim, emb, g->n_rel, 3, 0), o_b = pcg_dense_param_offset(g->feat_dim, emb, g->n_rel, 4, 0);
+    if (n_params < 0 || o_clf < 0) return PCG_E_ARG;
+    pcg::DeferredAdam ad;
+    ad.theta = theta; ad.m = m; ad.v = v;
+    ad.slabs = slabs;
+    ad.n_params = n_params;
+    ad.p_end = o_clf;
+    ad.step_counter = step_counter;
+    ad.pending = sync_words + 1;
+    ad.h = {(float)lr, (float)beta1, (float)beta2, (float)eps, (float)weight_decay};
+    const int rc = front_a(g, theta + o_clf, theta + o_b, 0, g->n_nodes, s0, nullptr, pos_keys, nullptr, nullptr, 0, nullptr, nullptr, 1, 0,
+                           nullptr, 1, nullptr, &ad, stream, true, sync_words + 3);
+    if (rc != PCG_OK) return rc;
+    if (g->n_pos > pcg::RANK_MAX) return pcg_pos_sort(g, s0, pos_keys, stream);
+    return PCG_OK;
+}
+
+int32_t pcg_pos_sort_in_select(int32_t n_pos) { return n_pos > 0 && n_pos <= pcg::RANK_MAX ? 1 : 0; }
+
+/* uint32 words of the `sync_words` buffer: [0] dense ticket, [1] update pending, [2] its slab count, [3] the in-kernel sort's group
+ * counter, then the sort's rank accumulators (one per train positive, up to RANK_MAX) and group tickets */
+int32_t pcg_sync_words_count(void) { return 4 + pcg::RANK_MAX + pcg::RANK_MAX / PCG_WAVE; }
+
 int pcg_step_front(const pcg_graph_desc *g, const float *W, const float *b, float *s0, uint64_t *pos_keys,
                    const int32_t *nodes, const int32_t *labels, int32_t B, const double *thresholds, const double *rho,
                    int32_t train_flag, int32_t add_self, void *workspace, int64_t list_capacity, uint32_t *status,
@@ -674,15 +827,18 @@ int pcg_choose_aggregate(const pcg_graph_desc *g, const int32_t *nodes, const in
 int pcg_choose_gather_planned(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B, const float *s0,
                               const float *center_s0, const uint64_t *pos_keys, const double *thresholds, const double *rho,
                               int32_t train_flag, int32_t add_self, float *agg, int32_t agg_stride, int32_t *cnt, void *workspace,
-                              int64_t list_capacity, uint32_t *status, void *stream) {
+                              const void *plan, int64_t list_capacity, uint32_t *status, uint32_t *sync_words, void *stream) {
     if (!g || B < 0) return PCG_E_ARG;
     if (B == 0) return PCG_OK;
     if (!g->X || !agg) return PCG_E_ARG;
-    const int rc = pcg_choose_select_planned(g, nodes, labels, B, s0, center_s0, pos_keys, thresholds, rho, train_flag,
-                                             add_self, cnt, workspace, list_capacity, status, stream);
+    PlannedExtra x;
+    x.plan = plan;
+    x.sync_words = sync_words;
+    const int rc = choose_select(true, g, nodes, labels, B, s0, center_s0, pos_keys, thresholds, rho, train_flag, add_self, cnt,
+                                 workspace, list_capacity, status, stream, x);
     if (rc != PCG_OK) return rc;
-    return pcg_gather_lists(g->X, g->feat_dim, g->feat_stride, g->n_nodes, g->n_rel * B, cnt, g, B, workspace, list_capacity, agg,
-                            agg_stride, status, stream);
+    return pcg_gather_lists_planned(g->X, g->feat_dim, g->feat_stride, g->n_nodes, g->n_rel * B, cnt, g, B, workspace, plan, list_capacity,
+                                    agg, agg_stride, status, stream);
 }
 
 int pcg_choose_aggregate_planned(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B,
@@ -694,7 +850,7 @@ int pcg_choose_aggregate_planned(const pcg_graph_desc *g, const int32_t *nodes, 
     if (B == 0) return PCG_OK;
     if (!g->X || !agg) return PCG_E_ARG;
     const int rc = pcg_choose_select_planned(g, nodes, labels, B, s0, center_s0, pos_keys, thresholds, rho, train_flag,
-                                             add_self, cnt, workspace, list_capacity, status, stream);
+                                             add_self, cnt, workspace, nullptr, list_capacity, status, stream);
     if (rc != PCG_OK) return rc;
     return pcg_aggregate_lists(g->X, g->feat_dim, g->feat_stride, g->n_nodes, g->n_rel * B, cnt, g, B, workspace, list_capacity,
                                norm, agg, agg_stride, status, stream);

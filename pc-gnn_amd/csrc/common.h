@@ -237,10 +237,11 @@ constexpr int RANK_MAX = 16384;
 constexpr int RANK_TILE = 8192;
 constexpr int RANK_WAVES = 16;
 
-// sh: TILE (default RANK_TILE) uint64, part: RANK_WAVES * 64 ints (LDS); workgroup `block` of ceil(n_pos / 64), 1024 threads
+// sh: TILE (default RANK_TILE) uint64, part: WAVES * 64 ints (LDS); workgroup `block` of ceil(n_pos / 64), WAVES * 64 threads
 // raw: the unsorted keys (make_pos_key of every i < n_pos), if somebody has formed them already (pos_key_body) - then a
 // tile is staged with coalesced 8-byte loads instead of two dependent loads and a random 4-byte gather per key
-template <int TILE = RANK_TILE>
+// PUBLISH: the sorted keys are read by other workgroups of the SAME launch (select_rows): write-through (sc1) stores
+template <int TILE = RANK_TILE, int WAVES = RANK_WAVES, bool PUBLISH = false>
 __device__ __forceinline__ void rank_sort_body(const float *__restrict__ s0, const int32_t *__restrict__ train_pos, int n_pos,
                                                int cap, uint64_t *__restrict__ keys, int block, uint64_t *sh, int *part,
                                                const uint64_t *__restrict__ raw = nullptr) {
@@ -248,7 +249,8 @@ __device__ __forceinline__ void rank_sort_body(const float *__restrict__ s0, con
     const int i = block * PCG_WAVE + lane;
     // a key costs two dependent loads (train_pos[i], then s0 of it): this thread's own key and its share of a tile's keys
     // are requested level by level, so the staging of a tile costs two load latencies in all
-    constexpr int PER = TILE / (RANK_WAVES * PCG_WAVE);
+    constexpr int PER = TILE / (WAVES * PCG_WAVE);
+    static_assert(PER >= 1 && PER * WAVES * PCG_WAVE == TILE, "a tile is staged PER keys per thread");
     // (every load here is unconditional - index clamped, the value OR-ed with all-ones where it must not count: a load inside
     //  a conditional is compiled into a branch that waits for every load in flight, and a tile's PER loads per thread would
     //  go out one at a time)
@@ -290,7 +292,7 @@ __device__ __forceinline__ void rank_sort_body(const float *__restrict__ s0, con
         }
         // this wave's stretch of the tile, eight keys (four 16-byte broadcast reads) per iteration; the tile is padded
         // with all-ones keys (never smaller than anybody's), so the stretches need no tail handling
-        const int chunk = (((nt + RANK_WAVES - 1) / RANK_WAVES) + 7) & ~7;
+        const int chunk = (((nt + WAVES - 1) / WAVES) + 7) & ~7;
         const int j0 = wave * chunk;
         int j1 = j0 + chunk;
         const int nt8 = (nt + 7) & ~7;
@@ -310,11 +312,15 @@ __device__ __forceinline__ void rank_sort_body(const float *__restrict__ s0, con
     if (wave == 0 && i < n_pos) {
         int rank = 0;
 #pragma unroll
-        for (int w = 0; w < RANK_WAVES; ++w) rank += part[w * PCG_WAVE + lane];
-        keys[rank] = mine;
+        for (int w = 0; w < WAVES; ++w) rank += part[w * PCG_WAVE + lane];
+        if constexpr (PUBLISH) __hip_atomic_store(reinterpret_cast<unsigned long long *>(keys) + rank, (unsigned long long)mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else keys[rank] = mine;
     }
     if (block == 0)
-        for (int t = n_pos + threadIdx.x; t < cap; t += blockDim.x) keys[t] = ~0ull;
+        for (int t = n_pos + threadIdx.x; t < cap; t += blockDim.x) {
+            if constexpr (PUBLISH) __hip_atomic_store(reinterpret_cast<unsigned long long *>(keys) + t, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else keys[t] = ~0ull;
+        }
 }
 
 // ---- Adam update of a range of the flat parameter buffer from per-tile gradient slabs -----------------------------------

@@ -793,7 +793,7 @@ int pcg_dense_step(const pcg_graph_desc *g, const float *theta, int32_t emb, con
 
 int pcg_train_dense(const pcg_graph_desc *g, float *theta, float *m, float *v, int32_t emb, const int32_t *ids,
                     const int32_t *labels, int32_t B, const float *agg, int32_t agg_stride, const int32_t *cnt,
-                    const void *workspace, int64_t list_capacity, float lambda_1, float inv_count, float *logits, float *center,
+                    const void *workspace, const void *plan, int64_t list_capacity, float lambda_1, float inv_count, float *logits, float *center,
                     float *combined, float *row_loss, float *slabs, int32_t *step_counter, uint32_t *sync_words, double lr,
                     double beta1, double beta2, double eps, double weight_decay, int32_t adam_clf, void *stream) {
     if (!g || B < 0) return PCG_E_ARG;
@@ -801,7 +801,8 @@ int pcg_train_dense(const pcg_graph_desc *g, float *theta, float *m, float *v, i
     if (workspace) {
         if (!cnt || list_capacity < 1) return PCG_E_ARG;
         pcg::Workspace w;
-        pcg::carve(g, B, list_capacity, static_cast<unsigned char *>(const_cast<void *>(workspace)), &w);
+        pcg::carve1(g, B, list_capacity, static_cast<unsigned char *>(const_cast<void *>(workspace)), &w,
+                    static_cast<unsigned char *>(const_cast<void *>(plan)));
         x.chunk_begin = w.chunk_begin;
         x.partial = w.partial;
         x.cnt = cnt;

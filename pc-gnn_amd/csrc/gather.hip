@@ -213,7 +213,7 @@ extern "C" {
 
 static int aggregate(const float *X, int32_t feat_dim, int32_t feat_stride, int64_t table_rows, int32_t n_rows, const int32_t *cnt,
                      const pcg_graph_desc *g, int32_t B, void *workspace, int64_t list_capacity, int32_t norm,
-                     float *agg, int32_t agg_stride, bool combine, uint32_t *status, void *stream) {
+                     float *agg, int32_t agg_stride, bool combine, uint32_t *status, void *stream, const void *plan = nullptr) {
     if (!X || !cnt || !g || !workspace || !agg || n_rows < 0 || B < 0 || table_rows < 1) return PCG_E_ARG;
     if (n_rows != g->n_rel * B) return PCG_E_ARG;       // the lists are those of the plan in `workspace`: n_rel * B rows
     if (n_rows == 0) return PCG_OK;
@@ -221,7 +221,7 @@ static int aggregate(const float *X, int32_t feat_dim, int32_t feat_stride, int6
     if (feat_stride > 512) return PCG_E_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(X) & 15u) != 0) return PCG_E_ARG;
     pcg::Workspace w;
-    pcg::carve(g, B, list_capacity, static_cast<unsigned char *>(workspace), &w);
+    pcg::carve1(g, B, list_capacity, static_cast<unsigned char *>(workspace), &w, static_cast<unsigned char *>(const_cast<void *>(plan)));
     pcg::AggArgs a;
     a.X = X;
     a.feat_dim = feat_dim;
@@ -259,6 +259,14 @@ int pcg_gather_lists(const float *X, int32_t feat_dim, int32_t feat_stride, int6
                      int32_t agg_stride, uint32_t *status, void *stream) {
     return aggregate(X, feat_dim, feat_stride, table_rows, n_rows, cnt, g, B, workspace, list_capacity, PCG_NORM_COUNT, agg,
                      agg_stride, false, status, stream);
+}
+
+/* the same with the batch's plan part outside the workspace (pcg_plan_batches; plan == NULL: inside, as pcg_gather_lists) */
+int pcg_gather_lists_planned(const float *X, int32_t feat_dim, int32_t feat_stride, int64_t table_rows, int32_t n_rows,
+                             const int32_t *cnt, const pcg_graph_desc *g, int32_t B, void *workspace, const void *plan,
+                             int64_t list_capacity, float *agg, int32_t agg_stride, uint32_t *status, void *stream) {
+    return aggregate(X, feat_dim, feat_stride, table_rows, n_rows, cnt, g, B, workspace, list_capacity, PCG_NORM_COUNT, agg,
+                     agg_stride, false, status, stream, plan);
 }
 
 }  // extern "C"

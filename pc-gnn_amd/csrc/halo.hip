@@ -374,7 +374,7 @@ int pcg_halo_lookup(const pcg_graph_desc *g, int32_t B, void *workspace, int64_t
         (table_slots & (table_slots - 1)) != 0 || lo > hi || n_pos < 0 || (n_pos > 0 && (!pos_ids || !pos_idx)))
         return PCG_E_ARG;
     pcg::Workspace w;
-    pcg::carve(g, B, list_capacity, static_cast<unsigned char *>(workspace), &w);
+    pcg::carve1(g, B, list_capacity, static_cast<unsigned char *>(workspace), &w);
     pcg::HaloArgs a = {};
     a.list = w.list;
     a.chunk_desc = w.chunk_desc;

@@ -96,7 +96,82 @@ __device__ __forceinline__ bool sorted_contains(const uint32_t *list, int n, uin
     return lo < n && list[lo] == x;
 }
 
-__device__ __forceinline__ float pos_score(const uint64_t *pk, int i) { return from_orderable((uint32_t)(pk[i] >> 32)); }
+// The sorted train-pos keys may be produced INSIDE this launch (select_rows sorts them before the rows start, every workgroup
+// doing a share): a wave that needs them waits - once - until every key group has been counted in.  Visibility: the producers
+// store the sorted keys write-through (sc1) and count a group in only behind those stores' completion (the count is an
+// agent-scope atomic, polled with agent-scope loads).  The consumer side needs no cache invalidate: a CU's L1 - and its XCD's L2 -
+// hold no line of the sorted-key buffer before the count is complete (both start the launch clean - the scores, rewritten by the
+// launch before this one and read here with plain loads, depend on that too - and in this launch nothing reads the buffer
+// before its own wait has returned: the loads are behind the wait in program order and the hardware does not speculate loads),
+// so the first touch of a line after the wait fetches what the producers wrote through.  An agent-scope acquire fence here
+// (buffer_inv sc1, one per workgroup, three workgroups per CU, all at the same moment) cost ~5 us per positive row: it empties
+// the L1 under the other workgroups' gathers and under the window search's own first probes.  Nobody waits on a
+// workgroup that itself waits: the sort comes first in every workgroup.  The wait is bounded: if the count never arrives (it
+// cannot, short of a lost workgroup) the row goes on with whatever the buffer holds and PCG_ST_SYNC_TIMEOUT is raised - a wrong
+// result that is reported, never a hung device.
+constexpr int SORT_SPIN_MAX = 1 << 21;       // x >= 0.2 us per poll
+// sortw: an LDS block of the workgroup, [0] and [1] zero at kernel start: [0] = "the sorted keys are complete", [1] = "a wave of
+// this workgroup is polling", [2] = entries of the search index, [3] = its stride, [4 ..] = the index.  ONE wave per workgroup
+// polls the device counter (thousands of waves polling one address every few hundred nanoseconds saturate its L2 channel); the
+// others wait on the LDS word.  The polling wave also builds the workgroup's SEARCH INDEX: the score bits of every stride-th
+// sorted key.  Every row's window search starts in it (LDS) instead of in the keys themselves: a thousand rows are released at
+// the same moment, and the first round of a search over the whole buffer probes the same 64 positions for every one of them -
+// the few L2 lines behind those positions took ~4 us to serve them all.
+constexpr int KIDX_MAX = 512;
+__device__ __forceinline__ uint64_t pk_ld(const uint64_t *pk, int i);
+__device__ __forceinline__ void wait_sorted_keys(const ChooseArgs &a, int &keys_ok, int lane, int *sortw) {
+    if (a.n_sort == 0 || keys_ok) return;                                  // (wave-uniform)
+    if (__hip_atomic_load(&sortw[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {
+        int elected = 0;
+        if (lane == 0) elected = atomicCAS(&sortw[1], 0, 1) == 0;
+        elected = __builtin_amdgcn_readfirstlane(elected);
+        if (elected) {
+            for (int spins = 0;; ++spins) {
+                const unsigned seen = (unsigned)__builtin_amdgcn_readfirstlane(
+                    (int)__hip_atomic_load(a.sort_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if (seen >= (unsigned)a.n_sort) break;
+                if (spins >= SORT_SPIN_MAX) {
+                    if (lane == 0 && a.status) atomicOr(a.status, (uint32_t)PCG_ST_SYNC_TIMEOUT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");         // (compiler + wave ordering: the key loads come after the wait)
+            const int P = a.g.n_pos;
+            int stride = 16;
+            while ((P + stride - 1) / stride > KIDX_MAX) stride <<= 1;
+            const int n_idx = (P + stride - 1) / stride;
+            for (int t = lane; t < n_idx; t += PCG_WAVE) sortw[4 + t] = (int)(uint32_t)(pk_ld(a.pos_keys, t * stride) >> 32);
+            if (lane == 0) {
+                sortw[2] = n_idx;
+                sortw[3] = stride;
+            }
+            if (lane == 0) __hip_atomic_store(&sortw[0], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            while (__hip_atomic_load(&sortw[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");                 // (compiler + wave ordering: the key loads come after the wait)
+    keys_ok = 1;
+}
+
+// every load of a sorted train-pos key.  PCG_PK_NT = 1: past the L1 (non-temporal: served by L2 like an agent-scope load, yet an
+// ordinary load to the compiler - agent-scope ATOMIC loads are never speculated: "x = cond ? load : c" became a branch with a load
+// and a full wait of its own, +5 us per positive row).  Default: plain loads - see wait_sorted_keys for why no L1 line of the
+// sorted keys can predate their publication; with L1 bypassed the first probes of the window search (the same 64 positions for
+// every row) hit the same few L2 lines from a thousand rows released at once: +4 us per positive row.
+#ifndef PCG_PK_NT
+#define PCG_PK_NT 0
+#endif
+__device__ __forceinline__ uint64_t pk_ld(const uint64_t *pk, int i) {
+#if PCG_PK_NT
+    return __builtin_nontemporal_load(pk + i);
+#else
+    return pk[i];
+#endif
+}
+
+__device__ __forceinline__ float pos_score(const uint64_t *pk, int i) { return from_orderable((uint32_t)(pk_ld(pk, i) >> 32)); }
 __device__ __forceinline__ uint32_t pos_dkey(const uint64_t *pk, int i, float c) { return dist_key(c, pos_score(pk, i)); }
 
 // First x in [lo, hi] with pred(x) false, pred being true on a prefix of [lo, hi).
@@ -178,7 +253,7 @@ __device__ __forceinline__ void wave_kth(uint32_t ck, bool have, int n, int want
 // ---------------------------------------------------------------------------------------------------------------------
 template <int NW>
 __device__ __forceinline__ void finish_row(const ChooseArgs &a, int row, const RowRec &p, float c, const uint32_t *sel, int ns,
-                                           bool sel_stored, int wave, int lane, int *red) {
+                                           bool sel_stored, int wave, int lane, int *red, int &keys_ok, int *sortw) {
     constexpr int NT = NW * PCG_WAVE;
     const int tid = wave * PCG_WAVE + lane;
     const int m = p.m, node = p.node;
@@ -186,6 +261,8 @@ __device__ __forceinline__ void finish_row(const ChooseArgs &a, int row, const R
     int mt = 0;        // slots used
     int valid = 0;     // per-thread count of non-duplicate minority picks
     if (m > 0) {
+        wait_sorted_keys(a, keys_ok, lane, sortw);
+        PCG_STAMP(7);
         const uint64_t *__restrict__ pk = a.pos_keys;
         const int P = a.g.n_pos;
         int L, R, L2, R2, tau = INT_MAX, need_t = 0;
@@ -193,8 +270,21 @@ __device__ __forceinline__ void finish_row(const ChooseArgs &a, int row, const R
             L = L2 = 0;
             R = R2 = P;
         } else {
-            // window [lo, lo+m) of the m nearest: first lo whose left end is not farther than the element right of the window
-            const int lo = wave_partition_point(0, P - m, lane, [&](int x) {
+            // window [lo, lo+m) of the m nearest: first lo whose left end is not farther than the element right of the window.
+            // With pc = the number of keys whose score is below c: the predicate is false for every x >= pc (the left end is not
+            // below c) and true for every x < pc - m (the element right of the window is still below c), so lo is in
+            // [pc - m, pc]; the workgroup's search index (every stride-th key's score, in LDS) brackets pc to one stride.
+            int lo_min = 0, lo_max = P - m;
+            if (a.n_sort > 0 && sortw) {
+                const int n_idx = sortw[2], stride = sortw[3];
+                const uint32_t *ix = reinterpret_cast<const uint32_t *>(sortw + 4);
+                const int t = wave_partition_point(0, n_idx, lane, [&](int x) { return from_orderable(ix[x]) < c; });
+                const int pc_lo = t > 0 ? (t - 1) * stride + 1 : 0, pc_hi = t * stride < P ? t * stride : P;
+                lo_min = pc_lo - m > 0 ? pc_lo - m : 0;
+                lo_max = pc_hi < P - m ? pc_hi : P - m;
+                lo_max = lo_max < lo_min ? lo_min : lo_max;
+            }
+            const int lo = wave_partition_point(lo_min, lo_max, lane, [&](int x) {
                 return (c - pos_score(pk, x)) > (pos_score(pk, x + m) - c);
             });
             // one batch of six independent loads decides the usual tie-free case
@@ -235,11 +325,11 @@ __device__ __forceinline__ void finish_row(const ChooseArgs &a, int row, const R
                     int cn = 0;
                     for (int i0 = L2; i0 < L; i0 += PCG_WAVE) {
                         const int i = i0 + lane;
-                        cn += wave_count(i < L && (int)(uint32_t)pk[i] <= mid);
+                        cn += wave_count(i < L && (int)(uint32_t)pk_ld(pk, i) <= mid);
                     }
                     for (int i0 = R; i0 < R2; i0 += PCG_WAVE) {
                         const int i = i0 + lane;
-                        cn += wave_count(i < R2 && (int)(uint32_t)pk[i] <= mid);
+                        cn += wave_count(i < R2 && (int)(uint32_t)pk_ld(pk, i) <= mid);
                     }
                     if (cn >= need_t) phi = mid;
                     else plo = mid + 1;
@@ -249,7 +339,7 @@ __device__ __forceinline__ void finish_row(const ChooseArgs &a, int row, const R
                 const int nl = L - L2;
                 const int ti = lane < nl ? L2 + lane : R + (lane - nl);
                 const bool tv = lane < T;
-                const int tp = tv ? (int)(uint32_t)pk[ti] : INT_MAX;
+                const int tp = tv ? (int)(uint32_t)pk_ld(pk, ti) : INT_MAX;
                 int rank = 0;
                 for (int j = 0; j < T; ++j) rank += __builtin_amdgcn_readlane(tp, j) < tp;
                 // tau = the need_t-th smallest position among the ties (positions are distinct)
@@ -266,7 +356,7 @@ __device__ __forceinline__ void finish_row(const ChooseArgs &a, int row, const R
 #pragma unroll
             for (int x = 0; x < KEY_UNROLL; ++x) {
                 const int j = base + x * NT;
-                pos[x] = (uint32_t)pk[L + (j < n_strict ? j : n_strict - 1)];
+                pos[x] = (uint32_t)pk_ld(pk, L + (j < n_strict ? j : n_strict - 1));
             }
 #pragma unroll
             for (int x = 0; x < KEY_UNROLL; ++x) u[x] = (uint32_t)a.g.train_pos[pos[x]];
@@ -291,7 +381,7 @@ __device__ __forceinline__ void finish_row(const ChooseArgs &a, int row, const R
                     bool take = false;
                     uint32_t u = 0;
                     if (i < e0i) {
-                        const uint32_t pos = (uint32_t)pk[i];
+                        const uint32_t pos = (uint32_t)pk_ld(pk, i);
                         take = (int)pos <= tau;
                         if (take) u = (uint32_t)a.g.train_pos[pos];
                     }
@@ -389,7 +479,7 @@ __device__ __forceinline__ void select_four_short_rows(const ChooseArgs &a, int 
 
 // One row of 17 .. 64 neighbours on one wave: one key per lane, ranked lane against lane in the stable (key, position)
 // order - no k-th value is formed.  area: WAVE_AREA words of LDS (the kept ids go behind the histogram's place).
-__device__ __forceinline__ void select_lane_row(const ChooseArgs &a, int row, uint32_t *area, int lane) {
+__device__ __forceinline__ void select_lane_row(const ChooseArgs &a, int row, uint32_t *area, int lane, int &keys_ok, int *sortw) {
     const int tid = lane;
     if (a.stamps && tid == 0) a.stamps[(size_t)row * 8] = wall_clock64() | ((unsigned long long)blockIdx.x << 54);   // + who ran it
     const RowRec p = a.w.recs[row];
@@ -432,7 +522,7 @@ __device__ __forceinline__ void select_lane_row(const ChooseArgs &a, int row, ui
         else a.w.list[p.lbeg + at] = (int32_t)id;
     }
     PCG_STAMP(3);
-    if (tail) finish_row<1>(a, row, p, c, sel_lds, ns, false, 0, lane, nullptr);
+    if (tail) finish_row<1>(a, row, p, c, sel_lds, ns, false, 0, lane, nullptr, keys_ok, sortw);
     else {
         if (lane == 0) report_plain_row(a, row, p, ns);
         PCG_STAMP(6);
@@ -441,7 +531,7 @@ __device__ __forceinline__ void select_lane_row(const ChooseArgs &a, int row, ui
 
 // One row of 65 .. 512 neighbours on one wave: keys in registers.  area: WAVE_AREA words of LDS
 // (histogram HIST_W | kept ids T1_CAP | candidates 64).
-__device__ __forceinline__ void select_wave_row(const ChooseArgs &a, int row, uint32_t *area, int lane) {
+__device__ __forceinline__ void select_wave_row(const ChooseArgs &a, int row, uint32_t *area, int lane, int &keys_ok, int *sortw) {
     const int tid = lane;
     if (a.stamps && tid == 0) a.stamps[(size_t)row * 8] = wall_clock64() | ((unsigned long long)blockIdx.x << 54);   // + who ran it
     const RowRec p = a.w.recs[row];
@@ -556,7 +646,7 @@ __device__ __forceinline__ void select_wave_row(const ChooseArgs &a, int row, ui
         ns += __popcll(sm);
     }
     PCG_STAMP(3);
-    if (tail) finish_row<1>(a, row, p, c, sel_lds, ns, false, 0, lane, nullptr);
+    if (tail) finish_row<1>(a, row, p, c, sel_lds, ns, false, 0, lane, nullptr, keys_ok, sortw);
     else {
         if (lane == 0) report_plain_row(a, row, p, ns);
         PCG_STAMP(6);
@@ -592,7 +682,7 @@ __device__ __forceinline__ void for_keys(const uint32_t *keys, const uint32_t *_
 // lds: WG_KEYCAP words (keys, later the kept ids) | hist HIST_WG | cand 64 | red
 template <bool LDSK, int NW = SEL_NW>
 __device__ __forceinline__ void select_wg_row(const ChooseArgs &a, int row, uint32_t *keys, uint32_t *hist, uint32_t *cand,
-                                              int *red, int tid, uint32_t *gk = nullptr) {
+                                              int *red, int tid, int &keys_ok, int *sortw, uint32_t *gk = nullptr) {
     constexpr int NT = NW * PCG_WAVE;
     constexpr int HBITS = NW == 8 ? 11 : 12;                 // 4 * NT histogram bins: one uint4 of them per thread
     static_assert(4 * NT == (1 << HBITS), "NW is 8 or 16");
@@ -858,8 +948,8 @@ __device__ __forceinline__ void select_wg_row(const ChooseArgs &a, int row, uint
         PCG_STAMP(6);
         return;
     }
-    if constexpr (LDSK) finish_row<NW>(a, row, p, c, keys, ns, false, wave, lane, red);
-    else finish_row<NW>(a, row, p, c, selbuf, ns, !sel_in_lds, wave, lane, red);
+    if constexpr (LDSK) finish_row<NW>(a, row, p, c, keys, ns, false, wave, lane, red, keys_ok, sortw);
+    else finish_row<NW>(a, row, p, c, selbuf, ns, !sel_in_lds, wave, lane, red, keys_ok, sortw);
 }
 
 // One persistent launch selects every row of the batch, longest rows first.  The work is one queue of workgroup-sized units,
@@ -871,6 +961,88 @@ __device__ __forceinline__ void select_wg_row(const ChooseArgs &a, int row, uint
 // workgroups from serialising on one address (one word serves ~90 atomics per microsecond); per-wave pulls would be
 // thousands.  A workgroup busy with long rows simply pulls fewer units; nothing else is assigned in advance.
 constexpr int SEL_SHARDS = 8;
+constexpr int SORT_TILE = 4096;          // keys per LDS tile of the in-kernel train-pos sort (32 KB of the 40 KB key area)
+
+// The train positives' sort inside select_rows, shared by (nearly) every workgroup of the launch: the unsorted keys (formed
+// beside the score pass, unique) come in groups of 64; workgroup w works on group w % n_sort and on slice w / n_sort of the key
+// range: it counts, for each of its group's keys, the keys of its slice that are smaller (keys in LDS, the slice split over
+// the waves, broadcast reads: rank_sort_body's inner loop), adds the 64 counts to the group's rank accumulators (device-scope
+// atomics) and takes the group's ticket; the workgroup whose ticket is the last reads the complete ranks, stores the group's
+// keys at their ranks (write-through), puts accumulators and ticket back to zero and counts the group in.  A few hundred
+// compares per lane instead of the thousands a whole-range rank sort by ceil(P / 64) workgroups costs while the other
+// workgroups of its CU compete for the same SIMDs: the keys are sorted ~4 us into the launch instead of ~9.
+template <int TILE>
+__device__ __forceinline__ void sort_share(const ChooseArgs &a, int w, uint64_t *sh, int *part, int tid) {
+    constexpr int PER = TILE / (SEL_NW * PCG_WAVE);
+    const int lane = tid & (PCG_WAVE - 1), wave = tid >> 6;
+    const int P = a.g.n_pos;
+    const int group = w % a.n_sort, slice = w / a.n_sort;
+    const int i = group * PCG_WAVE + lane;
+    const uint64_t *__restrict__ raw = a.raw_keys;
+    const uint64_t mine = raw[i < P ? i : P - 1] | (i < P ? 0ull : ~0ull);
+    const int jb = slice * a.sort_slice_len;
+    const int je = jb + a.sort_slice_len < P ? jb + a.sort_slice_len : P;
+    int c = 0;
+    for (int t0 = jb; t0 < je; t0 += TILE) {
+        const int nt = je - t0 < TILE ? je - t0 : TILE;
+        uint64_t kt[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {                                    // (unconditional loads: index clamped, pad = all ones)
+            const int t = tid + u * SEL_NW * PCG_WAVE;
+            kt[u] = raw[t0 + (t < nt ? t : nt - 1)] | (t < nt ? 0ull : ~0ull);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PER; ++u) sh[tid + u * SEL_NW * PCG_WAVE] = kt[u];
+        __syncthreads();
+        const int chunk = (((nt + SEL_NW - 1) / SEL_NW) + 7) & ~7;
+        const int j0 = wave * chunk;
+        const int nt8 = (nt + 7) & ~7;
+        const int j1 = j0 + chunk < nt8 ? j0 + chunk : nt8;
+        const uint4 *sh4 = reinterpret_cast<const uint4 *>(sh);
+        for (int j = j0; j < j1; j += 8) {
+            const uint4 q0 = sh4[(j >> 1) + 0], q1 = sh4[(j >> 1) + 1], q2 = sh4[(j >> 1) + 2], q3 = sh4[(j >> 1) + 3];
+            const uint64_t a0 = ((uint64_t)q0.y << 32) | q0.x, a1 = ((uint64_t)q0.w << 32) | q0.z;
+            const uint64_t a2 = ((uint64_t)q1.y << 32) | q1.x, a3 = ((uint64_t)q1.w << 32) | q1.z;
+            const uint64_t a4 = ((uint64_t)q2.y << 32) | q2.x, a5 = ((uint64_t)q2.w << 32) | q2.z;
+            const uint64_t a6 = ((uint64_t)q3.y << 32) | q3.x, a7 = ((uint64_t)q3.w << 32) | q3.z;
+            c += (a0 < mine) + (a1 < mine) + (a2 < mine) + (a3 < mine) + (a4 < mine) + (a5 < mine) + (a6 < mine) + (a7 < mine);
+        }
+    }
+    part[wave * PCG_WAVE + lane] = c;
+    __syncthreads();
+    if (wave == 0) {
+        int cnt = 0;
+#pragma unroll
+        for (int x = 0; x < SEL_NW; ++x) cnt += part[x * PCG_WAVE + lane];
+        uint32_t ticket = 0;
+        if (a.sort_slices > 1) {                                           // (one slice: the count is the rank)
+            if (i < P) __hip_atomic_fetch_add(a.rank_acc + i, (uint32_t)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the adds have been performed before the ticket is taken
+            if (lane == 0) ticket = __hip_atomic_fetch_add(a.group_ticket + group, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
+        }
+        if (ticket == (uint32_t)a.sort_slices - 1u) {                      // the group's last slice: every share has been added
+            if (i < P) {
+                uint32_t rank = (uint32_t)cnt;
+                if (a.sort_slices > 1) {
+                    rank = __hip_atomic_load(a.rank_acc + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(a.rank_acc + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.sort_out) + (rank < (uint32_t)P ? rank : 0u),
+                                   (unsigned long long)mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (group == 0)
+                for (int t = P + lane; t < a.sort_cap; t += PCG_WAVE)
+                    __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.sort_out) + t, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0 && a.sort_slices > 1) __hip_atomic_store(a.group_ticket + group, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's stores are complete: count the group in
+            if (lane == 0) __hip_atomic_fetch_add(a.sort_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.stamps && lane == 0) atomicMax(&a.stamps[(size_t)a.g.n_rel * a.B * 8 + 5], (unsigned long long)wall_clock64());
+        }
+    }
+    __syncthreads();                                                       // (the LDS is the row paths' again)
+}
 __global__ void __launch_bounds__(SEL_NW *PCG_WAVE) __attribute__((amdgpu_waves_per_eu(6, 8))) select_rows(const ChooseArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t *lds = reinterpret_cast<uint32_t *>(smem);
@@ -881,8 +1053,10 @@ __global__ void __launch_bounds__(SEL_NW *PCG_WAVE) __attribute__((amdgpu_waves_
     // per-relation neighbour arrays in LDS: a per-lane relation index (four short rows per wave) then costs one ds_read
     // instead of a waterfall over the kernel arguments
     const int32_t **t_indices = reinterpret_cast<const int32_t **>(red + 2 * SEL_NW + 8);
+    int *sortw = reinterpret_cast<int *>(t_indices + PCG_MAX_REL);         // 4 + KIDX_MAX words: wait_sorted_keys
     if (threadIdx.x < PCG_MAX_REL) t_indices[threadIdx.x] = a.g.indices[threadIdx.x < (unsigned)a.g.n_rel ? threadIdx.x : 0];
     const bool leader = threadIdx.x == 0;
+    if (leader) sortw[0] = sortw[1] = 0;
     const int n16 = (int)a.w.counters[C_N16], n4 = (int)a.w.counters[C_N4];
     const int n1 = (int)a.w.counters[C_N1], n0 = (int)a.w.counters[C_N0], na = (int)a.w.counters[C_NA];
     const int n_wg = n16 + n4, n_items = n1 + n0 + (na + 3) / 4;
@@ -896,9 +1070,27 @@ __global__ void __launch_bounds__(SEL_NW *PCG_WAVE) __attribute__((amdgpu_waves_
     const bool pull = n_units > grid;                                      // otherwise unit = workgroup: no atomics at all
     const int shard = (int)blockIdx.x % SEL_SHARDS;
     uint32_t *head = a.w.heads + 16 * shard;                               // (64 bytes apart)
+    if (a.pending_clear && blockIdx.x == 0 && leader) a.pending_clear[0] = 0u;   // the launch before has applied the deferred update
     __syncthreads();
 
-    int u = (int)blockIdx.x, pending = 0, slot = 0;
+    // The train positives' sort, inside this launch and shared by its workgroups (sort_share), before the rows: only rows with
+    // minority picks ever wait for the result (wait_sorted_keys), and they are busy with their own distance keys meanwhile.
+    int u = (int)blockIdx.x;
+    if (a.n_sort > 0) {
+        const int helpers = a.n_sort * a.sort_slices;
+        if (u < helpers) {
+            if (a.stamps && leader && u == 0) a.stamps[(size_t)a.g.n_rel * a.B * 8 + 4] = wall_clock64();
+            __builtin_amdgcn_s_setprio(3);                                 // (the other workgroups of this CU are busy with their rows)
+            if (a.sort_slice_len <= 512) sort_share<512>(a, u, reinterpret_cast<uint64_t *>(lds), reinterpret_cast<int *>(hist), (int)threadIdx.x);
+            else sort_share<SORT_TILE>(a, u, reinterpret_cast<uint64_t *>(lds), reinterpret_cast<int *>(hist), (int)threadIdx.x);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        // the sorting workgroups start late: they take the LAST of the first `grid` units (short rows), the others move up -
+        // the longest rows (the first units) start at once
+        u = u < helpers ? grid - helpers + u : u - helpers;
+    }
+    int keys_ok = 0;                                                       // this wave has seen the sorted keys (wave-uniform)
+    int pending = 0, slot = 0;
     while (u < n_units) {
         // the unit after this one: behind a batch of single-wave items (a few microseconds) its claim is in flight while the
         // batch runs; behind a workgroup row (up to tens of microseconds) it is made afterwards - a busy workgroup must not sit
@@ -915,13 +1107,13 @@ __global__ void __launch_bounds__(SEL_NW *PCG_WAVE) __attribute__((amdgpu_waves_
         if (u < n_wg) {
             const int row = __builtin_amdgcn_readfirstlane(u < n16 ? a.w.q16[u] : a.w.q4[u - n16]);     // one row per workgroup: scalar
             const int d = a.w.recs[row].d;
-            if (d <= WG_KEYCAP) select_wg_row<true>(a, row, lds, hist, cand, red, tid);      // (longer rows: select_long_rows)
+            if (d <= WG_KEYCAP) select_wg_row<true>(a, row, lds, hist, cand, red, tid, keys_ok, sortw);      // (longer rows: select_long_rows)
         } else {
             const int j = wave < bs ? (u - n_wg) * bs + wave : n_items;
             if (j < n1) {
-                select_wave_row(a, __builtin_amdgcn_readfirstlane(a.w.q1[j]), area, lane);
+                select_wave_row(a, __builtin_amdgcn_readfirstlane(a.w.q1[j]), area, lane, keys_ok, sortw);
             } else if (j < n1 + n0) {
-                select_lane_row(a, __builtin_amdgcn_readfirstlane(a.w.q0[j - n1]), area, lane);
+                select_lane_row(a, __builtin_amdgcn_readfirstlane(a.w.q0[j - n1]), area, lane, keys_ok, sortw);
             } else if (j < n_items) {
                 select_four_short_rows(a, 4 * (j - n1 - n0), na, t_indices, lane);
             }
@@ -964,10 +1156,11 @@ __global__ void __launch_bounds__(LONG_NW *PCG_WAVE) select_long_rows(const Choo
     uint32_t *cursor = a.w.heads + 14, *done = a.w.heads + 13;
     const bool leader = threadIdx.x == 0;
     int u = (int)blockIdx.x, slot = 0;
+    int keys_ok = 1;                                                        // (select_rows, the launch before, has sorted them)
     while (u < n16) {
         const int row = __builtin_amdgcn_readfirstlane(a.w.q16[u]);
         if (a.w.recs[row].d > WG_KEYCAP) {                                  // (workgroup-uniform)
-            select_wg_row<false, LONG_NW>(a, row, lds, hist, cand, red, (int)threadIdx.x, gk);
+            select_wg_row<false, LONG_NW>(a, row, lds, hist, cand, red, (int)threadIdx.x, keys_ok, nullptr, gk);
         }
         __syncthreads();
         if (leader) claim[slot] = (int)gridDim.x + (int)atomicAdd(cursor, 1u);
@@ -985,7 +1178,8 @@ __global__ void __launch_bounds__(LONG_NW *PCG_WAVE) select_long_rows(const Choo
 }
 
 static size_t select_smem_bytes() {
-    return sizeof(uint32_t) * (WG_KEYCAP + HIST_WG + PCG_WAVE) + sizeof(int) * (2 * SEL_NW + 8) + sizeof(void *) * PCG_MAX_REL;   // (claim[2] = red[22..23])
+    return sizeof(uint32_t) * (WG_KEYCAP + HIST_WG + PCG_WAVE) + sizeof(int) * (2 * SEL_NW + 8) + sizeof(void *) * PCG_MAX_REL +   // (claim[2] = red[22..23])
+           sizeof(int) * (4 + KIDX_MAX);                                                                                            // sortw
 }
 
 int launch_select_rows(const ChooseArgs &a, hipStream_t st) {
@@ -994,13 +1188,31 @@ int launch_select_rows(const ChooseArgs &a, hipStream_t st) {
     static_assert(WAVE_AREA >= HIST_W + T1_CAP + PCG_WAVE, "a wave's LDS area: histogram | kept ids | candidates");
     static_assert(((WG_KEYCAP / SEL_NW + PCG_WAVE - 1) / PCG_WAVE) <= 32, "pass A keeps one bit per iteration in a uint32");
     static_assert((2 * SEL_NW + 8) % 2 == 0, "the pointer table behind red stays 8-byte aligned");
+    static_assert(SORT_TILE * 2 <= WG_KEYCAP && SEL_NW * PCG_WAVE <= HIST_WG, "the in-kernel sort's tile and partial counts fit the row paths' LDS");
     static int blocks = 0;
     if (!blocks) {                      // (tuning knob: PCG_SEL_BLOCKS = persistent workgroups, a multiple of 8, at most 3 per CU)
         const char *e = getenv("PCG_SEL_BLOCKS");
         const int v = e ? atoi(e) : 0;
         blocks = (v >= SEL_SHARDS && v <= SEL_BLOCKS && v % SEL_SHARDS == 0) ? v : SEL_BLOCKS;
     }
-    hipLaunchKernelGGL(select_rows, dim3(blocks), dim3(SEL_NW * PCG_WAVE), select_smem_bytes(), st, a);
+    ChooseArgs as = a;
+    if (a.n_sort > 0) {                      // how the sort is shared: slices per key group, keys per slice (>= 128)
+        if (a.n_sort > blocks) return PCG_E_ARG;
+        // (PCG_SORT_SLICES: tuning knob.  More slices = fewer compares per workgroup, but accumulator atomics and a ticket hop,
+        //  and more workgroups that start on their rows late; measured on the YelpChi-like batch: see DESIGN.md)
+        static int knob = -1;
+        if (knob < 0) {
+            const char *e = getenv("PCG_SORT_SLICES");
+            knob = e ? atoi(e) : 0;
+        }
+        int slices = knob > 0 ? knob : 4;
+        if (slices > blocks / a.n_sort) slices = blocks / a.n_sort;
+        const int most = (a.g.n_pos + 127) / 128;
+        slices = slices > most ? most : slices;
+        as.sort_slices = slices < 1 ? 1 : slices;
+        as.sort_slice_len = (a.g.n_pos + as.sort_slices - 1) / as.sort_slices;
+    }
+    hipLaunchKernelGGL(select_rows, dim3(blocks), dim3(SEL_NW * PCG_WAVE), select_smem_bytes(), st, as);
     PCG_LAUNCH_CHECK();
     if (a.g.max_degree > WG_KEYCAP) {        // rows too long for the LDS keys: their own launch (hub-heavy graphs only)
         const int64_t per_wg = a.g.max_degree;
@@ -1008,7 +1220,10 @@ int launch_select_rows(const ChooseArgs &a, hipStream_t st) {
         nb = nb < LONG_BLOCKS ? nb : LONG_BLOCKS;
         if (nb < 1) return PCG_E_ARG;
         const size_t long_smem = sizeof(uint32_t) * (WG_KEYCAP + 4 * LONG_NW * PCG_WAVE + PCG_WAVE) + sizeof(int) * (2 * LONG_NW + 8);
-        hipLaunchKernelGGL(select_long_rows, dim3((int)nb), dim3(LONG_NW * PCG_WAVE), long_smem, st, a, per_wg);
+        ChooseArgs al = a;                   // (the keys are sorted by now: nothing to sort, nothing to wait for)
+        al.n_sort = 0;
+        al.pending_clear = nullptr;
+        hipLaunchKernelGGL(select_long_rows, dim3((int)nb), dim3(LONG_NW * PCG_WAVE), long_smem, st, al, per_wg);
         PCG_LAUNCH_CHECK();
     }
     return PCG_OK;

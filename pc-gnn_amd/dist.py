@@ -481,7 +481,7 @@ class DistributedPCGNN:
         check(lib.pcg_gather_lists(_p(g.X), g.feat_dim, g.X.stride(0), g.X.shape[0], g.R * B, _p(self.cnt), g.desc_ref(), B, _p(ws.buf),
                                    ws.list_capacity, _p(agg), agg.stride(1), _p(ws.status), st), "pcg_gather_lists")
         check(lib.pcg_train_dense(g.desc_ref(), _p(self.theta), None, None, self.E, _p(ids_local), _p(labels), B, _p(agg),
-                                  agg.stride(1), _p(self.cnt), _p(ws.buf), ws.list_capacity, float(c["alpha"]),
+                                  agg.stride(1), _p(self.cnt), _p(ws.buf), None, ws.list_capacity, float(c["alpha"]),
                                   1.0 / (B * self.world), _p(self.logits), _p(self.center), None, _p(self.row_loss),
                                   _p(self.slabs), _p(self.step_counter), None, c["lr"], 0.9, 0.999, 1e-8, c["weight_decay"], 0,
                                   st), "pcg_train_dense")

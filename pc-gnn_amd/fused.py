@@ -1,14 +1,16 @@
 """Whole-step driver: every launch of one PC-GNN train step, back to back on one
-stream, no torch ops and no host synchronisation in between - five launches:
+stream, no torch ops and no host synchronisation in between - four launches:
 
-    front_a [scores || plan 1 || train-pos keys || Adam of the previous step's gradient (all but the label classifier)]
-    front_b [train-pos sort || plan 2]
-    select_rows -> gather_chunks
+    scores  [score pass || train-pos keys || Adam of the previous step's gradient (all but the label classifier)]
+    select_rows [the train positives' sort by its first workgroups || every row's selection] -> gather_chunks
     dense_step [sums of multi-chunk rows, forward, loss, backward partials, Adam of the label classifier]
 
-(``pcg_step_front_train`` / ``pcg_choose_gather_planned`` / ``pcg_train_dense``); a deferred update is flushed
-(``pcg_adam_flush``) before any public call returns unless the caller asks otherwise, so the parameters a caller
-sees are always complete.  The same sequence is captured into hipGraphs (``torch.cuda.CUDAGraph``) - per batch, or a
+(``pcg_step_scores_train`` / ``pcg_choose_gather_planned`` / ``pcg_train_dense``).  The PLAN of a batch (row records, list
+offsets, tier queues, the gather's chunk table) depends only on the batch's ids, labels and the CSR degrees - not on any
+parameter - so it is not part of a step: ``pcg_plan_batches`` plans every batch of an epoch in ONE launch right after the
+sampler (one plan slot per batch; the selection list and the partial sums - the data part - are shared).  A deferred Adam
+update is flushed (``pcg_adam_flush``) before any public call returns unless the caller asks otherwise, so the parameters a
+caller sees are always complete.  The same sequence is captured into hipGraphs (``torch.cuda.CUDAGraph``) - per batch, or a
 whole epoch in one - so that a step costs no host work at all.
 
 The model's parameters are re-pointed into ONE flat f32 buffer (order: see
@@ -28,6 +30,16 @@ from .graph import DeviceGraph
 from .model import PCALayer
 
 _p = ops._p
+
+
+def default_list_capacity(g: DeviceGraph, B: int, max_list_bytes: int = 8 << 30):
+    """Worst case of the graph for a batch of B (every centre being the largest hub), clipped to ``max_list_bytes``:
+    kept <= deg, minority m = int(ceil(deg / 2) * rho) <= 2 * deg for rho <= 4 (and <= n_pos), +1 self.
+    Returns (entries, clipped)."""
+    per_row = g.max_degree + min(2 * max(g.max_degree, 1), g.n_pos) + 1
+    worst = per_row * g.R * max(B, 1)
+    cap = min(worst, max_list_bytes // 4, (1 << 31) - 1)
+    return int(max(cap, 1)), cap < worst
 
 
 class FusedPCGNN:
@@ -68,73 +80,105 @@ class FusedPCGNN:
         self.v = torch.zeros_like(self.theta)
         self.step_counter = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self.grad = torch.zeros_like(self.theta)
-        self.sync = torch.zeros(4, dtype=torch.int32, device=self.dev)    # [ticket, update pending, its slab count, -]
+        # [ticket of the dense kernel, update pending, its slab count, group counter of the select kernel's in-kernel sort | its
+        #  rank accumulators and group tickets]
+        self.sync = torch.zeros(int(lib.pcg_sync_words_count()), dtype=torch.int32, device=self.dev)
         self.n_rest = int(lib.pcg_dense_param_offset(self.F, self.E, self.R, 3, 0))   # parameters before the label classifier
 
-        self.list_capacity = list_capacity      # entries of every workspace's selection list (None: worst case of the graph)
-        self.status = torch.zeros(1, dtype=torch.int32, device=self.dev)   # ONE device status word for all workspaces
+        self._list_capacity_arg = list_capacity  # entries of the selection list (None: worst case of the graph)
+        self.status = torch.zeros(1, dtype=torch.int32, device=self.dev)   # ONE device status word
         self._graphs = {}
         self._ep_graphs = {}
+        self._ep_ids = None
+        self._ep_plans = None
         self._alloc(max_batch)
         self._prof = None          # bench.py: list of (start, end) events around the choose+aggregate launch
         self.last_counts = None
+        thr, rhos = ops._host_arrays(g, self.thresholds, self.rho)
+        self._thr, self._rhos = thr, rhos
 
     # ------------------------------------------------------------------
     def _alloc(self, B: int):
-        g, dev = self.g, self.dev
+        g, dev, lib = self.g, self.dev, self.lib
         if torch.cuda.is_current_stream_capturing():
             raise _lib.PcgnnLibraryError("batch larger than max_batch inside a graph capture: allocate before capturing")
         # every captured graph holds raw pointers into the buffers replaced below
         self._graphs.clear()
         self._ep_graphs.clear()
+        self._ep_plans = None
         self.maxB = B
+        if self._list_capacity_arg is None:
+            self.list_capacity, self.clipped = default_list_capacity(g, B)
+        else:
+            self.list_capacity, self.clipped = int(max(self._list_capacity_arg, 1)), False
         self.s0 = torch.empty(g.n_nodes, dtype=torch.float32, device=dev)
-        self.keys = torch.empty(self.lib.pcg_pos_sort_capacity(g.n_pos), dtype=torch.int64, device=dev)
-        self._ws_by_b = {B: ops.ChooseWorkspace(g, B, self.list_capacity, status=self.status)}
+        self.keys = torch.empty(lib.pcg_pos_sort_capacity(g.n_pos), dtype=torch.int64, device=dev)
+        nbytes = lib.pcg_choose_data_bytes(g.desc_ref(), B, self.list_capacity)
+        if nbytes < 0:
+            raise _lib.PcgnnLibraryError("pcg_choose_data_bytes rejected the arguments")
+        self.data = torch.zeros(int(nbytes), dtype=torch.uint8, device=dev)     # list | partial sums | key scratch: shared by every plan
+        self._plans = {}                                                        # batch size -> a single plan slot (calls outside an epoch)
         self.agg = torch.empty(g.R, B, g.feat_dim, dtype=torch.float32, device=dev)
         self.cnt = torch.empty(g.R, B, dtype=torch.int32, device=dev)
         self.logits = torch.empty(B, 2, dtype=torch.float32, device=dev)
         self.center = torch.empty(B, 2, dtype=torch.float32, device=dev)
         self.row_loss = torch.zeros(B, dtype=torch.float32, device=dev)
-        self.slabs = torch.empty(self.lib.pcg_dense_n_tiles(B), self.n_params, dtype=torch.float32, device=dev)
+        self.slabs = torch.empty(lib.pcg_dense_n_tiles(B), self.n_params, dtype=torch.float32, device=dev)
         self.ids_buf = torch.zeros(B, dtype=torch.int32, device=dev)
         self.lab_buf = torch.zeros(B, dtype=torch.int32, device=dev)
 
     def _stream(self):
         return ops._stream(self.dev)
 
+    def _plan_bytes(self, B):
+        n = self.lib.pcg_choose_plan_bytes(self.g.desc_ref(), B, self.list_capacity)
+        if n < 0:
+            raise _lib.PcgnnLibraryError("pcg_choose_plan_bytes rejected the arguments")
+        return int(n)
+
+    def _plan_slot(self, B) -> torch.Tensor:
+        """the plan slot of calls that are not part of a staged epoch (one per batch size: the layout depends on it)"""
+        buf = self._plans.get(B)
+        if buf is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.PcgnnLibraryError("a new batch size inside a graph capture: warm up before capturing")
+            buf = self._plans[B] = torch.zeros(self._plan_bytes(B), dtype=torch.uint8, device=self.dev)
+        return buf
+
     # ------------------------------------------------------------------
+    def _enqueue_plan(self, ids, labels, n_total, B, plans: torch.Tensor, stride: int, train_flag, bump_counter=None):
+        """the plans of the batches ids[s * B : (s + 1) * B] (s < ceil(n_total / B)), one launch"""
+        _lib.check(self.lib.pcg_plan_batches(
+            self.g.desc_ref(), _p(ids), _p(labels if train_flag else None), n_total, B, self._thr, self._rhos, 1 if train_flag else 0, 0,
+            _p(plans), stride, self.list_capacity, _p(self.status), _p(bump_counter), self._stream()), "pcg_plan_batches")
+
+    def _enqueue_plan_one(self, ids, labels, B, train_flag) -> int:
+        """plan of ONE batch into this batch size's own slot; returns the slot's address"""
+        slot = self._plan_slot(B)
+        self._enqueue_plan(ids, labels, B, B, slot, slot.numel(), train_flag)
+        return slot.data_ptr()
+
     def _enqueue_scores(self, train_flag):
-        """label-aware score table + per-step sort of the train positives."""
+        """label-aware score table + per-step sort of the train positives (the calls of their own: evaluation, parity)."""
         g = self.g
         ops.score_table(g, self.w_clf, self.b_clf, out=self.s0)
         return ops.pos_sort(g, self.s0, self.keys) if (train_flag and g.n_pos) else None
 
-    def _ws(self, B):
-        ws = self._ws_by_b.get(B)
-        if ws is None:      # the workspace layout depends on the batch size: one per size
-            ws = self._ws_by_b[B] = ops.ChooseWorkspace(self.g, B, self.list_capacity, status=self.status)
-        return ws
-
-    def _enqueue_front(self, ids, labels, B, train_flag):
-        """scores + train-pos sort + this batch's plan in two launches (pcg_step_front)."""
+    def _enqueue_scores_train(self):
+        """the front of a training step: score pass || train-pos keys (unsorted) || the previous step's deferred Adam update."""
         g = self.g
-        return ops.step_front(g, self.w_clf, self.b_clf, self.s0, self.keys if (train_flag and g.n_pos) else None,
-                              ids, labels if train_flag else None, self.thresholds, self.rho, train_flag, self._ws(B))
-
-    def _enqueue_front_train(self, ids, labels, B):
-        """the front of a training step with the previous step's deferred Adam update beside the score pass."""
-        g, ws = self.g, self._ws(B)
-        thr, rhos = ops._host_arrays(g, self.thresholds, self.rho)
         b1, b2 = self.betas
-        _lib.check(self.lib.pcg_step_front_train(
+        _lib.check(self.lib.pcg_step_scores_train(
             g.desc_ref(), _p(self.theta), _p(self.m), _p(self.v), self.E, _p(self.s0), _p(self.keys) if g.n_pos else None,
-            _p(ids), _p(labels), B, thr, rhos, 0, _p(ws.buf), ws.list_capacity, _p(ws.status), _p(self.slabs),
-            _p(self.step_counter), _p(self.sync), self.lr, b1, b2, self.eps, self.wd, self._stream()), "pcg_step_front_train")
+            _p(self.slabs), _p(self.step_counter), _p(self.sync), self.lr, b1, b2, self.eps, self.wd, self._stream()),
+            "pcg_step_scores_train")
         return self.keys if g.n_pos else None
 
-    def _enqueue_choose(self, ids, labels, B, keys, train_flag, planned=False, combine=True):
-        """select + gather (+ combine unless the dense kernel will add up the partial sums itself)."""
+    def _enqueue_choose(self, ids, labels, B, keys, train_flag, plan: int, sort_in_kernel: bool):
+        """select + gather over the batch's plan (rows of several chunks are left as partial sums for the dense kernel).
+        sort_in_kernel: the launch follows ``_enqueue_scores_train`` - `keys` holds this step's UNSORTED train-pos keys (the
+        select kernel sorts them itself unless there are too many: then they are sorted already) and the launch clears the
+        "deferred update pending" word."""
         g = self.g
         agg = self.agg.view(-1)[:g.R * B * g.feat_dim].view(g.R, B, g.feat_dim)
         cnt = self.cnt.view(-1)[:g.R * B].view(g.R, B)
@@ -142,47 +186,29 @@ class FusedPCGNN:
         if timed:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        if combine:
-            ops.choose_aggregate(g, ids, labels if train_flag else None, self.s0, keys, self.thresholds, self.rho,
-                                 train_flag, ws=self._ws(B), agg=agg, cnt=cnt, planned=planned)
-        else:
-            assert planned
-            ws = self._ws(B)
-            thr, rhos = ops._host_arrays(g, self.thresholds, self.rho)
-            _lib.check(self.lib.pcg_choose_gather_planned(
-                g.desc_ref(), _p(ids), _p(labels if train_flag else None), B, _p(self.s0), None, _p(keys), thr, rhos,
-                1 if train_flag else 0, 0, _p(agg), agg.stride(-2), _p(cnt), _p(ws.buf), ws.list_capacity, _p(ws.status),
-                self._stream()), "pcg_choose_gather_planned")
+        _lib.check(self.lib.pcg_choose_gather_planned(
+            g.desc_ref(), _p(ids), _p(labels if train_flag else None), B, _p(self.s0), None, _p(keys), self._thr, self._rhos,
+            1 if train_flag else 0, 0, _p(agg), agg.stride(-2), _p(cnt), _p(self.data), C.c_void_p(plan), self.list_capacity,
+            _p(self.status), _p(self.sync) if sort_in_kernel else None, self._stream()), "pcg_choose_gather_planned")
         if timed:
             ev[1].record()
             self._prof.append(ev)
         self.last_counts = cnt
         return agg, cnt
 
-    def _enqueue_sample(self, ids, labels, B, train_flag):
-        """score table + train-pos sort + plan (two launches), then select + aggregate, for one batch (views sized to B)."""
-        keys = self._enqueue_front(ids, labels, B, train_flag)
-        return self._enqueue_choose(ids, labels, B, keys, train_flag, planned=True)
-
-    def _enqueue_dense(self, ids, labels, B, agg, train: bool, combined=None):
-        g = self.g
-        _lib.check(self.lib.pcg_dense_step(
-            g.desc_ref(), _p(self.theta), self.E, _p(ids), _p(labels), B, _p(agg), agg.stride(1), self.lambda_1,
-            1.0 / (B * self.scale), _p(self.logits), _p(self.center), _p(combined),
-            _p(self.row_loss) if labels is not None else None, _p(self.slabs) if train else None,
-            _p(self.step_counter) if train else None, self._stream()), "pcg_dense_step")
-
-    def _enqueue_tail(self, ids, labels, B, agg, train: bool, combined=None):
+    def _enqueue_tail(self, ids, labels, B, agg, plan: int, train: bool, combined=None, adam_clf: Optional[bool] = None):
         """dense tail reading the gather's partial sums (no combine launch); training: + the label classifier's Adam
-        in the same launch, the update of the other parameters left pending (flush() or the next front applies it)."""
-        g, ws = self.g, self._ws(B)
+        in the same launch, the update of the other parameters left pending (flush() or the next front applies it).
+        adam_clf=False (training): gradient slabs only - the caller reduces / all-reduces them itself."""
+        g = self.g
         cnt = self.cnt.view(-1)[:g.R * B]
         b1, b2 = self.betas
+        adam_clf = train if adam_clf is None else adam_clf
         _lib.check(self.lib.pcg_train_dense(
             g.desc_ref(), _p(self.theta), _p(self.m), _p(self.v), self.E, _p(ids), _p(labels), B, _p(agg), agg.stride(1),
-            _p(cnt), _p(ws.buf), ws.list_capacity, self.lambda_1, 1.0 / (B * self.scale), _p(self.logits), _p(self.center),
-            _p(combined), _p(self.row_loss) if labels is not None else None, _p(self.slabs) if train else None,
-            _p(self.step_counter) if train else None, _p(self.sync), self.lr, b1, b2, self.eps, self.wd, 1 if train else 0,
+            _p(cnt), _p(self.data), C.c_void_p(plan), self.list_capacity, self.lambda_1, 1.0 / (B * self.scale), _p(self.logits),
+            _p(self.center), _p(combined), _p(self.row_loss) if labels is not None else None, _p(self.slabs) if train else None,
+            _p(self.step_counter) if train else None, _p(self.sync), self.lr, b1, b2, self.eps, self.wd, 1 if adam_clf else 0,
             self._stream()), "pcg_train_dense")
 
     def flush(self):
@@ -192,11 +218,11 @@ class FusedPCGNN:
             _p(self.theta), _p(self.m), _p(self.v), _p(self.slabs), 0, self.n_params, self.n_rest, _p(self.step_counter),
             _p(self.sync), self.lr, b1, b2, self.eps, self.wd, self._stream()), "pcg_adam_flush")
 
-    def _enqueue_step(self, ids, labels, B, defer: bool):
-        """the five launches of one training step (+ the flush unless deferred)."""
-        keys = self._enqueue_front_train(ids, labels, B)
-        agg, _ = self._enqueue_choose(ids, labels, B, keys, True, planned=True, combine=False)
-        self._enqueue_tail(ids, labels, B, agg, True)
+    def _enqueue_step(self, ids, labels, B, plan: int, defer: bool):
+        """the four launches of one training step over an existing plan (+ the flush unless deferred)."""
+        keys = self._enqueue_scores_train()
+        agg, _ = self._enqueue_choose(ids, labels, B, keys, True, plan, sort_in_kernel=True)
+        self._enqueue_tail(ids, labels, B, agg, plan, True)
         if not defer:
             self.flush()
 
@@ -209,13 +235,21 @@ class FusedPCGNN:
             _p(self.step_counter), self.lr, b1, b2, self.eps, self.wd, _p(self.grad) if want_grad else None,
             1 if apply else 0, self._stream()), "pcg_adam_step")
 
+    def _enqueue_grad_slabs(self, ids, labels, B):
+        """plan, scores, sort, select, gather, dense forward + backward partials: the gradient is left in the slabs (no Adam)."""
+        plan = self._enqueue_plan_one(ids, labels, B, True)
+        keys = self._enqueue_scores(True)
+        agg, _ = self._enqueue_choose(ids, labels, B, keys, True, plan, sort_in_kernel=False)
+        self._enqueue_tail(ids, labels, B, agg, plan, True, adam_clf=False)
+
     # ------------------------------------------------------------------
-    def train_step(self, ids: torch.Tensor, labels: torch.Tensor, allreduce=None, defer: bool = False):
+    def train_step(self, ids: torch.Tensor, labels: torch.Tensor, allreduce=None, defer: bool = False, plan: Optional[int] = None):
         """zero_grad + loss + backward + Adam step for one batch (model_handler.py:149-153).
         ids / labels: int32 device tensors.  Nothing is returned and nothing syncs;
         ``last_loss()`` reads the batch loss afterwards.  ``allreduce(flat_grad)`` (data-parallel
         ranks) is called between the gradient reduction and the Adam update.  ``defer``: leave the Adam update of
-        everything but the label classifier to the next step's front (or ``flush()``) - inside an epoch."""
+        everything but the label classifier to the next step's front (or ``flush()``) - inside an epoch.
+        ``plan``: address of this batch's plan slot if it has been planned already (a staged epoch); else it is planned here."""
         B = ids.numel()
         if B == 0:
             return
@@ -224,20 +258,21 @@ class FusedPCGNN:
             self._alloc(B)
         self._lastB = B
         if allreduce is None:
-            self._enqueue_step(ids, labels, B, defer)
+            if plan is None:
+                plan = self._enqueue_plan_one(ids, labels, B, True)
+            self._enqueue_step(ids, labels, B, plan, defer)
             return
         # data-parallel ranks: gradient of the local batch -> all-reduce -> the same Adam on every rank
         self.flush()
-        agg, _ = self._enqueue_sample(ids, labels, B, True)
-        self._enqueue_dense(ids, labels, B, agg, True)
+        self._enqueue_grad_slabs(ids, labels, B)
         self._enqueue_adam(B, apply=False, want_grad=True)
         allreduce(self.grad)
         self._enqueue_adam(B, apply=True, from_grad=True)
 
     def train_step_graph(self, ids: torch.Tensor, labels: torch.Tensor, timed: bool = False):
         """Same as train_step through captured hipGraphs (one set per batch size): one graph launch
-        per step.  timed=True (bench.py, every Nth step) replays the step as [scores graph] ->
-        eager choose+aggregate bracketed by HIP events -> [dense+Adam graph]; same kernels, same order."""
+        per step.  timed=True (bench.py, every Nth step) replays the step as [plan + scores graph] ->
+        choose+aggregate bracketed by HIP events -> [dense+Adam graph]; same kernels, same order."""
         B = ids.numel()
         if B == 0:
             return
@@ -263,7 +298,7 @@ class FusedPCGNN:
             gr["full"].replay()
 
     def _capture_graphs(self, fns, warm=None):
-        """Warm up (kernel attributes, per-batch-size workspaces: nothing may allocate inside a capture) on a side
+        """Warm up (kernel attributes, per-batch-size plan slots: nothing may allocate inside a capture) on a side
         stream, capture every fn into a hipGraph of its own, and put the optimizer state back.  A deferred Adam update
         of real steps is applied first (the saved state then includes it); the warm-up's own is flushed and undone."""
         self.flush()
@@ -292,16 +327,18 @@ class FusedPCGNN:
         keys = self.keys if self.g.n_pos else None
         g = self.g
         agg = self.agg.view(-1)[:g.R * B * g.feat_dim].view(g.R, B, g.feat_dim)
+        plan = self._plan_slot(B).data_ptr()
 
         def pre():
-            self._enqueue_front_train(ids, lab, B)
+            self._enqueue_plan_one(ids, lab, B, True)
+            self._enqueue_scores_train()
 
         def post():
-            self._enqueue_tail(ids, lab, B, agg, True)
+            self._enqueue_tail(ids, lab, B, agg, plan, True)
             self.flush()
 
         def choose():
-            self._enqueue_choose(ids, lab, B, keys, True, planned=True, combine=False)
+            self._enqueue_choose(ids, lab, B, keys, True, plan, sort_in_kernel=True)
 
         def full():
             pre()
@@ -313,19 +350,49 @@ class FusedPCGNN:
         self._graphs[B] = graphs
         return graphs
 
-    # -- whole-epoch path: ids / labels of an epoch live in static buffers, one graph per batch slot ------
+    # -- whole-epoch path: ids / labels of an epoch live in static buffers, one plan slot and one graph per batch ------
+    def stage_epoch(self, n: int, batch_size: int):
+        """Static id / label buffers and plan slots of an epoch of n picks (the ids are filled by begin_epoch or by a
+        sampler; ``plan_staged()`` must follow before any of the epoch's steps runs)."""
+        if self._ep_ids is None or self._ep_ids.numel() < n:
+            self._ep_ids = torch.zeros(n, dtype=torch.int32, device=self.dev)
+            self._ep_lab = torch.zeros(n, dtype=torch.int32, device=self.dev)
+            self._ep_graphs.clear()
+        if batch_size > self.maxB:
+            self.flush()
+            self._alloc(batch_size)
+        nb = -(-n // batch_size)
+        stride = self._plan_bytes(batch_size)
+        if self._ep_plans is None or getattr(self, "_ep_stride", 0) != stride or self._ep_plans.numel() < nb * stride:
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.PcgnnLibraryError("stage_epoch with a new shape inside a graph capture")
+            self._ep_plans = torch.zeros(nb * stride, dtype=torch.uint8, device=self.dev)
+            self._ep_stride = stride
+            self._ep_graphs.clear()
+        self._ep_n, self._ep_bs = n, batch_size
+        return self._ep_ids[:n], self._ep_lab[:n]
+
+    def plan_staged(self, bump_counter: Optional[torch.Tensor] = None):
+        """Plan every batch of the staged epoch: ONE launch (after the sampler, before the epoch's first step).
+        bump_counter: the sampler's device epoch counter, incremented by this launch."""
+        self._enqueue_plan(self._ep_ids, self._ep_lab, self._ep_n, self._ep_bs, self._ep_plans, self._ep_stride, True, bump_counter)
+
+    def _ep_plan(self, b: int) -> int:
+        return self._ep_plans.data_ptr() + b * self._ep_stride
+
     def begin_epoch(self, ids: torch.Tensor, labels: torch.Tensor, batch_size: int):
-        """Stage an epoch's (already shuffled) ids and labels; afterwards ``epoch_step(b)`` is exactly one
-        graph launch - no copies, no indexing kernels (model_handler.py:142-148 slices a Python list here)."""
+        """Stage an epoch's (already shuffled) ids and labels and plan its batches; afterwards ``epoch_step(b)`` is exactly
+        one graph launch - no copies, no indexing kernels (model_handler.py:142-148 slices a Python list here)."""
         n = ids.numel()
         ep_ids, ep_lab = self.stage_epoch(n, batch_size)
         ep_ids.copy_(ids)
         ep_lab.copy_(labels)
+        self.plan_staged()
 
     def epoch_step(self, b: int, defer: bool = False):
-        """Batch b of the staged epoch as one graph replay.  defer: as inside epoch_run - the Adam update of everything but
-        the label classifier is left to the next batch's front launch (the epoch's last batch flushes it), so the
-        parameters are complete only after the last batch or a flush()."""
+        """Batch b of the staged (and planned) epoch as one graph replay.  defer: as inside epoch_run - the Adam update of
+        everything but the label classifier is left to the next batch's front launch (the epoch's last batch flushes it), so
+        the parameters are complete only after the last batch or a flush()."""
         lo = b * self._ep_bs
         B = min(self._ep_bs, self._ep_n - lo)
         if B <= 0:
@@ -336,15 +403,15 @@ class FusedPCGNN:
         gr = self._ep_graphs.get(key)
         if gr is None:
             ids, lab = self._ep_ids[lo:lo + B], self._ep_lab[lo:lo + B]
-            gr = self._capture_graphs([lambda: self.train_step(ids, lab, defer=defer)])[0]
+            gr = self._capture_graphs([lambda: self.train_step(ids, lab, defer=defer, plan=self._ep_plan(b))])[0]
             self._ep_graphs[key] = gr
         gr.replay()
 
     def epoch_step_timed(self, b: int, eager: bool = True):
         """Batch b of the staged epoch with HIP events around the select + gather call (appended to ``_prof``): the same
         kernels in the same order as one step of ``epoch_run``, reading the staged ids in place (no copies, no label
-        gather).  eager: the five kernels launched one by one with the two event records between them (the host stays
-        ahead of the GPU, so the events bracket the two kernels and nothing else); otherwise three graphs - front | select +
+        gather).  eager: the four kernels launched one by one with the two event records between them (the host stays
+        ahead of the GPU, so the events bracket the two kernels and nothing else); otherwise three graphs - scores | select +
         gather | dense - whose launch latency lands inside the bracket."""
         lo = b * self._ep_bs
         B = min(self._ep_bs, self._ep_n - lo)
@@ -355,23 +422,22 @@ class FusedPCGNN:
         grs = self._ep_graphs.get(key)
         ids, lab = self._ep_ids[lo:lo + B], self._ep_lab[lo:lo + B]
         g = self.g
+        plan = self._ep_plan(b)
+        agg = self.agg.view(-1)[:g.R * B * g.feat_dim].view(g.R, B, g.feat_dim)
+        keys = self.keys if g.n_pos else None
+        last = lo + B >= self._ep_n               # the epoch's last batch: nothing follows that would apply the deferred update
         if eager:
-            agg = self.agg.view(-1)[:g.R * B * g.feat_dim].view(g.R, B, g.feat_dim)
-            keys = self.keys if g.n_pos else None
-            self._enqueue_front_train(ids, lab, B)
-            self._enqueue_choose(ids, lab, B, keys, True, planned=True, combine=False)     # (records the two events itself)
-            self._enqueue_tail(ids, lab, B, agg, True)
-            if lo + B >= self._ep_n:              # the epoch's last batch: nothing follows that would apply the deferred update
+            self._enqueue_scores_train()
+            self._enqueue_choose(ids, lab, B, keys, True, plan, sort_in_kernel=True)     # (records the two events itself)
+            self._enqueue_tail(ids, lab, B, agg, plan, True)
+            if last:
                 self.flush()
             self.last_counts = self.cnt.view(-1)[:g.R * B].view(g.R, B)
             return
         if grs is None:
-            agg = self.agg.view(-1)[:g.R * B * g.feat_dim].view(g.R, B, g.feat_dim)
-            keys = self.keys if g.n_pos else None
-            last = lo + B >= self._ep_n           # the epoch's last batch: nothing follows that would apply the deferred update
-            parts = (lambda: self._enqueue_front_train(ids, lab, B),
-                     lambda: self._enqueue_choose(ids, lab, B, keys, True, planned=True, combine=False),
-                     lambda: (self._enqueue_tail(ids, lab, B, agg, True), self.flush() if last else None))
+            parts = (lambda: self._enqueue_scores_train(),
+                     lambda: self._enqueue_choose(ids, lab, B, keys, True, plan, sort_in_kernel=True),
+                     lambda: (self._enqueue_tail(ids, lab, B, agg, plan, True), self.flush() if last else None))
             grs = self._capture_graphs(list(parts))
             self._ep_graphs[key] = grs
         grs[0].replay()
@@ -384,35 +450,36 @@ class FusedPCGNN:
         self.last_counts = self.cnt.view(-1)[:g.R * B].view(g.R, B)
         grs[2].replay()
 
-    def stage_epoch(self, n: int, batch_size: int):
-        """Static id / label buffers of an epoch of n picks (filled by begin_epoch or by a sampler)."""
-        if getattr(self, "_ep_ids", None) is None or self._ep_ids.numel() < n:
-            self._ep_ids = torch.zeros(n, dtype=torch.int32, device=self.dev)
-            self._ep_lab = torch.zeros(n, dtype=torch.int32, device=self.dev)
-            self._ep_graphs.clear()
-        self._ep_n, self._ep_bs = n, batch_size
-        return self._ep_ids[:n], self._ep_lab[:n]
-
-    def epoch_run(self, n_steps: Optional[int] = None, sample=None):
+    def epoch_run(self, n_steps: Optional[int] = None, sample=None, bump_counter: Optional[torch.Tensor] = None,
+                  flush: bool = True):
         """All batches of the staged epoch as ONE graph launch: the host latency between two graph launches (~8 us)
         is paid once per epoch instead of once per batch.  ``sample()``, if given, is enqueued (and captured) first: it
-        fills the staged id / label buffers on the device (pick + shuffle + labels), so a replay is a whole new epoch."""
+        fills the staged id / label buffers on the device (pick + shuffle + labels), so a replay is a whole new epoch;
+        the plans of all batches follow (which also bumps ``bump_counter``, the sampler's epoch number).
+        flush=False: the last batch's deferred Adam update (everything but the label classifier) is left to whatever comes
+        next - the next epoch's first front launch applies it, any other public call flushes it first."""
         nb = -(-self._ep_n // self._ep_bs)
         n_steps = nb if n_steps is None else min(n_steps, nb)
-        key = ("epoch", self._ep_n, self._ep_bs, n_steps, sample is not None)
+        key = ("epoch", self._ep_n, self._ep_bs, n_steps, sample is not None, None if bump_counter is None else bump_counter.data_ptr(),
+               flush)
         gr = self._ep_graphs.get(key)
         if gr is None:
             def run():
                 for b in range(n_steps):
                     lo = b * self._ep_bs
                     B = min(self._ep_bs, self._ep_n - lo)
-                    self.train_step(self._ep_ids[lo:lo + B], self._ep_lab[lo:lo + B], defer=True)
-                self.flush()
+                    self.train_step(self._ep_ids[lo:lo + B], self._ep_lab[lo:lo + B], defer=True, plan=self._ep_plan(b))
+                if flush:
+                    self.flush()
+            def warm_run():                      # (the warm-up leaves the staged ids - and the epoch counter - as they are)
+                self.plan_staged()
+                run()
             def sampled_run():
                 if sample is not None:
                     sample()
+                self.plan_staged(bump_counter)
                 run()
-            gr = self._capture_graphs([sampled_run], warm=[run])[0]   # (the warm-up leaves the staged ids as they are)
+            gr = self._capture_graphs([sampled_run], warm=[warm_run])[0]
             self._ep_graphs[key] = gr
         self._lastB = min(self._ep_bs, self._ep_n - (n_steps - 1) * self._ep_bs)
         gr.replay()
@@ -420,13 +487,22 @@ class FusedPCGNN:
 
     def check(self):
         """Raise if any batch since the last check did not fit its selection list (the kernels then select nothing and
-        only set the device status word).  Reads one word: synchronises - call it where the host waits anyway
-        (``last_loss``, the end of an evaluation pass or of an epoch, after a timed region)."""
+        only set the device status word), or a list named a row outside its table, or an in-kernel wait ran out.  Reads one
+        word: synchronises - call it where the host waits anyway (``last_loss``, the end of an evaluation pass or of an epoch,
+        after a timed region)."""
         st = int(self.status.item())
+        if st == 0:
+            return
+        self.status.zero_()
+        what = []
         if st & _lib.PCG_ST_SEL_OVERFLOW:
-            self.status.zero_()
-            raise _lib.PcgnnLibraryError("selection list overflow: a batch needed more list entries than the workspace "
-                                         "holds - raise FusedPCGNN(list_capacity=...)")
+            what.append("selection list overflow: a batch needed more list entries than the workspace holds - raise "
+                        "FusedPCGNN(list_capacity=...)")
+        if st & _lib.PCG_ST_LIST_ID_RANGE:
+            what.append("a selection list named a row outside the feature table")
+        if st & _lib.PCG_ST_SYNC_TIMEOUT:
+            what.append("the select kernel's wait for its own train-pos sort ran out")
+        raise _lib.PcgnnLibraryError("; ".join(what) or f"device status {st}")
 
     def last_loss(self) -> torch.Tensor:
         self.check()
@@ -437,9 +513,10 @@ class FusedPCGNN:
         """loss.backward() without the optimizer step: per-parameter gradients (parity tests)."""
         B = ids.numel()
         self.flush()
-        agg, _ = self._enqueue_sample(ids, labels, B, True)
-        self._enqueue_dense(ids, labels, B, agg, True)
-        self.step_counter -= 1                   # dense_step counted a step that is not taken
+        if B > self.maxB:
+            self._alloc(B)
+        self._enqueue_grad_slabs(ids, labels, B)
+        self.step_counter -= 1                   # the dense kernel counted a step that is not taken
         self._enqueue_adam(B, apply=False, want_grad=True)
         self._lastB = B
         out = {}
@@ -456,9 +533,10 @@ class FusedPCGNN:
         self.flush()
         if B > self.maxB:
             self._alloc(B)
-        keys = self._enqueue_front(ids, labels, B, train_flag)
-        agg, _ = self._enqueue_choose(ids, labels, B, keys, train_flag, planned=True, combine=False)
+        plan = self._enqueue_plan_one(ids, labels, B, train_flag)
+        keys = self._enqueue_scores(train_flag)
+        agg, _ = self._enqueue_choose(ids, labels, B, keys, train_flag, plan, sort_in_kernel=False)
         comb = torch.empty(B, self.E, dtype=torch.float32, device=self.dev) if want_combined else None
-        self._enqueue_tail(ids, None, B, agg, False, combined=comb)
+        self._enqueue_tail(ids, None, B, agg, plan, False, combined=comb)
         res = (self.logits[:B].clone(), self.center[:B].clone())
         return res + (comb,) if want_combined else res

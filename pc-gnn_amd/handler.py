@@ -73,14 +73,20 @@ class PCGNNTrainer:
     def start_epoch_staged(self) -> torch.Tensor:
         """pick + shuffle + label lookup in ONE launch (pcg_pick_shuffled), straight into the fused engine's epoch
         buffers; the epoch number lives on the device and is incremented by the call.  Returns the staged ids."""
-        ids, lab = self.fused.stage_epoch(self.pick_size, self.batch_size)
-        self.sampler.pick_shuffled(self.pick_size, ids, self.labels_i32, lab, epoch_counter=self._epoch_dev, bump=True)
+        ids = self._sample_staged()
+        self.fused.plan_staged(self._epoch_dev)      # every batch's plan, one launch; it also moves the epoch number on
         return ids
 
-    def run_epoch_one_graph(self) -> int:
-        """A whole epoch - pick, shuffle, labels and every batch's training step - as one graph launch."""
+    def _sample_staged(self) -> torch.Tensor:
+        ids, lab = self.fused.stage_epoch(self.pick_size, self.batch_size)
+        self.sampler.pick_shuffled(self.pick_size, ids, self.labels_i32, lab, epoch_counter=self._epoch_dev, bump=False)
+        return ids
+
+    def run_epoch_one_graph(self, flush: bool = True) -> int:
+        """A whole epoch - pick, shuffle, labels, every batch's plan and every batch's training step - as one graph launch.
+        flush=False: see FusedPCGNN.epoch_run (back-to-back epochs: the next one's first launch applies the last update)."""
         self.fused.stage_epoch(self.pick_size, self.batch_size)
-        self.fused.epoch_run(sample=self.start_epoch_staged)
+        self.fused.epoch_run(sample=self._sample_staged, bump_counter=self._epoch_dev, flush=flush)
         return self.pick_size
 
     def step(self, batch_ids: torch.Tensor, timed: bool = False) -> torch.Tensor:
@@ -256,7 +262,7 @@ class ModelHandler(object):
                 engine.stage_epoch(pick_size, args.batch_size)
                 engine.epoch_run(sample=lambda: sampler.pick_shuffled(pick_size, engine._ep_ids[:pick_size], labels_dev,
                                                                        engine._ep_lab[:pick_size], epoch_counter=epoch_dev,
-                                                                       bump=True))
+                                                                       bump=False), bump_counter=epoch_dev)
             else:
                 sampled = list(idx_train)                                                                # :132-133
                 random.shuffle(sampled)

@@ -139,11 +139,13 @@ def choose_select(g: DeviceGraph, nodes, labels, s0, pos_keys, thresholds, rho, 
     planned: ws already holds this batch's plan (step_front / step_front_a + _b)."""
     lib = _lib.load()
     thr, rhos = _host_arrays(g, thresholds, rho)
-    fn = lib.pcg_choose_select_planned if planned else lib.pcg_choose_select
-    _lib.check(fn(
-        g.desc_ref(), _p(nodes), _p(labels), nodes.numel(), _p(s0), _p(center_s0), _p(pos_keys), thr, rhos,
-        1 if train_flag else 0, 1 if add_self else 0, _p(cnt), _p(ws.buf), ws.list_capacity, _p(ws.status),
-        _stream(g.device)), "pcg_choose_select")
+    args = (g.desc_ref(), _p(nodes), _p(labels), nodes.numel(), _p(s0), _p(center_s0), _p(pos_keys), thr, rhos,
+            1 if train_flag else 0, 1 if add_self else 0, _p(cnt), _p(ws.buf))
+    rest = (ws.list_capacity, _p(ws.status), _stream(g.device))
+    if planned:
+        _lib.check(lib.pcg_choose_select_planned(*args, None, *rest), "pcg_choose_select_planned")
+    else:
+        _lib.check(lib.pcg_choose_select(*args, *rest), "pcg_choose_select")
 
 
 def aggregate_lists(g: DeviceGraph, X: torch.Tensor, B: int, ws: ChooseWorkspace, cnt: torch.Tensor, agg: torch.Tensor,

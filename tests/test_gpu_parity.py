@@ -776,13 +776,15 @@ def test_epoch_as_one_graph_equals_step_by_step(P):
     from pcgnn_amd.handler import PCGNNTrainer
     w = synth.make_workload("mini", 6000, 32, (4000, 30000, 90000), 0.12, seed=3)
     cfg = dict(engine="graph", batch_size=256, seed=5)
-    a, b, c = PCGNNTrainer(w, cfg, dev()), PCGNNTrainer(w, cfg, dev()), PCGNNTrainer(w, cfg, dev())
+    a, b, c, d = (PCGNNTrainer(w, cfg, dev()) for _ in range(4))
     b.fused.theta.copy_(a.fused.theta)
     c.fused.theta.copy_(a.fused.theta)
+    d.fused.theta.copy_(a.fused.theta)
     nb = a.batches_per_epoch()
     assert a.pick_size % a.batch_size != 0 and nb >= 3
     for ep in range(3):
         a.run_epoch_one_graph()
+        d.run_epoch_one_graph(flush=False)      # the last batch's update left to the next epoch's first launch (bench.py)
         ids = b.start_epoch_staged()
         for k in range(nb):
             sl = slice(k * b.batch_size, min((k + 1) * b.batch_size, b.pick_size))
@@ -795,13 +797,15 @@ def test_epoch_as_one_graph_equals_step_by_step(P):
                 c.fused.epoch_step_timed(k)
             else:
                 c.fused.epoch_step(k, defer=True)
+    d.fused.flush()
     torch.cuda.synchronize()
-    assert int(a._epoch_dev[0]) == int(b._epoch_dev[0]) == int(c._epoch_dev[0]) == 3
+    assert int(a._epoch_dev[0]) == int(b._epoch_dev[0]) == int(c._epoch_dev[0]) == int(d._epoch_dev[0]) == 3
     assert torch.equal(a.fused._ep_ids[:a.pick_size], b.fused._ep_ids[:b.pick_size])
     assert torch.equal(a.fused._ep_ids[:a.pick_size], c.fused._ep_ids[:c.pick_size])
     for name in ("theta", "m", "v", "step_counter"):
         assert torch.equal(getattr(a.fused, name), getattr(b.fused, name)), name
         assert torch.equal(getattr(a.fused, name), getattr(c.fused, name)), name + " (per-batch graphs, deferred Adam)"
+        assert torch.equal(getattr(a.fused, name), getattr(d.fused, name)), name + " (epoch graphs without the end-of-epoch flush)"
     assert torch.isfinite(a.fused.theta).all() and not torch.equal(a.fused.theta, torch.zeros_like(a.fused.theta))
 
 
@@ -884,6 +888,108 @@ def test_step_front_equals_separate_calls(P, B, train):
     assert torch.equal(s0_a, s0_c)
 
 
+@pytest.mark.parametrize("B,n_pos", [(300, 1500), (700, 5000), (64, 40)])
+def test_epoch_plans_and_in_kernel_sort_equal_separate_calls(P, B, n_pos):
+    """pcg_plan_batches (every batch of an "epoch" planned in one launch, one plan slot each, ONE shared data part) +
+    pcg_step_scores_train (scores and UNSORTED train-pos keys in one launch) + pcg_choose_gather_planned(sync_words) (the
+    select kernel sorts the keys itself, rows with minority picks wait for it) give bit for bit what pcg_score_table +
+    pcg_pos_sort + pcg_choose_aggregate give batch by batch: scores, sorted keys, row offsets, list entries, counts, and the
+    aggregated rows of every single-chunk row."""
+    import ctypes as C
+    from pcgnn_amd import _lib
+    lib = _lib.load()
+    ops = P.ops
+    _p = ops._p
+    n = 30000
+    hub_degs = [9000, 7000, 5000, 600, 300, 100, 3, 1]
+    X, labels, csr = hub_graph(5, n, hub_degs)
+    _, _, csrs2 = synth_graph(43, n, 32, (4,), 0.1)
+    csrs = [csr, csrs2[0]]
+    train_pos = np.flatnonzero(labels == 1)[:n_pos].tolist()
+    if len(train_pos) < n_pos:                      # (more positives than the labels hold: any distinct nodes will do)
+        train_pos = sorted(set(train_pos) | set(range(100, 100 + n_pos - len(train_pos))))
+    g = P.DeviceGraph(X, csrs, train_pos, dev())
+    F, E, R = 32, 16, 2
+    gen = torch.Generator().manual_seed(8)
+    W, b = torch.randn(2, F, generator=gen).cuda(), torch.randn(2, generator=gen).cuda()
+    n_params = int(lib.pcg_dense_n_params(F, E, R))
+    theta = torch.zeros(n_params, device=dev())
+    o_w, o_b = int(lib.pcg_dense_param_offset(F, E, R, 3, 0)), int(lib.pcg_dense_param_offset(F, E, R, 4, 0))
+    theta[o_w:o_w + 2 * F] = W.reshape(-1)
+    theta[o_b:o_b + 2] = b
+    m, v = torch.zeros_like(theta), torch.zeros_like(theta)
+    slabs = torch.zeros(4, n_params, device=dev())
+    step = torch.zeros(1, dtype=torch.int32, device=dev())
+    sync = torch.zeros(int(lib.pcg_sync_words_count()), dtype=torch.int32, device=dev())
+    sync[3] = 12345                                  # (pcg_step_scores_train must zero the arrival counter itself)
+    rs = np.random.RandomState(B)
+    n_total = 2 * B + B // 3                         # three batches, the last one shorter
+    nodes = np.concatenate([np.arange(len(hub_degs)), rs.randint(0, n, size=n_total - len(hub_degs))]).astype(np.int32)
+    rs.shuffle(nodes)
+    ids = torch.from_numpy(nodes).cuda()
+    lab = torch.from_numpy(labels[nodes].astype(np.int32)).cuda()
+    thr, rho = [0.5, 0.7], [0.5, 1.5]
+    thr_c, rho_c = ops._host_arrays(g, thr, rho)
+    cap = int(ops.sel_capacity(g, nodes, labels[nodes], thr, rho, True).reshape(R, -1)[:, :].sum()) + 64
+    status = torch.zeros(1, dtype=torch.int32, device=dev())
+    stride = int(lib.pcg_choose_plan_bytes(g.desc_ref(), B, cap))
+    n_slots = -(-n_total // B)
+    plans = torch.zeros(n_slots * stride, dtype=torch.uint8, device=dev())
+    data = torch.zeros(int(lib.pcg_choose_data_bytes(g.desc_ref(), B, cap)), dtype=torch.uint8, device=dev())
+    bump = torch.zeros(2, dtype=torch.int64, device=dev())
+    st = ops._stream(dev())
+    _lib.check(lib.pcg_plan_batches(g.desc_ref(), _p(ids), _p(lab), n_total, B, thr_c, rho_c, 1, 0, _p(plans), stride, cap, _p(status),
+                                    _p(bump), st), "pcg_plan_batches")
+    s0_b = torch.full((n,), float("nan"), device=dev())
+    keys_b = torch.zeros(int(lib.pcg_pos_sort_capacity(g.n_pos)), dtype=torch.int64, device=dev())
+    # separate calls (the reference for every slot)
+    s0_a = ops.score_table(g, W, b)
+    keys_a = ops.pos_sort(g, s0_a)
+    half = keys_a.numel() // 2
+    for s in range(n_slots):
+        sl = slice(s * B, min((s + 1) * B, n_total))
+        Bs = sl.stop - sl.start
+        ids_s, lab_s = ids[sl].contiguous(), lab[sl].contiguous()
+        ws_a = ops.ChooseWorkspace(g, Bs, cap)
+        agg_a, cnt_a = ops.choose_aggregate(g, ids_s, lab_s, s0_a, keys_a, thr, rho, True, ws=ws_a)
+        # the planned path: scores + unsorted keys, then select (sorting inside) + gather over slot s and the shared data part
+        keys_b.zero_()
+        _lib.check(lib.pcg_step_scores_train(g.desc_ref(), _p(theta), _p(m), _p(v), E, _p(s0_b), _p(keys_b), _p(slabs), _p(step), _p(sync),
+                                             0.01, 0.9, 0.999, 1e-8, 0.0, st), "pcg_step_scores_train")
+        agg_b = torch.full((R, Bs, F), float("nan"), device=dev())
+        cnt_b = torch.zeros(R, Bs, dtype=torch.int32, device=dev())
+        _lib.check(lib.pcg_choose_gather_planned(g.desc_ref(), _p(ids[sl]), _p(lab[sl]), Bs, _p(s0_b), None, _p(keys_b), thr_c, rho_c, 1, 0,
+                                                 _p(agg_b), F, _p(cnt_b), _p(data), C.c_void_p(plans.data_ptr() + s * stride), cap,
+                                                 _p(status), _p(sync), st), "pcg_choose_gather_planned")
+        torch.cuda.synchronize()
+        assert int(status.item()) == 0 and int(sync[3].item()) == (-(-g.n_pos // 64) if g.n_pos <= 16384 else 0)
+        assert int(sync[4:].abs().sum().item()) == 0, "rank accumulators and group tickets are left zero"
+        assert torch.equal(s0_a, s0_b)
+        assert torch.equal(keys_a[:half], keys_b[:half]), "the in-kernel sort"
+        assert torch.equal(cnt_a, cnt_b)
+        rows = R * Bs
+        off = lambda which: int(lib.pcg_choose_workspace_offset(g.desc_ref(), Bs, cap, which))
+        plan_s = plans[s * stride:(s + 1) * stride]
+        begin_a = ws_a.view(0, torch.int64, rows + 1)
+        begin_b = plan_s[off(0):off(0) + 8 * (rows + 1)].view(torch.int64)
+        assert torch.equal(begin_a, begin_b)
+        total = int(begin_a[-1])
+        len_b = plan_s[off(1):off(1) + 4 * rows].view(torch.int32)
+        assert torch.equal(ws_a.view(1, torch.int32, rows), len_b)
+        plan_bytes = int(lib.pcg_choose_plan_bytes(g.desc_ref(), Bs, cap))
+        lo = off(2) - plan_bytes
+        list_b = data[lo:lo + 4 * total].view(torch.int32)
+        list_a = ws_a.view(2, torch.int32, total)
+        # (only the entries in use are written: compare row by row over each row's length)
+        la, lb, bg, ln = list_a.cpu().numpy(), list_b.cpu().numpy(), begin_a.cpu().numpy(), len_b.cpu().numpy()
+        for row in range(rows):
+            assert np.array_equal(la[bg[row]:bg[row] + ln[row]], lb[bg[row]:bg[row] + ln[row]]), (s, row)
+        chunks = ws_a.view(3, torch.int32, rows + 1).cpu().numpy()
+        single = torch.from_numpy(np.diff(chunks) == 1).cuda().view(R, Bs)
+        assert single.any() and torch.equal(agg_a.view(torch.int32)[single], agg_b.view(torch.int32)[single])
+    assert int(bump[0].item()) == 1
+
+
 def test_fused_trajectory_tracks_oracle(P, case):
     """Four consecutive Adam steps: the HIP path's loss trajectory and parameters follow the CPU oracle's
     (independent implementation: Python sets + torch.sort + dense-mask mean + torch autograd + torch Adam)."""
@@ -926,7 +1032,7 @@ def test_list_overflow_is_reported_not_silent(P):
     # the same engine with room: no error, and the default capacity of this graph is not clipped
     tr.fused.train_step(ids, lab)
     assert np.isfinite(float(tr.fused.last_loss()))
-    assert not tr.fused._ws(256).clipped
+    assert not tr.fused.clipped
 
 
 def test_realloc_between_epoch_graphs(P):
