@@ -73,6 +73,9 @@ def parse():
                     "medians (SURVEY 8d); 0 = skip")
     ap.add_argument("--verify-batches", type=int, default=1, help="batches whose chosen sets are checked after the clock stops "
                     "(count law on every row, the oracle's sets on a strided sample); 0 = skip")
+    ap.add_argument("--prefetch", action="store_true", help="graph engine: sampler + plans of the NEXT epoch on a parallel branch of an "
+                    "epoch's graph (two buffer sets) instead of at the head of its own graph.  A/B switch, off: a forked hipGraph "
+                    "costs more per replay (~45 us) than the three launches it hides (~23 us per epoch): 62.2 vs 58.1 us/step")
     ap.add_argument("--engine", default=None, choices=["graph", "fused", "torch", "dp"],
                     help="graph: fused HIP step replayed from a hipGraph (default at 1 GPU); fused: same kernels "
                          "launched eagerly (default at N>1, gradient all-reduce in between); torch: torch dense tail")
@@ -143,6 +146,7 @@ def epoch_report(tr, n_epochs):
     as the reference sums it) - with HIP events before, between and after; medians over the epochs."""
     fz = tr.fused
     fz.stage_epoch(tr.pick_size, tr.batch_size)
+    fz.take_prefetched()                         # (an epoch prepared ahead by the timed region is not used here: every epoch below samples)
     evs = []
     for e in range(n_epochs + 1):                # (the first one captures the batches-only graph: not counted)
         e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
@@ -469,10 +473,14 @@ def main():
             at_epoch_start = state["ids"] is None or state["b"] == nb
             if at_epoch_start:
                 phase["epochs"] += 1
-            # the first epoch of a phase (warm-up, measurement) and every event_every-th after it are event-bracketed
-            timed_epoch = engine != "graph" or (phase["epochs"] - 1) % args.event_every == 0
+            # the SECOND epoch of a phase (warm-up, measurement) and every event_every-th after it are event-bracketed: the phase
+            # starts from an idle device (a barrier), and behind a whole-epoch graph launch the host is far enough ahead for the
+            # kernel-by-kernel launches of a bracketed epoch not to leave the device waiting
+            # (a phase shorter than two epochs brackets its first one)
+            first_timed = 2 if n_steps >= 2 * nb else 1
+            timed_epoch = engine != "graph" or (phase["epochs"] - first_timed) % args.event_every == 0
             if epoch_graphs and at_epoch_start and not timed_epoch and k + nb <= n_steps:
-                tr.run_epoch_one_graph(flush=False)  # pick + shuffle + labels + plans + every batch's step: one graph launch (the
+                tr.run_epoch_one_graph(flush=False, prefetch=args.prefetch)  # pick + shuffle + labels + plans + every batch's step: one graph launch (the
                                                      # last batch's deferred Adam update is applied by the next front launch, or
                                                      # by the flush that ends the timed region)
                 state["ids"], state["b"] = tr.fused._ep_ids[:tr.pick_size], nb
@@ -494,14 +502,31 @@ def main():
             k += 1
 
     prof._prof = []
-    run_steps(warmup, False)
-    while epoch_graphs and state["b"] != nb:   # the warm-up may end mid-epoch; whole-epoch graphs start at an epoch boundary
-        one_step(next_batch())
-        warmup += 1
-    if epoch_graphs:                           # one more epoch, every batch as its own graph replay: captures all of them
-        for _ in range(nb):
+    if epoch_graphs:
+        # every graph the timed region can replay is captured here: the whole-epoch graph in each of its variants (buffer set
+        # 0 / 1; with the next epoch's sampler on a parallel branch: sampling its own epoch first or finding it prepared) and the
+        # per-batch graphs of both buffer sets
+        def whole():
+            tr.run_epoch_one_graph(flush=False, prefetch=args.prefetch)
+            state["epoch"] += 1
+            return nb
+
+        def batchwise():
+            tr.start_epoch_staged()
+            for b in range(nb):
+                tr.fused.epoch_step(b, defer=True)
+            state["epoch"] += 1
+            return nb
+        seq = (whole, whole, batchwise, whole, batchwise, whole, whole) if args.prefetch else (whole, batchwise)
+        warmup = sum(f() for f in seq)
+        state["ids"], state["b"] = None, 0
+        run_steps(2 * nb + 2, False)           # ... and one pass through the timed region's own sequence (bracketed epoch included)
+        warmup += 2 * nb + 2
+        while state["b"] != nb:                # the warm-up ends at an epoch boundary
             one_step(next_batch())
             warmup += 1
+    else:
+        run_steps(warmup, False)
     prof._prof = []                                    # (start, end) HIP events around the select + aggregate launch
     barrier()
     t0 = time.perf_counter()

@@ -89,8 +89,8 @@ class FusedPCGNN:
         self.status = torch.zeros(1, dtype=torch.int32, device=self.dev)   # ONE device status word
         self._graphs = {}
         self._ep_graphs = {}
-        self._ep_ids = None
-        self._ep_plans = None
+        self._ep_sets = None       # two sets of epoch buffers: ids | labels | plan slots (stage_epoch)
+        self._cur, self._cur_ready, self._ep_stride = 0, False, 0
         self._alloc(max_batch)
         self._prof = None          # bench.py: list of (start, end) events around the choose+aggregate launch
         self.last_counts = None
@@ -105,7 +105,7 @@ class FusedPCGNN:
         # every captured graph holds raw pointers into the buffers replaced below
         self._graphs.clear()
         self._ep_graphs.clear()
-        self._ep_plans = None
+        self._ep_sets = None
         self.maxB = B
         if self._list_capacity_arg is None:
             self.list_capacity, self.clipped = default_list_capacity(g, B)
@@ -351,34 +351,56 @@ class FusedPCGNN:
         return graphs
 
     # -- whole-epoch path: ids / labels of an epoch live in static buffers, one plan slot and one graph per batch ------
+    # There are TWO sets of epoch buffers (ids | labels | plan slots).  The picks of an epoch and its plans depend on nothing
+    # a training step computes, so with ``epoch_run(prefetch=True)`` the sampler and the plan launches of epoch e + 1 run on a
+    # parallel branch of epoch e's graph, into the other set - off the steps' serial chain altogether.
+    @property
+    def _ep_ids(self):
+        return None if self._ep_sets is None else self._ep_sets[self._cur]["ids"]
+
+    @property
+    def _ep_lab(self):
+        return self._ep_sets[self._cur]["lab"]
+
+    @property
+    def _ep_plans(self):
+        return None if self._ep_sets is None else self._ep_sets[self._cur]["plans"]
+
     def stage_epoch(self, n: int, batch_size: int):
         """Static id / label buffers and plan slots of an epoch of n picks (the ids are filled by begin_epoch or by a
-        sampler; ``plan_staged()`` must follow before any of the epoch's steps runs)."""
-        if self._ep_ids is None or self._ep_ids.numel() < n:
-            self._ep_ids = torch.zeros(n, dtype=torch.int32, device=self.dev)
-            self._ep_lab = torch.zeros(n, dtype=torch.int32, device=self.dev)
-            self._ep_graphs.clear()
+        sampler; ``plan_staged()`` must follow before any of the epoch's steps runs).  Returns the CURRENT set's (ids, labels)."""
         if batch_size > self.maxB:
             self.flush()
             self._alloc(batch_size)
         nb = -(-n // batch_size)
         stride = self._plan_bytes(batch_size)
-        if self._ep_plans is None or getattr(self, "_ep_stride", 0) != stride or self._ep_plans.numel() < nb * stride:
+        sets = self._ep_sets
+        if sets is None or sets[0]["ids"].numel() < n or self._ep_stride != stride or sets[0]["plans"].numel() < nb * stride:
             if torch.cuda.is_current_stream_capturing():
                 raise _lib.PcgnnLibraryError("stage_epoch with a new shape inside a graph capture")
-            self._ep_plans = torch.zeros(nb * stride, dtype=torch.uint8, device=self.dev)
+            self._ep_sets = [dict(ids=torch.zeros(n, dtype=torch.int32, device=self.dev),
+                                  lab=torch.zeros(n, dtype=torch.int32, device=self.dev),
+                                  plans=torch.zeros(nb * stride, dtype=torch.uint8, device=self.dev)) for _ in range(2)]
             self._ep_stride = stride
+            self._cur, self._cur_ready = 0, False
             self._ep_graphs.clear()
         self._ep_n, self._ep_bs = n, batch_size
         return self._ep_ids[:n], self._ep_lab[:n]
 
-    def plan_staged(self, bump_counter: Optional[torch.Tensor] = None):
-        """Plan every batch of the staged epoch: ONE launch (after the sampler, before the epoch's first step).
-        bump_counter: the sampler's device epoch counter, incremented by this launch."""
-        self._enqueue_plan(self._ep_ids, self._ep_lab, self._ep_n, self._ep_bs, self._ep_plans, self._ep_stride, True, bump_counter)
+    def take_prefetched(self) -> bool:
+        """True if the current set already holds a sampled and planned epoch that no step has used yet (left by
+        ``epoch_run(prefetch=True)``) - the caller then starts on it instead of sampling; the set counts as used from here on."""
+        ready, self._cur_ready = self._cur_ready, False
+        return ready
 
-    def _ep_plan(self, b: int) -> int:
-        return self._ep_plans.data_ptr() + b * self._ep_stride
+    def plan_staged(self, bump_counter: Optional[torch.Tensor] = None, which: Optional[int] = None):
+        """Plan every batch of the staged epoch (set `which`, default the current one): two launches (after the sampler, before
+        the epoch's first step).  bump_counter: the sampler's device epoch counter, incremented by the first of them."""
+        st = self._ep_sets[self._cur if which is None else which]
+        self._enqueue_plan(st["ids"], st["lab"], self._ep_n, self._ep_bs, st["plans"], self._ep_stride, True, bump_counter)
+
+    def _ep_plan(self, b: int, which: Optional[int] = None) -> int:
+        return self._ep_sets[self._cur if which is None else which]["plans"].data_ptr() + b * self._ep_stride
 
     def begin_epoch(self, ids: torch.Tensor, labels: torch.Tensor, batch_size: int):
         """Stage an epoch's (already shuffled) ids and labels and plan its batches; afterwards ``epoch_step(b)`` is exactly
@@ -387,6 +409,7 @@ class FusedPCGNN:
         ep_ids, ep_lab = self.stage_epoch(n, batch_size)
         ep_ids.copy_(ids)
         ep_lab.copy_(labels)
+        self._cur_ready = False
         self.plan_staged()
 
     def epoch_step(self, b: int, defer: bool = False):
@@ -399,7 +422,7 @@ class FusedPCGNN:
             return
         self._lastB = B
         defer = defer and lo + B < self._ep_n
-        key = (lo, B, "deferred") if defer else (lo, B)
+        key = (self._cur, lo, B, "deferred") if defer else (self._cur, lo, B)
         gr = self._ep_graphs.get(key)
         if gr is None:
             ids, lab = self._ep_ids[lo:lo + B], self._ep_lab[lo:lo + B]
@@ -418,7 +441,7 @@ class FusedPCGNN:
         if B <= 0:
             return
         self._lastB = B
-        key = (lo, B, "timed")
+        key = (self._cur, lo, B, "timed")
         grs = self._ep_graphs.get(key)
         ids, lab = self._ep_ids[lo:lo + B], self._ep_lab[lo:lo + B]
         g = self.g
@@ -451,38 +474,64 @@ class FusedPCGNN:
         grs[2].replay()
 
     def epoch_run(self, n_steps: Optional[int] = None, sample=None, bump_counter: Optional[torch.Tensor] = None,
-                  flush: bool = True):
+                  flush: bool = True, prefetch: bool = False):
         """All batches of the staged epoch as ONE graph launch: the host latency between two graph launches (~8 us)
-        is paid once per epoch instead of once per batch.  ``sample()``, if given, is enqueued (and captured) first: it
-        fills the staged id / label buffers on the device (pick + shuffle + labels), so a replay is a whole new epoch;
+        is paid once per epoch instead of once per batch.  ``sample(ids, labels)``, if given, is enqueued (and captured): it
+        fills the given id / label buffers on the device (pick + shuffle + labels), so a replay is a whole new epoch;
         the plans of all batches follow (which also bumps ``bump_counter``, the sampler's epoch number).
         flush=False: the last batch's deferred Adam update (everything but the label classifier) is left to whatever comes
-        next - the next epoch's first front launch applies it, any other public call flushes it first."""
+        next - the next epoch's first front launch applies it, any other public call flushes it first.
+        prefetch=True (needs ``sample``): the sampler and the plans of the NEXT epoch run on a parallel branch of this epoch's
+        graph, into the other buffer set; afterwards that set is the current one and ready (``take_prefetched``).  The first
+        such call - or one after the ready set was used up by other calls - samples its own epoch first."""
         nb = -(-self._ep_n // self._ep_bs)
         n_steps = nb if n_steps is None else min(n_steps, nb)
-        key = ("epoch", self._ep_n, self._ep_bs, n_steps, sample is not None, None if bump_counter is None else bump_counter.data_ptr(),
-               flush)
+        n = self._ep_n
+        prefetch = prefetch and sample is not None
+        cur = self._cur
+        primed = prefetch and self._cur_ready
+        key = ("epoch", cur, n, self._ep_bs, n_steps, sample is not None, None if bump_counter is None else bump_counter.data_ptr(),
+               flush, prefetch, primed)
         gr = self._ep_graphs.get(key)
         if gr is None:
+            st = self._ep_sets[cur]
+            nxt = self._ep_sets[cur ^ 1]
             def run():
                 for b in range(n_steps):
                     lo = b * self._ep_bs
-                    B = min(self._ep_bs, self._ep_n - lo)
-                    self.train_step(self._ep_ids[lo:lo + B], self._ep_lab[lo:lo + B], defer=True, plan=self._ep_plan(b))
+                    B = min(self._ep_bs, n - lo)
+                    self.train_step(st["ids"][lo:lo + B], st["lab"][lo:lo + B], defer=True, plan=self._ep_plan(b, cur))
                 if flush:
                     self.flush()
             def warm_run():                      # (the warm-up leaves the staged ids - and the epoch counter - as they are)
-                self.plan_staged()
+                self.plan_staged(which=cur)
                 run()
+                if prefetch:                     # (the other set's plan slots and kernels get their first use outside a capture)
+                    self.plan_staged(which=cur ^ 1)
             def sampled_run():
-                if sample is not None:
-                    sample()
-                self.plan_staged(bump_counter)
-                run()
+                if not primed:
+                    if sample is not None:
+                        sample(st["ids"][:n], st["lab"][:n])
+                    self.plan_staged(bump_counter, which=cur)
+                if prefetch:                     # fork: the next epoch's sampler + plans beside this epoch's steps
+                    main = torch.cuda.current_stream(self.dev)
+                    side = torch.cuda.Stream(self.dev)
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        sample(nxt["ids"][:n], nxt["lab"][:n])
+                        self.plan_staged(bump_counter, which=cur ^ 1)
+                    run()
+                    main.wait_stream(side)
+                else:
+                    run()
             gr = self._capture_graphs([sampled_run], warm=[warm_run])[0]
             self._ep_graphs[key] = gr
-        self._lastB = min(self._ep_bs, self._ep_n - (n_steps - 1) * self._ep_bs)
+        self._lastB = min(self._ep_bs, n - (n_steps - 1) * self._ep_bs)
         gr.replay()
+        if prefetch:
+            self._cur, self._cur_ready = cur ^ 1, True
+        else:
+            self._cur_ready = False
         return n_steps
 
     def check(self):

@@ -72,21 +72,24 @@ class PCGNNTrainer:
 
     def start_epoch_staged(self) -> torch.Tensor:
         """pick + shuffle + label lookup in ONE launch (pcg_pick_shuffled), straight into the fused engine's epoch
-        buffers; the epoch number lives on the device and is incremented by the call.  Returns the staged ids."""
-        ids = self._sample_staged()
-        self.fused.plan_staged(self._epoch_dev)      # every batch's plan, one launch; it also moves the epoch number on
-        return ids
-
-    def _sample_staged(self) -> torch.Tensor:
+        buffers, then every batch's plan; the epoch number lives on the device and is moved on by the plan launch.  If a
+        previous ``run_epoch_one_graph(prefetch=True)`` has prepared this epoch already, nothing is launched.
+        Returns the staged ids."""
         ids, lab = self.fused.stage_epoch(self.pick_size, self.batch_size)
-        self.sampler.pick_shuffled(self.pick_size, ids, self.labels_i32, lab, epoch_counter=self._epoch_dev, bump=False)
+        if not self.fused.take_prefetched():
+            self._sample_into(ids, lab)
+            self.fused.plan_staged(self._epoch_dev)      # every batch's plan; it also moves the epoch number on
         return ids
 
-    def run_epoch_one_graph(self, flush: bool = True) -> int:
+    def _sample_into(self, ids: torch.Tensor, lab: torch.Tensor):
+        self.sampler.pick_shuffled(self.pick_size, ids, self.labels_i32, lab, epoch_counter=self._epoch_dev, bump=False)
+
+    def run_epoch_one_graph(self, flush: bool = True, prefetch: bool = False) -> int:
         """A whole epoch - pick, shuffle, labels, every batch's plan and every batch's training step - as one graph launch.
-        flush=False: see FusedPCGNN.epoch_run (back-to-back epochs: the next one's first launch applies the last update)."""
+        flush=False / prefetch=True: see FusedPCGNN.epoch_run (back-to-back epochs: the next epoch's first launch applies the
+        last update; the next epoch's sampler and plans run beside this epoch's steps)."""
         self.fused.stage_epoch(self.pick_size, self.batch_size)
-        self.fused.epoch_run(sample=self._sample_staged, bump_counter=self._epoch_dev, flush=flush)
+        self.fused.epoch_run(sample=self._sample_into, bump_counter=self._epoch_dev, flush=flush, prefetch=prefetch)
         return self.pick_size
 
     def step(self, batch_ids: torch.Tensor, timed: bool = False) -> torch.Tensor:
@@ -260,9 +263,9 @@ class ModelHandler(object):
                 # pick + shuffle + label lookup on the device, then every batch of the epoch (the last one partial; the
                 # empty batch the reference's int(len / B) + 1 can produce is not run): one graph launch
                 engine.stage_epoch(pick_size, args.batch_size)
-                engine.epoch_run(sample=lambda: sampler.pick_shuffled(pick_size, engine._ep_ids[:pick_size], labels_dev,
-                                                                       engine._ep_lab[:pick_size], epoch_counter=epoch_dev,
-                                                                       bump=False), bump_counter=epoch_dev)
+                engine.epoch_run(sample=lambda ids, lab: sampler.pick_shuffled(pick_size, ids, labels_dev, lab,
+                                                                                epoch_counter=epoch_dev, bump=False),
+                                 bump_counter=epoch_dev)
             else:
                 sampled = list(idx_train)                                                                # :132-133
                 random.shuffle(sampled)

@@ -776,15 +776,24 @@ def test_epoch_as_one_graph_equals_step_by_step(P):
     from pcgnn_amd.handler import PCGNNTrainer
     w = synth.make_workload("mini", 6000, 32, (4000, 30000, 90000), 0.12, seed=3)
     cfg = dict(engine="graph", batch_size=256, seed=5)
-    a, b, c, d = (PCGNNTrainer(w, cfg, dev()) for _ in range(4))
-    b.fused.theta.copy_(a.fused.theta)
-    c.fused.theta.copy_(a.fused.theta)
-    d.fused.theta.copy_(a.fused.theta)
+    a, b, c, d, e = (PCGNNTrainer(w, cfg, dev()) for _ in range(5))
+    for t in (b, c, d, e):
+        t.fused.theta.copy_(a.fused.theta)
     nb = a.batches_per_epoch()
     assert a.pick_size % a.batch_size != 0 and nb >= 3
     for ep in range(3):
         a.run_epoch_one_graph()
         d.run_epoch_one_graph(flush=False)      # the last batch's update left to the next epoch's first launch (bench.py)
+        # ... and with the NEXT epoch's sampler and plans on a parallel branch of this epoch's graph (two buffer sets); the second
+        # epoch is taken batch by batch from the set the first one prepared
+        if ep == 1:
+            assert e.fused._cur_ready
+            e.start_epoch_staged()
+            assert not e.fused._cur_ready
+            for k in range(nb):
+                e.fused.epoch_step(k, defer=True)
+        else:
+            e.run_epoch_one_graph(flush=False, prefetch=True)
         ids = b.start_epoch_staged()
         for k in range(nb):
             sl = slice(k * b.batch_size, min((k + 1) * b.batch_size, b.pick_size))
@@ -798,14 +807,17 @@ def test_epoch_as_one_graph_equals_step_by_step(P):
             else:
                 c.fused.epoch_step(k, defer=True)
     d.fused.flush()
+    e.fused.flush()
     torch.cuda.synchronize()
     assert int(a._epoch_dev[0]) == int(b._epoch_dev[0]) == int(c._epoch_dev[0]) == int(d._epoch_dev[0]) == 3
+    assert int(e._epoch_dev[0]) == 4 and e.fused._cur_ready        # (the fourth epoch is sampled and planned already)
     assert torch.equal(a.fused._ep_ids[:a.pick_size], b.fused._ep_ids[:b.pick_size])
     assert torch.equal(a.fused._ep_ids[:a.pick_size], c.fused._ep_ids[:c.pick_size])
     for name in ("theta", "m", "v", "step_counter"):
         assert torch.equal(getattr(a.fused, name), getattr(b.fused, name)), name
         assert torch.equal(getattr(a.fused, name), getattr(c.fused, name)), name + " (per-batch graphs, deferred Adam)"
         assert torch.equal(getattr(a.fused, name), getattr(d.fused, name)), name + " (epoch graphs without the end-of-epoch flush)"
+        assert torch.equal(getattr(a.fused, name), getattr(e.fused, name)), name + " (next epoch's sampler + plans on a parallel branch)"
     assert torch.isfinite(a.fused.theta).all() and not torch.equal(a.fused.theta, torch.zeros_like(a.fused.theta))
 
 
