@@ -253,6 +253,7 @@ def run_partitioned(args, w, B, lr, wd, dev, dist, world, rank):
     barrier()
     t0 = time.perf_counter()
     run_steps(warmup, args.steps)
+    d.flush()                               # the last step's Adam update (it otherwise rides at the head of the next step's graph)
     barrier()
     elapsed = time.perf_counter() - t0
     d.check()                               # raises on every rank if any rank's exchange / lists went over capacity

@@ -197,7 +197,10 @@ int pcg_choose_select_planned(const pcg_graph_desc *g, const int32_t *nodes, con
                               const float *s0, const float *center_s0, const uint64_t *pos_keys,
                               const double *thresholds, const double *rho, int32_t train_flag, int32_t add_self,
                               int32_t *cnt, void *workspace, const void *plan, int64_t list_capacity, uint32_t *status,
-                              void *stream);
+                              uint32_t *sync_words, int64_t center_id_offset, void *stream);
+/* (sync_words: as pcg_choose_gather_planned - the select kernel sorts the unsorted train-pos keys itself; center_id_offset > 0
+ *  with center_s0 == NULL: centre b's score is s0[nodes[b] + center_id_offset] - the partitioned path, whose `nodes` are table rows
+ *  of owned nodes while s0 is indexed by global node id) */
 /* The plans of ALL batches of an epoch in one launch - off every step's critical path (a plan depends on the picked ids, their
  * labels and the CSR degrees, never on a parameter; the reference does this bookkeeping per batch, src/layers.py:217-219,
  * 246-262).  Batch s = nodes[s * B, min((s + 1) * B, n_total)) (the last one may be shorter) is planned into
@@ -225,8 +228,17 @@ int pcg_choose_gather_planned(const pcg_graph_desc *g, const int32_t *nodes, con
                               float *agg, int32_t agg_stride, int32_t *cnt, void *workspace, const void *plan,
                               int64_t list_capacity, uint32_t *status, uint32_t *sync_words, void *stream);
 int32_t pcg_pos_sort_in_select(int32_t n_pos);      /* 1: 0 < n_pos <= 16384 (host helper) */
+/* scores of rows [row_begin, row_end) (-> s0_out[row], or s0_out[row_ids[row]]) || the UNSORTED train-pos keys into pos_keys'
+ * scratch half (pos_keys may be NULL; pos_row_base >= 0: train positive i's feature row is table row pos_row_base + i - required
+ * with row_ids -, else row train_pos[i]); zeroes sync_words[3].  ONE launch, no plan, no parameter update. */
+int pcg_step_scores(const pcg_graph_desc *g, const float *W, const float *b, int64_t row_begin, int64_t row_end, float *s0_out,
+                    const int32_t *row_ids, uint64_t *pos_keys, int64_t pos_row_base, uint32_t *sync_words, void *stream);
 int32_t pcg_sync_words_count(void);                 /* uint32 words of a `sync_words` buffer (zero-initialised ONCE by the caller; the
                                                         kernels leave every word but [1], [2] zero between launches) */
+int pcg_aggregate_lists_planned(const float *X, int32_t feat_dim, int32_t feat_stride, int64_t table_rows, int32_t n_rows,
+                                const int32_t *cnt, const pcg_graph_desc *g, int32_t B, void *workspace, const void *plan,
+                                int64_t list_capacity, int32_t norm, float *agg, int32_t agg_stride, uint32_t *status,
+                                void *stream);       /* pcg_aggregate_lists with the plan part outside the workspace */
 int pcg_gather_lists_planned(const float *X, int32_t feat_dim, int32_t feat_stride, int64_t table_rows, int32_t n_rows,
                              const int32_t *cnt, const pcg_graph_desc *g, int32_t B, void *workspace, const void *plan,
                              int64_t list_capacity, float *agg, int32_t agg_stride, uint32_t *status, void *stream);
@@ -344,6 +356,16 @@ int pcg_step_front_train(const pcg_graph_desc *g, float *theta, float *m, float 
                          int64_t list_capacity, uint32_t *status, const float *slabs, const int32_t *step_counter,
                          uint32_t *sync_words, double lr, double beta1, double beta2, double eps, double weight_decay,
                          void *stream);
+/* The optimizer of a data-parallel / partitioned step, whose gradient passes through an all-reduce: pcg_grad_reduce sums the
+ * slabs (tile order) into grad_out and sets flag[0] ("a gradient is waiting"); after the collective, pcg_adam_apply_pending - at
+ * the head of the NEXT step's launches, or on its own before parameters are read - applies torch.optim.Adam's update from grad to
+ * every parameter if flag[0] is set.  The flag is cleared by a later launch: clear != 0 adds a one-thread launch that does it;
+ * clear == 0 leaves it to the caller's next launch (flag = sync_words + 1: pcg_choose_select_planned(sync_words) clears it).
+ * flag: one zero-initialised uint32 device word. */
+int pcg_grad_reduce(const float *slabs, int32_t n_slabs, int64_t n_params, float *grad_out, uint32_t *flag, void *stream);
+int pcg_adam_apply_pending(float *theta, float *m, float *v, const float *grad, int64_t n_params, const int32_t *step_counter,
+                           uint32_t *flag, int32_t clear, double lr, double beta1, double beta2, double eps, double weight_decay,
+                           void *stream);
 int pcg_adam_flush(float *theta, float *m, float *v, const float *slabs, int32_t n_slabs, int64_t n_params, int64_t p_end,
                    const int32_t *step_counter, uint32_t *sync_words, double lr, double beta1, double beta2, double eps,
                    double weight_decay, void *stream);
@@ -380,7 +402,7 @@ int pcg_halo_collect(const pcg_graph_desc *g, const int32_t *centres, int32_t n_
                      int32_t halo_base, int32_t owner_pitch, int32_t self_rank, void *stream);
 int pcg_halo_serve(const pcg_graph_desc *g, const int32_t *req, int32_t n_req, int32_t lo, int32_t n_local, float *out,
                    int32_t out_stride, void *stream);
-int pcg_halo_lookup(const pcg_graph_desc *g, int32_t B, void *workspace, int64_t list_capacity, int32_t lo, int32_t hi,
+int pcg_halo_lookup(const pcg_graph_desc *g, int32_t B, void *workspace, const void *plan, int64_t list_capacity, int32_t lo, int32_t hi,
                     int32_t n_local, const int32_t *pos_ids, const int32_t *pos_idx, int32_t n_pos, uint32_t *table,
                     int64_t table_slots, uint32_t *counts, int32_t halo_cap, int32_t halo_base, void *stream);
 

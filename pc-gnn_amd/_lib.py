@@ -59,13 +59,15 @@ PROTOTYPES = {
     "pcg_step_front_b": (C.c_int, [_G, _P, _P, _I32, _P, _P, _I32, C.POINTER(_F64), C.POINTER(_F64), _I32, _I32, _P, _I64, _P,
                                    _P, _I64, _P]),
     "pcg_choose_select_planned": (C.c_int, [_G, _P, _P, _I32, _P, _P, _P, C.POINTER(_F64), C.POINTER(_F64), _I32, _I32,
-                                            _P, _P, _P, _I64, _P, _P]),
+                                            _P, _P, _P, _I64, _P, _P, _I64, _P]),
+    "pcg_step_scores": (C.c_int, [_G, _P, _P, _I64, _I64, _P, _P, _P, _I64, _P, _P]),
     "pcg_choose_plan_bytes": (_I64, [_G, _I32, _I64]),
     "pcg_choose_data_bytes": (_I64, [_G, _I32, _I64]),
     "pcg_plan_batches": (C.c_int, [_G, _P, _P, _I32, _I32, C.POINTER(_F64), C.POINTER(_F64), _I32, _I32, _P, _I64, _I64, _P, _P,
                                    _P]),
     "pcg_pos_sort_in_select": (_I32, [_I32]),
     "pcg_sync_words_count": (_I32, []),
+    "pcg_aggregate_lists_planned": (C.c_int, [_P, _I32, _I32, _I64, _I32, _P, _G, _I32, _P, _P, _I64, _I32, _P, _I32, _P, _P]),
     "pcg_gather_lists_planned": (C.c_int, [_P, _I32, _I32, _I64, _I32, _P, _G, _I32, _P, _P, _I64, _P, _I32, _P, _P]),
     "pcg_step_scores_train": (C.c_int, [_G, _P, _P, _P, _I32, _P, _P, _P, _P, _P, _F64, _F64, _F64, _F64, _F64, _P]),
     "pcg_choose_aggregate_planned": (C.c_int, [_G, _P, _P, _I32, _P, _P, _P, C.POINTER(_F64), C.POINTER(_F64), _I32, _I32,
@@ -77,6 +79,8 @@ PROTOTYPES = {
                                   _P, _P, _P, _P, _F64, _F64, _F64, _F64, _F64, _I32, _P]),
     "pcg_step_front_train": (C.c_int, [_G, _P, _P, _P, _I32, _P, _P, _P, _P, _I32, C.POINTER(_F64), C.POINTER(_F64), _I32, _P,
                                        _I64, _P, _P, _P, _P, _F64, _F64, _F64, _F64, _F64, _P]),
+    "pcg_grad_reduce": (C.c_int, [_P, _I32, _I64, _P, _P, _P]),
+    "pcg_adam_apply_pending": (C.c_int, [_P, _P, _P, _P, _I64, _P, _P, _I32, _F64, _F64, _F64, _F64, _F64, _P]),
     "pcg_adam_flush": (C.c_int, [_P, _P, _P, _P, _I32, _I64, _I64, _P, _P, _F64, _F64, _F64, _F64, _F64, _P]),
     "pcg_debug_set_stamps": (None, [_P]),
     "pcg_debug_set_dense_stamps": (None, [_P]),
@@ -89,7 +93,7 @@ PROTOTYPES = {
     "pcg_halo_serve": (C.c_int, [_G, _P, _I32, _I32, _I32, _P, _I32, _P]),
     "pcg_halo_collect": (C.c_int, [_G, _P, _I32, _I32, _I32, _I32, _P, _I32, _P, _I32, _P, _I64, _P, _P, _I32, _I32, _I32, _I32,
                                    _P]),
-    "pcg_halo_lookup": (C.c_int, [_G, _I32, _P, _I64, _I32, _I32, _I32, _P, _P, _I32, _P, _I64, _P, _I32, _I32, _P]),
+    "pcg_halo_lookup": (C.c_int, [_G, _I32, _P, _P, _I64, _I32, _I32, _I32, _P, _P, _I32, _P, _I64, _P, _I32, _I32, _P]),
     "pcg_dense_n_params": (_I64, [_I32, _I32, _I32]),
     "pcg_dense_param_offset": (_I64, [_I32, _I32, _I32, _I32, _I32]),
     "pcg_dense_n_tiles": (_I32, [_I32]),

@@ -137,6 +137,8 @@ struct ChooseArgs {
     int32_t B;
     const float *s0;
     const float *center_s0;
+    int64_t center_off;        // center_s0 == null: centre b's score is s0[nodes[b] + center_off] (the partitioned path: `nodes` are
+                               // table rows of owned nodes, the scores are indexed by global node id)
     const uint64_t *pos_keys;
     // in-kernel sort of the train positives (select_rows; null / 0 = pos_keys is sorted already): the keys come in groups of 64
     // (n_sort groups); group g's ranks are worked out by sort_slices workgroups, each against its share of all the keys, added

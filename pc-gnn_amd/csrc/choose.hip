@@ -424,7 +424,7 @@ __global__ void __launch_bounds__(FRONT_COUNT_THREADS) front_a_kernel(const Choo
                                                                       const float *__restrict__ W, const float *__restrict__ bias,
                                                                       int64_t row_begin, int64_t row_end, float *__restrict__ s0,
                                                                       const DeferredAdam ad, int n_adam_blocks,
-                                                                      const int32_t *__restrict__ row_ids) {
+                                                                      const int32_t *__restrict__ row_ids, int64_t pos_row_base) {
     __shared__ float part[4][PCG_WAVE];
     const int b = (int)blockIdx.x;
     if (a.sort_done && b == 0 && threadIdx.x == 0) a.sort_done[0] = 0u;
@@ -432,7 +432,7 @@ __global__ void __launch_bounds__(FRONT_COUNT_THREADS) front_a_kernel(const Choo
         plan_count_body<FRONT_COUNT_THREADS>(a, a.w, totals, b);
     else if (b < n_plan_blocks + n_key_blocks)      // the train positives' sort keys, from their feature rows
         pos_key_body(a.g.X, a.g.feat_dim, a.g.feat_stride, W, bias, a.g.train_pos, a.g.n_pos, raw_keys, b - n_plan_blocks,
-                     n_key_blocks);
+                     n_key_blocks, pos_row_base);
     else if (b < n_plan_blocks + n_key_blocks + n_adam_blocks) {
         if (ad.pending[0] != 0u)                    // (one word, the same for every thread)
             adam_reduce_body(ad.theta, ad.m, ad.v, ad.slabs, (int)ad.pending[1], ad.n_params, 0, ad.p_end, ad.step_counter, ad.h,
@@ -551,6 +551,7 @@ static int choose_args(pcg::ChooseArgs &a, const pcg_graph_desc *g, const int32_
     a.B = B;
     a.s0 = s0;
     a.center_s0 = center_s0;
+    a.center_off = 0;
     a.pos_keys = pos_keys;
     for (int r = 0; r < PCG_MAX_REL; ++r) a.thr[r] = r < g->n_rel ? thresholds[r] : 0.0;
     for (int r = 0; r < PCG_MAX_REL; ++r) a.rho[r] = (r < g->n_rel && rho) ? rho[r] : 0.0;
@@ -574,6 +575,7 @@ struct PlannedExtra {
     const void *plan = nullptr;
     uint32_t *sync_words = nullptr;     // non-null: pos_keys' scratch half holds the UNSORTED keys (pcg_step_scores_train); the
                                         // select kernel sorts them itself ([3] = arrival counter, zero on entry) and clears [1]
+    int64_t center_off = 0;
 };
 
 static int choose_select(bool planned, const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B,
@@ -588,6 +590,7 @@ static int choose_select(bool planned, const pcg_graph_desc *g, const int32_t *n
     const int rc = choose_args(a, g, nodes, labels, B, s0, center_s0, pos_keys, thresholds, rho, train_flag, add_self, cnt,
                                workspace, list_capacity, status, false, x.plan);
     if (rc != PCG_OK) return rc;
+    a.center_off = x.center_off;
     if (x.sync_words) {
         a.pending_clear = x.sync_words + 1;
         if (train_flag && g->n_pos > 0 && g->n_pos <= pcg::RANK_MAX) {
@@ -615,8 +618,12 @@ int pcg_choose_select(const pcg_graph_desc *g, const int32_t *nodes, const int32
 int pcg_choose_select_planned(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B,
                               const float *s0, const float *center_s0, const uint64_t *pos_keys, const double *thresholds,
                               const double *rho, int32_t train_flag, int32_t add_self, int32_t *cnt, void *workspace,
-                              const void *plan, int64_t list_capacity, uint32_t *status, void *stream) {
+                              const void *plan, int64_t list_capacity, uint32_t *status, uint32_t *sync_words,
+                              int64_t center_id_offset, void *stream) {
+    if (center_id_offset < 0 || (center_id_offset > 0 && center_s0)) return PCG_E_ARG;
     PlannedExtra x;
+    x.sync_words = sync_words;
+    x.center_off = center_id_offset;
     x.plan = plan;
     return choose_select(true, g, nodes, labels, B, s0, center_s0, pos_keys, thresholds, rho, train_flag, add_self, cnt,
                          workspace, list_capacity, status, stream, x);
@@ -657,12 +664,12 @@ static int front_a(const pcg_graph_desc *g, const float *W, const float *b, int6
                    float *s0_out, const int32_t *row_ids, uint64_t *pos_keys, const int32_t *nodes, const int32_t *labels, int32_t B,
                    const double *thresholds, const double *rho, int32_t train_flag, int32_t add_self, void *workspace,
                    int64_t list_capacity, uint32_t *status, const pcg::DeferredAdam *ad, void *stream, bool no_plan = false,
-                   uint32_t *zero_word = nullptr) {
+                   uint32_t *zero_word = nullptr, int64_t pos_row_base = -1) {
     if (!g || !g->X || !W || !b || !s0_out || B < 0) return PCG_E_ARG;
     if (g->feat_dim < 1 || g->feat_stride < g->feat_dim || g->feat_stride % 4 != 0) return PCG_E_ARG;
     if ((reinterpret_cast<uintptr_t>(g->X) & 15u) != 0) return PCG_E_ARG;
     if (row_begin < 0 || row_end > g->n_nodes || row_begin > row_end) return PCG_E_ARG;
-    if (B == 0 && row_ids) return PCG_E_ARG;
+    if (B == 0 && row_ids && !no_plan) return PCG_E_ARG;
     if (B == 0 && !no_plan) return pcg_score_table(g, W, b, row_begin, row_end, s0_out, stream);   // (then _b gathers its keys itself)
     pcg::ChooseArgs a;
     if (no_plan) {
@@ -680,7 +687,7 @@ static int front_a(const pcg_graph_desc *g, const float *W, const float *b, int6
     const int n_count = (rows + pcg::FRONT_COUNT_THREADS - 1) / pcg::FRONT_COUNT_THREADS;
     const int n_score = (int)pcg::score_table_blocks(row_end - row_begin, g->feat_stride);
     // the train positives' unsorted keys go to the scratch half of pos_keys (rank-sort sizes only)
-    const bool raw = pos_keys && train_flag && g->n_pos > 0 && g->n_pos <= pcg::RANK_MAX && g->train_pos;
+    const bool raw = pos_keys && train_flag && g->n_pos > 0 && g->n_pos <= pcg::RANK_MAX && (g->train_pos || pos_row_base >= 0);
     const int rows_per_block = 4 * (PCG_WAVE / pcg::lanes_per_row(g->feat_stride));
     int n_key = raw ? (g->n_pos + rows_per_block - 1) / rows_per_block : 0;
     if (n_key > 256) n_key = 256;
@@ -689,7 +696,7 @@ static int front_a(const pcg_graph_desc *g, const float *W, const float *b, int6
     const int n_adam = ad ? (int)((ad->p_end + PCG_WAVE - 1) / PCG_WAVE) : 0;
     hipLaunchKernelGGL(pcg::front_a_kernel, dim3(n_count + n_key + n_adam + n_score), dim3(pcg::FRONT_COUNT_THREADS), 0,
                        static_cast<hipStream_t>(stream), a, tot, n_count, n_key, raw_keys, W, b, row_begin, row_end, s0_out,
-                       ad ? *ad : none, n_adam, row_ids);
+                       ad ? *ad : none, n_adam, row_ids, pos_row_base);
     PCG_LAUNCH_CHECK();
     return PCG_OK;
 }
@@ -791,6 +798,18 @@ int pcg_step_scores_train(const pcg_graph_desc *g, float *theta, float *m, float
     return PCG_OK;
 }
 
+/* scores (+ unsorted train-pos keys) on their own, no plan, no Adam: the front of a step of the PARTITIONED path, whose table
+ * rows are [owned | train-pos | halo] and whose scores are indexed by global node id (row_ids), and of any caller that plans its
+ * batches with pcg_plan_batches and updates its parameters itself. */
+int pcg_step_scores(const pcg_graph_desc *g, const float *W, const float *b, int64_t row_begin, int64_t row_end, float *s0_out,
+                    const int32_t *row_ids, uint64_t *pos_keys, int64_t pos_row_base, uint32_t *sync_words, void *stream) {
+    if (!g || !sync_words) return PCG_E_ARG;
+    if (pos_keys && row_ids && pos_row_base < 0) return PCG_E_ARG;     // (with row_ids a node id is not a table row)
+    if (pos_row_base >= 0 && pos_row_base + g->n_pos > g->n_nodes) return PCG_E_ARG;
+    return front_a(g, W, b, row_begin, row_end, s0_out, row_ids, pos_keys, nullptr, nullptr, 0, nullptr, nullptr, 1, 0, nullptr, 1, nullptr,
+                   nullptr, stream, true, sync_words + 3, pos_row_base);
+}
+
 int32_t pcg_pos_sort_in_select(int32_t n_pos) { return n_pos > 0 && n_pos <= pcg::RANK_MAX ? 1 : 0; }
 
 /* uint32 words of the `sync_words` buffer: [0] dense ticket, [1] update pending, [2] its slab count, [3] the in-kernel sort's group
@@ -850,7 +869,7 @@ int pcg_choose_aggregate_planned(const pcg_graph_desc *g, const int32_t *nodes, 
     if (B == 0) return PCG_OK;
     if (!g->X || !agg) return PCG_E_ARG;
     const int rc = pcg_choose_select_planned(g, nodes, labels, B, s0, center_s0, pos_keys, thresholds, rho, train_flag,
-                                             add_self, cnt, workspace, nullptr, list_capacity, status, stream);
+                                             add_self, cnt, workspace, nullptr, list_capacity, status, nullptr, 0, stream);
     if (rc != PCG_OK) return rc;
     return pcg_aggregate_lists(g->X, g->feat_dim, g->feat_stride, g->n_nodes, g->n_rel * B, cnt, g, B, workspace, list_capacity,
                                norm, agg, agg_stride, status, stream);

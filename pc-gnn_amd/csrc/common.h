@@ -211,7 +211,7 @@ __device__ __forceinline__ uint64_t make_pos_key(const float *s0, const int32_t 
 // workgroup `block` of `n_blocks`, 256 threads.
 __device__ __forceinline__ void pos_key_body(const float *__restrict__ X, int feat_dim, int stride, const float *__restrict__ W,
                                              const float *__restrict__ bias, const int32_t *__restrict__ train_pos, int n_pos,
-                                             uint64_t *__restrict__ raw, int block, int n_blocks) {
+                                             uint64_t *__restrict__ raw, int block, int n_blocks, int64_t pos_row_base = -1) {
     const int lane = lane_id();
     const int lpr = lanes_per_row(stride);
     const int rpw = PCG_WAVE / lpr;
@@ -221,7 +221,9 @@ __device__ __forceinline__ void pos_key_body(const float *__restrict__ X, int fe
     for (int base = (block * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6)) * rpw; base < n_pos; base += waves * rpw) {
         const int i = base + slot;
         const bool ok = i < n_pos;
-        const float *row = X + (size_t)(ok ? train_pos[i] : 0) * stride;
+        // (pos_row_base >= 0: the train positives' rows are a block of the table of their own - the partitioned path's replicated
+        //  block - in train_pos order; else row = node id)
+        const float *row = X + (size_t)(pos_row_base >= 0 ? pos_row_base + (ok ? i : 0) : (ok ? train_pos[i] : 0)) * stride;
         float p = ok ? score_partial(row, W, feat_dim, stride, sub, lpr) : 0.f;
         p = score_reduce(p, lpr);
         if (ok && sub == 0) raw[i] = ((uint64_t)orderable(p + b0) << 32) | (uint32_t)i;

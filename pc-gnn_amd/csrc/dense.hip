@@ -649,6 +649,29 @@ __global__ void __launch_bounds__(256) adam_reduce_kernel(float *__restrict__ th
 
 __global__ void clear_word_kernel(uint32_t *w) { w[0] = 0u; }
 
+// The partitioned path's two optimizer launches (its gradient goes through an all-reduce between them):
+//   grad_reduce   : slabs summed in tile order -> grad; marks "a gradient is waiting" (flag[0] = 1)
+//   apply_pending : if a gradient is waiting: Adam on every parameter from grad (after the all-reduce, at the head of the NEXT step's
+//                   graph - no launch of its own between the collective and the next score pass).  The flag is cleared by a LATER
+//                   launch (the step's select kernel: pcg_choose_select_planned(sync_words) clears sync_words[1]; or the
+//                   one-thread launch pcg_adam_apply_pending(clear = 1) adds) - a departure ticket in this kernel was 420
+//                   same-address atomics, 4.8 us
+__global__ void __launch_bounds__(256) grad_reduce_kernel(const float *__restrict__ slabs, int n_slabs, int64_t n_params,
+                                                          float *__restrict__ grad_out, uint32_t *flag) {
+    __shared__ float part[4][PCG_WAVE];
+    if (blockIdx.x == 0 && threadIdx.x == 0) flag[0] = 1u;
+    const AdamHyper none = {0.f, 0.f, 0.f, 0.f, 0.f};
+    adam_reduce_body(nullptr, nullptr, nullptr, slabs, n_slabs, n_params, 0, n_params, nullptr, none, grad_out, 0, (int)blockIdx.x, part);
+}
+__global__ void __launch_bounds__(256) apply_pending_kernel(float *__restrict__ theta, float *__restrict__ m, float *__restrict__ v,
+                                                            const float *__restrict__ grad, int64_t n_params,
+                                                            const int32_t *__restrict__ step_counter, AdamHyper h,
+                                                            const uint32_t *__restrict__ flag) {
+    __shared__ float part[4][PCG_WAVE];
+    if (flag[0] == 0u) return;                                    // (one word, the same for every thread)
+    adam_reduce_body(theta, m, v, grad, 1, n_params, 0, n_params, step_counter, h, nullptr, 1, (int)blockIdx.x, part);
+}
+
 static size_t dense_smem_bytes(int F, int E, int R, bool wlds) {
     const int K1p = (2 * F + KPAD - 1) / KPAD * KPAD, K2p = (F + R * E + KPAD - 1) / KPAD * KPAD;
     const int ntile_e = E / 16, kparts = ntile_e <= DENSE_WAVES ? DENSE_WAVES / ntile_e : 1;
@@ -832,6 +855,30 @@ int pcg_adam_step(float *theta, float *m, float *v, const float *slabs, int32_t 
                        static_cast<hipStream_t>(stream), theta, m, v, slabs, n_slabs, n_params, (int64_t)0, n_params,
                        step_counter, h, grad_out, apply, (const uint32_t *)nullptr);
     PCG_LAUNCH_CHECK();
+    return PCG_OK;
+}
+
+int pcg_grad_reduce(const float *slabs, int32_t n_slabs, int64_t n_params, float *grad_out, uint32_t *flag, void *stream) {
+    if (!slabs || n_slabs < 0 || n_params < 1 || !grad_out || !flag) return PCG_E_ARG;
+    hipLaunchKernelGGL(pcg::grad_reduce_kernel, dim3((unsigned)((n_params + PCG_WAVE - 1) / PCG_WAVE)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), slabs, n_slabs, n_params, grad_out, flag);
+    PCG_LAUNCH_CHECK();
+    return PCG_OK;
+}
+
+int pcg_adam_apply_pending(float *theta, float *m, float *v, const float *grad, int64_t n_params, const int32_t *step_counter,
+                           uint32_t *flag, int32_t clear, double lr, double beta1, double beta2, double eps, double weight_decay,
+                           void *stream) {
+    if (!theta || !m || !v || !grad || n_params < 1 || !step_counter || !flag) return PCG_E_ARG;
+    const pcg::AdamHyper h = {(float)lr, (float)beta1, (float)beta2, (float)eps, (float)weight_decay};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(pcg::apply_pending_kernel, dim3((unsigned)((n_params + PCG_WAVE - 1) / PCG_WAVE)), dim3(256), 0, st, theta, m, v,
+                       grad, n_params, step_counter, h, flag);
+    PCG_LAUNCH_CHECK();
+    if (clear) {
+        hipLaunchKernelGGL(pcg::clear_word_kernel, dim3(1), dim3(1), 0, st, flag);
+        PCG_LAUNCH_CHECK();
+    }
     return PCG_OK;
 }
 

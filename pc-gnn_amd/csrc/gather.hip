@@ -269,4 +269,12 @@ int pcg_gather_lists_planned(const float *X, int32_t feat_dim, int32_t feat_stri
                      agg_stride, false, status, stream, plan);
 }
 
+/* gather + combine (finished means) with the plan part outside the workspace */
+int pcg_aggregate_lists_planned(const float *X, int32_t feat_dim, int32_t feat_stride, int64_t table_rows, int32_t n_rows,
+                                const int32_t *cnt, const pcg_graph_desc *g, int32_t B, void *workspace, const void *plan,
+                                int64_t list_capacity, int32_t norm, float *agg, int32_t agg_stride, uint32_t *status, void *stream) {
+    return aggregate(X, feat_dim, feat_stride, table_rows, n_rows, cnt, g, B, workspace, list_capacity, norm, agg, agg_stride, true,
+                     status, stream, plan);
+}
+
 }  // extern "C"

@@ -367,14 +367,14 @@ int pcg_halo_collect(const pcg_graph_desc *g, const int32_t *centres, int32_t n_
     return PCG_OK;
 }
 
-int pcg_halo_lookup(const pcg_graph_desc *g, int32_t B, void *workspace, int64_t list_capacity, int32_t lo, int32_t hi,
+int pcg_halo_lookup(const pcg_graph_desc *g, int32_t B, void *workspace, const void *plan, int64_t list_capacity, int32_t lo, int32_t hi,
                     int32_t n_local, const int32_t *pos_ids, const int32_t *pos_idx, int32_t n_pos, uint32_t *table,
                     int64_t table_slots, uint32_t *counts, int32_t halo_cap, int32_t halo_base, void *stream) {
     if (!g || !workspace || !table || !counts || B < 1 || list_capacity < 1 || table_slots < 1024 ||
         (table_slots & (table_slots - 1)) != 0 || lo > hi || n_pos < 0 || (n_pos > 0 && (!pos_ids || !pos_idx)))
         return PCG_E_ARG;
     pcg::Workspace w;
-    pcg::carve1(g, B, list_capacity, static_cast<unsigned char *>(workspace), &w);
+    pcg::carve1(g, B, list_capacity, static_cast<unsigned char *>(workspace), &w, static_cast<unsigned char *>(const_cast<void *>(plan)));
     pcg::HaloArgs a = {};
     a.list = w.list;
     a.chunk_desc = w.chunk_desc;

@@ -463,7 +463,7 @@ __device__ __forceinline__ void select_four_short_rows(const ChooseArgs &a, int 
     const int32_t *__restrict__ nbr = t_indices[r] + (p.d > 0 ? p.start : 0);
     const bool have = active && pos < p.d;
     const uint32_t id = (uint32_t)nbr[pos < p.d ? pos : (p.d > 0 ? p.d - 1 : 0)];
-    const float c = a.center_s0 ? a.center_s0[row - r * a.B] : a.s0[p.node];
+    const float c = a.center_s0 ? a.center_s0[row - r * a.B] : a.s0[p.node + a.center_off];
     const bool keep_all = rec_keep_all(p);
     const float sc = a.s0[id];
     const uint32_t key = have ? dist_key(c, sc) : 0xFFFFFFFFu;     // (valid keys have bit 31 clear)
@@ -487,7 +487,7 @@ __device__ __forceinline__ void select_lane_row(const ChooseArgs &a, int row, ui
     const bool keep_all = rec_keep_all(p);
     const int r = row / a.B;
     const int32_t *__restrict__ nbr = a.g.indices[r] + (d > 0 ? p.start : 0);      // (d == 0: a node without neighbours that joins its own set)
-    const float c = a.center_s0 ? a.center_s0[row - r * a.B] : a.s0[p.node];
+    const float c = a.center_s0 ? a.center_s0[row - r * a.B] : a.s0[p.node + a.center_off];
     uint32_t *sel_lds = area + HIST_W;
     const bool tail = p.m > 0 || a.add_self;
     const bool have = lane < d;
@@ -539,7 +539,7 @@ __device__ __forceinline__ void select_wave_row(const ChooseArgs &a, int row, ui
     const bool keep_all = rec_keep_all(p);
     const int r = row / a.B;
     const int32_t *__restrict__ nbr = a.g.indices[r] + p.start;
-    const float c = a.center_s0 ? a.center_s0[row - r * a.B] : a.s0[p.node];
+    const float c = a.center_s0 ? a.center_s0[row - r * a.B] : a.s0[p.node + a.center_off];
     uint32_t *hist = area, *sel_lds = area + HIST_W, *cand = area + HIST_W + T1_CAP;
     const bool tail = p.m > 0 || a.add_self;
     int32_t *__restrict__ out = a.w.list + p.lbeg;
@@ -694,7 +694,7 @@ __device__ __forceinline__ void select_wg_row(const ChooseArgs &a, int row, uint
     const int r = row / a.B;
     const int32_t *__restrict__ nbr = a.g.indices[r] + p.start;
     const float *__restrict__ s0 = a.s0;
-    const float c = a.center_s0 ? a.center_s0[row - r * a.B] : s0[p.node];
+    const float c = a.center_s0 ? a.center_s0[row - r * a.B] : s0[p.node + a.center_off];
     int32_t *__restrict__ out = a.w.list + p.lbeg;
     // res: what one thread / wave found, for everybody: red[2 * NW + 2 ..]
     int *res = red + 2 * NW + 2;

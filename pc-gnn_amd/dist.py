@@ -295,12 +295,14 @@ class HaloExchangeHip(HaloExchange):
             graph.desc_ref(), ops._p(self.req_in), self.halo_cap, part.lo, part.n_local, ops._p(self.rows_out),
             self.rows_out.stride(0), ops._stream(self.X_ext.device)), "pcg_halo_serve")
 
-    def lookup(self, ws, B: int, graph):
-        """per step: ws.list (global ids; the chunk table says which entries are in use) -> rows of X_ext"""
+    def lookup(self, data, plan, list_capacity: int, B: int, graph):
+        """per step: the selection list in `data` (global ids; the chunk table of `plan` - an address, or None: the plan lies
+        inside `data` - says which entries are in use) -> rows of X_ext"""
         ops, part = self._ops, self.part
         _p = ops._p
+        import ctypes as C
         self._lib.check(self._lib.load().pcg_halo_lookup(
-            graph.desc_ref(), B, _p(ws.buf), ws.list_capacity, part.lo, part.hi, part.n_local, _p(self.pos_ids32),
+            graph.desc_ref(), B, _p(data), None if plan is None else C.c_void_p(plan), list_capacity, part.lo, part.hi, part.n_local, _p(self.pos_ids32),
             _p(self.pos_idx32), self.P, _p(self.table), self.slots, _p(self.counts), self.halo_cap, self.halo_base,
             ops._stream(self.X_ext.device)), "pcg_halo_lookup")
 
@@ -409,7 +411,17 @@ class DistributedPCGNN:
         self.s0_full = torch.zeros(w.n, dtype=torch.float32, device=self.dev)
         self.keys = torch.empty(self.lib.pcg_pos_sort_capacity(P), dtype=torch.int64, device=self.dev)
         self.status = torch.zeros(1, dtype=torch.int32, device=self.dev)
-        self.ws = ops.ChooseWorkspace(g, B, status=self.status)
+        # the plan of a batch depends on its ids / labels and the CSR degrees only: a window's batches are planned together,
+        # one plan slot each (pcg_plan_batches); the selection list and the partial sums (the data part) are shared
+        from .fused import default_list_capacity
+        self.list_capacity, self.clipped = default_list_capacity(g, B)
+        self.data = torch.zeros(int(self.lib.pcg_choose_data_bytes(g.desc_ref(), B, self.list_capacity)), dtype=torch.uint8, device=self.dev)
+        self.plan_stride = int(self.lib.pcg_choose_plan_bytes(g.desc_ref(), B, self.list_capacity))
+        self.win_plans = torch.zeros(max(int(window), 1) * self.plan_stride, dtype=torch.uint8, device=self.dev)
+        self._plan_one = {}                       # batch size -> plan slot of a step outside a window
+        self.sync = torch.zeros(int(self.lib.pcg_sync_words_count()), dtype=torch.int32, device=self.dev)
+        self.opt_flag = self.sync[1:2]             # "a gradient is waiting for its Adam update" (set by the slab sum, cleared by the next select launch)
+        self._thr, self._rhos = ops._host_arrays(g, [0.5] * g.R, [cfg["rho"]] * g.R)
         self.cnt = torch.empty(g.R * B, dtype=torch.int32, device=self.dev)
         self.agg = torch.empty(g.R, B, F, dtype=torch.float32, device=self.dev)
         self.logits = torch.empty(B, 2, dtype=torch.float32, device=self.dev)
@@ -427,8 +439,7 @@ class DistributedPCGNN:
         self.lab_buf = torch.zeros(B, dtype=torch.int32, device=self.dev)
         self.win_ids = torch.zeros(B * self.window, dtype=torch.int32, device=self.dev)
         self.win_lab = torch.zeros(B * self.window, dtype=torch.int32, device=self.dev)
-        self.center_buf = torch.zeros(B, dtype=torch.float32, device=self.dev)
-        self._graphs, self._ws_extra = {}, {}
+        self._graphs = {}
 
     def _agree_max(self, value: int) -> int:
         """the largest `value` over the ranks (construction-time collective)"""
@@ -455,46 +466,76 @@ class DistributedPCGNN:
         self.halo.prefetch(self.g, ids_window_local.to(torch.int32))
 
     # -- one step ---------------------------------------------------------------------------------
-    def _seg_front(self, ids_local, labels, B, train_flag):
-        """scores of every row this rank holds (owned, train-pos, halo), by node id || plan pass 1; train-pos sort || plan
-        pass 2; centre scores; select (lists of global ids); lists -> rows of the extended table."""
-        ops, g, part = self.ops, self.g, self.part
-        ws = self._ws_of(B)
-        lab = labels if train_flag else None
-        ops.step_front_a(g, self.w_clf, self.b_clf, self.s0_full, 0, g.n_nodes, ids_local, lab, self.thresholds, self.rho,
-                         train_flag, ws, row_ids=self.row_gid)
-        keys = ops.step_front_b(g, self.s0_full, self.keys, ids_local, lab, self.thresholds, self.rho, train_flag, ws,
-                                center_out=self.center_buf[:B], center_id_offset=part.lo)
-        ops.choose_select(g, ids_local, lab, self.s0_full, keys, self.thresholds, self.rho, train_flag, ws,
-                          self.cnt[:g.R * B], center_s0=self.center_buf[:B], planned=True)
-        self.halo.lookup(ws, B, g)
+    def _plan(self, ids, labels, n_total, B, plans: torch.Tensor, train_flag: bool):
+        """plans of the batches ids[s * B : (s + 1) * B] into consecutive plan slots (two launches for all of them)"""
+        _p = self.ops._p
+        self._libmod.check(self.lib.pcg_plan_batches(
+            self.g.desc_ref(), _p(ids), _p(labels if train_flag else None), n_total, B, self._thr, self._rhos, 1 if train_flag else 0, 0,
+            _p(plans), self.plan_stride, self.list_capacity, _p(self.status), None, self.ops._stream(self.dev)), "pcg_plan_batches")
 
-    def _seg_step(self, ids_local, labels, B):
-        """the collective-free part of a training step: front, gather over the extended table, dense step (it finishes the
-        long rows' means), this rank's gradient (slabs summed in tile order)."""
+    def _plan_single(self, ids, labels, B, train_flag) -> int:
+        """a step outside a window: its own plan slot (one per batch size), planned now; returns the slot's address"""
+        buf = self._plan_one.get(B)
+        if buf is None:
+            buf = self._plan_one[B] = torch.zeros(self.plan_stride, dtype=torch.uint8, device=self.dev)
+        self._plan(ids, labels, B, B, buf, train_flag)
+        return buf.data_ptr()
+
+    def _seg_front(self, ids_local, labels, B, train_flag, plan: int):
+        """scores of every row this rank holds (owned, train-pos, halo), by node id || the train positives' unsorted keys from
+        their replicated rows (one launch); select - it sorts the keys itself and reads the centres' scores by global id -
+        (lists of global ids); lists -> rows of the extended table."""
+        import ctypes as C
+        ops, g, part, lib, _p = self.ops, self.g, self.part, self.lib, self.ops._p
+        check = self._libmod.check
+        st = ops._stream(self.dev)
+        lab = labels if train_flag else None
+        P = g.n_pos
+        sort = train_flag and P > 0
+        in_select = sort and bool(lib.pcg_pos_sort_in_select(P))
+        check(lib.pcg_step_scores(g.desc_ref(), _p(self.w_clf), _p(self.b_clf), 0, g.n_nodes, _p(self.s0_full), _p(self.row_gid),
+                                  _p(self.keys) if in_select else None, part.n_local, _p(self.sync), st), "pcg_step_scores")
+        if sort and not in_select:           # too many positives for the in-kernel sort: the bucket sort's launches
+            ops.pos_sort(g, self.s0_full, self.keys)
+        check(lib.pcg_choose_select_planned(
+            g.desc_ref(), _p(ids_local), _p(lab), B, _p(self.s0_full), None, _p(self.keys) if sort else None, self._thr, self._rhos,
+            1 if train_flag else 0, 0, _p(self.cnt[:g.R * B]), _p(self.data), C.c_void_p(plan), self.list_capacity, _p(self.status),
+            _p(self.sync) if (in_select or train_flag) else None, part.lo, st), "pcg_choose_select_planned")
+        self.halo.lookup(self.data, plan, self.list_capacity, B, g)
+
+    def _seg_step(self, ids_local, labels, B, plan: int):
+        """the collective-free part of a training step: scores, select, look-up, gather over the extended table, dense step (it
+        finishes the long rows' means), this rank's gradient (slabs summed in tile order)."""
+        import ctypes as C
         ops, g, lib, _p = self.ops, self.g, self.lib, self.ops._p
-        self._seg_front(ids_local, labels, B, True)
-        ws = self._ws_of(B)
+        self._enqueue_apply()                      # the previous step's (all-reduced) gradient, if one is waiting
+        self._seg_front(ids_local, labels, B, True, plan)
         st = ops._stream(self.dev)
         check, c = self._libmod.check, self.cfg
         agg = self.agg.view(-1)[:g.R * B * self.F].view(g.R, B, self.F)
-        check(lib.pcg_gather_lists(_p(g.X), g.feat_dim, g.X.stride(0), g.X.shape[0], g.R * B, _p(self.cnt), g.desc_ref(), B, _p(ws.buf),
-                                   ws.list_capacity, _p(agg), agg.stride(1), _p(ws.status), st), "pcg_gather_lists")
+        check(lib.pcg_gather_lists_planned(_p(g.X), g.feat_dim, g.X.stride(0), g.X.shape[0], g.R * B, _p(self.cnt), g.desc_ref(), B,
+                                           _p(self.data), C.c_void_p(plan), self.list_capacity, _p(agg), agg.stride(1), _p(self.status), st),
+              "pcg_gather_lists_planned")
         check(lib.pcg_train_dense(g.desc_ref(), _p(self.theta), None, None, self.E, _p(ids_local), _p(labels), B, _p(agg),
-                                  agg.stride(1), _p(self.cnt), _p(ws.buf), None, ws.list_capacity, float(c["alpha"]),
+                                  agg.stride(1), _p(self.cnt), _p(self.data), C.c_void_p(plan), self.list_capacity, float(c["alpha"]),
                                   1.0 / (B * self.world), _p(self.logits), _p(self.center), None, _p(self.row_loss),
                                   _p(self.slabs), _p(self.step_counter), None, c["lr"], 0.9, 0.999, 1e-8, c["weight_decay"], 0,
                                   st), "pcg_train_dense")
-        check(lib.pcg_adam_step(_p(self.theta), _p(self.m), _p(self.v), _p(self.slabs), lib.pcg_dense_n_tiles(B),
-                                self.n_params, _p(self.step_counter), c["lr"], 0.9, 0.999, 1e-8, c["weight_decay"],
-                                _p(self.grad), 0, st), "pcg_adam_step")
+        check(lib.pcg_grad_reduce(_p(self.slabs), lib.pcg_dense_n_tiles(B), self.n_params, _p(self.grad), _p(self.opt_flag), st),
+              "pcg_grad_reduce")
 
-    def _ws_of(self, B):
-        if B == self.ws.B:
-            return self.ws
-        if B not in self._ws_extra:
-            self._ws_extra[B] = self.ops.ChooseWorkspace(self.g, B, status=self.status)
-        return self._ws_extra[B]
+    def _enqueue_apply(self, clear: bool = False):
+        """Adam from self.grad on every parameter if a gradient is waiting (device flag; a no-op launch otherwise).  Inside a
+        step the flag is cleared by the step's select launch; clear=True adds a one-thread launch that does it."""
+        c, lib, _p = self.cfg, self.lib, self.ops._p
+        self._libmod.check(lib.pcg_adam_apply_pending(_p(self.theta), _p(self.m), _p(self.v), _p(self.grad), self.n_params,
+                                                      _p(self.step_counter), _p(self.opt_flag), 1 if clear else 0, c["lr"], 0.9, 0.999,
+                                                      1e-8, c["weight_decay"], self.ops._stream(self.dev)), "pcg_adam_apply_pending")
+
+    def flush(self):
+        """Apply the last step's Adam update now (it otherwise rides at the head of the next step's launches): call before
+        the parameters are read.  Enqueued, not synchronised; every rank applies the same all-reduced gradient."""
+        self._enqueue_apply(clear=True)
 
     def forward_sample(self, ids_local: torch.Tensor, labels: Optional[torch.Tensor], train_flag: bool = True,
                        prefetch: bool = True):
@@ -502,25 +543,25 @@ class DistributedPCGNN:
         [R, B, F] and the set sizes.  prefetch=False: the centres are covered by the current window."""
         ops, g = self.ops, self.g
         B = ids_local.numel()
+        import ctypes as C
+        self.flush()                               # (the select launch below clears the "gradient waiting" word)
         if prefetch:
             self.begin_window(ids_local)
-        self._seg_front(ids_local, labels, B, train_flag)
+        plan = self._plan_single(ids_local, labels, B, train_flag)
+        self._seg_front(ids_local, labels, B, train_flag, plan)
         agg = self.agg.view(-1)[:g.R * B * self.F].view(g.R, B, self.F)
         cnt = self.cnt[:g.R * B]
-        ops.aggregate_lists(g, g.X, B, self._ws_of(B), cnt, agg)
+        _p, lib = ops._p, self.lib
+        self._libmod.check(lib.pcg_aggregate_lists_planned(_p(g.X), g.feat_dim, g.X.stride(0), g.X.shape[0], g.R * B, _p(cnt), g.desc_ref(),
+                                                           B, _p(self.data), C.c_void_p(plan), self.list_capacity, self._libmod.PCG_NORM_COUNT,
+                                                           _p(agg), agg.stride(1), _p(self.status), ops._stream(self.dev)),
+                           "pcg_aggregate_lists_planned")
         return agg, cnt
-
-    def _apply_adam(self):
-        c, lib, _p = self.cfg, self.lib, self.ops._p
-        self._libmod.check(lib.pcg_adam_step(_p(self.theta), _p(self.m), _p(self.v), _p(self.grad), 1, self.n_params,
-                                             _p(self.step_counter), c["lr"], 0.9, 0.999, 1e-8, c["weight_decay"], None, 1,
-                                             self.ops._stream(self.dev)), "pcg_adam_step")
 
     def _graph_for(self, B, slot: Optional[int] = None):
         """hipGraph of the collective-free part of a step for batch size B, reading its centres from the static id / label
         buffers (slot None) or from batch `slot` of the static window buffers.  The warm-up that precedes the capture runs the
-        same kernels once; its effect on the step counter is undone (parameters are only touched by _apply_adam, outside
-        the graph)."""
+        same kernels once; its effect on the step counter is undone, and the gradient it produced is discarded."""
         gr = self._graphs.get((B, slot))
         if gr is not None:
             return gr
@@ -529,12 +570,19 @@ class DistributedPCGNN:
         else:
             ids, lab = self.win_ids[slot * self.B:slot * self.B + B], self.win_lab[slot * self.B:slot * self.B + B]
         counter = self.step_counter.clone()
-        self._seg_step(ids, lab, B)                # warm-up: kernel attributes, workspaces
+        # (a step outside a window plans itself, inside its graph; a window's batches were planned together by train_window)
+        if slot is None:
+            step = lambda: self._seg_step(ids, lab, B, self._plan_single(ids, lab, B, True))
+        else:
+            plan = self.win_plans.data_ptr() + slot * self.plan_stride
+            step = lambda: self._seg_step(ids, lab, B, plan)
+        step()                                     # warm-up: kernel attributes, plan slots (its head applies a waiting gradient: due anyway)
+        self.opt_flag.zero_()                      # ... and the gradient the warm-up itself left behind is not one to apply
         torch.cuda.synchronize(self.dev)           # no collective of ours is in flight while capturing
         gr = torch.cuda.CUDAGraph()
         # thread_local: RCCL's watchdog thread may query events while this thread captures
         with torch.cuda.graph(gr, capture_error_mode="thread_local"):
-            self._seg_step(ids, lab, B)
+            step()
         self.step_counter.copy_(counter)
         self._graphs[(B, slot)] = (gr, ids)
         return gr, ids
@@ -552,8 +600,7 @@ class DistributedPCGNN:
         if timed:
             ev[1].record()
             prof.append((ev[0], ev[1], ids.clone(), self.cnt[:self.g.R * B].clone()))
-        self._all_reduce(self.grad)
-        self._apply_adam()
+        self._all_reduce(self.grad)                # (its Adam update rides at the head of the next step's graph; flush() applies it now)
 
     def train_step(self, ids_local: torch.Tensor, labels: torch.Tensor, use_graphs: bool = True):
         """COLLECTIVE.  One training step on centres the current window covers (begin_window): one graph replay (or the same
@@ -561,9 +608,8 @@ class DistributedPCGNN:
         host; a list or an exchange over capacity raises a device flag (check())."""
         B = ids_local.numel()
         if not use_graphs:
-            self._seg_step(ids_local, labels, B)
+            self._seg_step(ids_local, labels, B, self._plan_single(ids_local, labels, B, True))
             self._all_reduce(self.grad)
-            self._apply_adam()
             return
         self.ids_buf[:B].copy_(ids_local)
         self.lab_buf[:B].copy_(labels)
@@ -579,6 +625,7 @@ class DistributedPCGNN:
         if use_graphs and n <= self.win_ids.numel():
             self.win_ids[:n].copy_(ids_window_local)
             self.win_lab[:n].copy_(labels_window)
+            self._plan(self.win_ids, self.win_lab, n, self.B, self.win_plans, True)     # every batch of the window: two launches
             for slot, b0 in enumerate(range(0, n, self.B)):
                 B = min(self.B, n - b0)
                 gr, ids = self._graph_for(B, slot)
@@ -591,6 +638,7 @@ class DistributedPCGNN:
         """COLLECTIVE.  Raise - on every rank, or on none - if any rank's exchange or selection list went over capacity, or a
         step met an id outside its window, since the last check (those steps worked on lists with holes).  One small
         all-reduce and one host read: call it per epoch, not per step."""
+        self.flush()
         # the two words are bit fields: every bit travels as a 0/1 entry of its own, so that MAX over the ranks is a bitwise OR
         # (rank A's pitch overflow and rank B's id-outside-window would otherwise collapse into the larger number; NCCL has no BOR)
         words = torch.stack([self.halo.overflow_word[0], self.status[0]]).to(torch.int64)

@@ -143,7 +143,8 @@ def choose_select(g: DeviceGraph, nodes, labels, s0, pos_keys, thresholds, rho, 
             1 if train_flag else 0, 1 if add_self else 0, _p(cnt), _p(ws.buf))
     rest = (ws.list_capacity, _p(ws.status), _stream(g.device))
     if planned:
-        _lib.check(lib.pcg_choose_select_planned(*args, None, *rest), "pcg_choose_select_planned")
+        _lib.check(lib.pcg_choose_select_planned(*args, None, ws.list_capacity, _p(ws.status), None, 0, _stream(g.device)),
+                   "pcg_choose_select_planned")
     else:
         _lib.check(lib.pcg_choose_select(*args, *rest), "pcg_choose_select")
 

@@ -94,13 +94,17 @@ def _worker(rank, world, port, q):
         np.testing.assert_allclose(d.logits.cpu().numpy(), lg[rank * B:(rank + 1) * B].cpu().numpy(), rtol=0, atol=1e-6)
         # every rank holds the same parameters after the step
         th = [torch.empty(d.n_params) for _ in range(world)]
+        d.flush()                                   # (the step's Adam update otherwise rides at the head of the next step)
         dist.all_gather(th, d.theta.cpu())
         assert all(torch.equal(th[0], t) for t in th[1:])
         assert not torch.equal(th[0], theta0.cpu())
+        d.flush()                                   # a second flush without a new gradient changes nothing
+        assert torch.equal(d.theta.cpu(), th[rank])
         # a window of two more batches through the captured step on both ranks (fresh centres): the first step warms up and
         # captures, the second replays
         ids2 = d.pick_epoch(2 * B, 1)
         d.train_window(ids2, d.labels_of(ids2))
+        d.flush()
         torch.cuda.synchronize()
         dist.all_gather(th, d.theta.cpu())
         assert all(torch.equal(th[0], t) for t in th[1:]) and torch.isfinite(th[0]).all()
