@@ -62,7 +62,7 @@ def parse():
                     "so the remote rows of a window's centres are fetched once)")
     ap.add_argument("--timed-graphs", action="store_true", help="event-bracketed steps as three graph launches instead of five "
                     "kernel launches (the middle graph's launch latency then lands inside the bracket)")
-    ap.add_argument("--timed-per-epoch", type=int, default=2, help="batches of an event-bracketed epoch that are launched kernel by "
+    ap.add_argument("--timed-per-epoch", type=int, default=1, help="batches of an event-bracketed epoch that are launched kernel by "
                     "kernel with HIP events (the rest of that epoch: one graph replay per batch)")
     ap.add_argument("--event-every", type=int, default=3,
                     help="graph engine: bracket the select+aggregate launch with HIP events on every step of every Nth epoch")

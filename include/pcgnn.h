@@ -201,7 +201,7 @@ int pcg_choose_select_planned(const pcg_graph_desc *g, const int32_t *nodes, con
 /* (sync_words: as pcg_choose_gather_planned - the select kernel sorts the unsorted train-pos keys itself; center_id_offset > 0
  *  with center_s0 == NULL: centre b's score is s0[nodes[b] + center_id_offset] - the partitioned path, whose `nodes` are table rows
  *  of owned nodes while s0 is indexed by global node id) */
-/* The plans of ALL batches of an epoch in one launch - off every step's critical path (a plan depends on the picked ids, their
+/* The plans of ALL batches of an epoch in ONE launch - off every step's critical path (a plan depends on the picked ids, their
  * labels and the CSR degrees, never on a parameter; the reference does this bookkeeping per batch, src/layers.py:217-219,
  * 246-262).  Batch s = nodes[s * B, min((s + 1) * B, n_total)) (the last one may be shorter) is planned into
  * plans + s * plan_stride (plan_stride >= pcg_choose_plan_bytes(g, B, list_capacity), a multiple of 256); thresholds .. add_self

@@ -379,38 +379,155 @@ __global__ void __launch_bounds__(PLAN_THREADS) plan_write(const ChooseArgs a, c
     plan_write_body<PLAN_THREADS, PLAN_THREADS>(a, a.w, totals, (int)blockIdx.x, (int)gridDim.x);
 }
 
-// The plans of ALL batches of an epoch in two launches (they depend on the picked ids, their labels and the CSR degrees only -
-// not on any parameter - so they do not belong on a step's critical path): batch s = nodes[s * B_full, min((s + 1) * B_full,
-// n_total)) is planned into plan slot s (slot 0's plan part + s * stride bytes) by its own nb_full workgroups - the same two
-// passes, one row per thread, as plan_count / plan_write.  `full` is carved for B_full rows per relation, `tail` for the last,
-// shorter batch (its layout differs; same slot pitch).
+// The plans of ALL batches of an epoch in ONE launch (they depend on the picked ids, their labels and the CSR degrees only - not on
+// any parameter - so they do not belong on a step's critical path): batch s = nodes[s * B_full, min((s + 1) * B_full, n_total))
+// is planned into plan slot s (slot 0's plan part + s * stride bytes) by its own nb_full workgroups, one row per thread.
+// Workgroup j of a batch needs the sums (list entries, chunks, tier counts) over the rows of workgroups 0 .. j - 1: it counts
+// them itself (j passes of the same dependent loads, all in flight per pass; j <= 2 at batch 1024, <= 11 at 4096) instead of
+// waiting for a count launch - per epoch, one launch of ~6 us instead of two of 7 + 11.  The batch's last workgroup then knows the
+// batch's totals: it writes the counters, the select kernel's queue heads and the overflow verdict.  Rows are guarded one by one
+// against the list / chunk capacities (a prefix is all a workgroup knows), so nothing is written out of bounds when a batch
+// overflows; its counters are zeroed then and nothing is selected.  `full` is carved for B_full rows per relation, `tail` for
+// the last, shorter batch (its layout differs; same slot pitch).
 // bump: a device counter incremented once per epoch (the sampler's epoch number: the picks were made before this launch).
 // (the arguments are used in place - no per-slot copy, no pointer to them: the relation arrays inside are indexed per lane, and
 //  a copy, or an argument whose address is taken, lives in scratch)
-template <bool WRITE>
 __device__ __forceinline__ void plan_slot(const ChooseArgs &a, int s, int block, int64_t stride, int64_t full_B) {
-    const int nb = (a.g.n_rel * a.B + PLAN_THREADS - 1) / PLAN_THREADS;
+    __shared__ int4 lds4[PLAN_THREADS / PCG_WAVE];
+    __shared__ long long s_part[PLAN_THREADS / PCG_WAVE][8];
+    __shared__ long long s_run[8];
+    const int rows = a.g.n_rel * a.B;
+    const int nb = (rows + PLAN_THREADS - 1) / PLAN_THREADS;
     if (block >= nb) return;
     Workspace w = a.w;                       // the slot's plan part (pointers only)
     shift_plan(w, (int64_t)s * stride);
-    if constexpr (WRITE) plan_write_body<PLAN_THREADS, PLAN_THREADS>(a, w, reinterpret_cast<const PlanTotals *>(w.plan_totals), block, nb);
-    else plan_count_body<PLAN_THREADS>(a, w, reinterpret_cast<PlanTotals *>(w.plan_totals), block, (int64_t)s * full_B);
+    const int64_t node_off = (int64_t)s * full_B;
+    const int tid = (int)threadIdx.x, lane = lane_id(), wave = tid >> 6;
+#define SLOT_STAMP(k) do { if (a.stamps && tid == 0 && block == nb - 1 && s == 0) a.stamps[(size_t)rows * 8 + (k)] = wall_clock64(); } while (0)
+    SLOT_STAMP(0);
+    // ---- 1. the sums over the rows of the workgroups before this one
+    long long c_cap = 0;
+    int c[6] = {0, 0, 0, 0, 0, 0};           // chunks, na, n0, n1, n4, n16
+    // (four workgroups' worth of rows per iteration - this workgroup's own rows are the last of them -, their dependent loads -
+    //  centre, then its two row offsets - issued level by level and unconditionally (index clamped, the surplus not counted): one
+    //  pass of memory latency (two levels of ~2 us: the picks and the row offsets come from HBM) per four workgroups)
+    constexpr int PBU = 4;
+    RowRec rec;                              // this thread's own row
+    rec.node = 0; rec.start = 0; rec.d = rec.k = rec.m = rec.lbeg = rec.chunk0 = 0;
+    for (int pb0 = 0; pb0 <= block; pb0 += PBU) {
+        int rel[PBU], nodev[PBU], labv[PBU];
+        long long b0v[PBU], b1v[PBU];
+#pragma unroll
+        for (int u = 0; u < PBU; ++u) {
+            const int pb = pb0 + u <= block ? pb0 + u : block;
+            int row = pb * PLAN_THREADS + tid;
+            row = row < rows ? row : rows - 1;                                // (only the batch's last workgroup has rows beyond the batch)
+            rel[u] = row / a.B;
+            const int64_t b = node_off + (row - rel[u] * a.B);
+            nodev[u] = a.nodes[b];
+            labv[u] = (a.train_flag && a.labels) ? a.labels[b] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < PBU; ++u) {
+            const int64_t *ip = a.g.indptr[rel[u]];
+            b0v[u] = ip[nodev[u]];
+            b1v[u] = ip[nodev[u] + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < PBU; ++u) {
+            if (pb0 + u > block) break;                                       // (workgroup-uniform)
+            RowRec p;
+            p.node = nodev[u];
+            p.start = b0v[u];
+            p.d = (int)(b1v[u] - b0v[u]);
+            p.k = (int)ceil((double)p.d * a.thr[rel[u]]);                     // layers.py:260
+            p.m = 0;
+            if (a.train_flag && labv[u] == 1) {                               // layers.py:675
+                p.m = (int)((double)p.k * a.rho[rel[u]]);                     // layers.py:681
+                if (p.m > a.g.n_pos) p.m = a.g.n_pos;
+                if (p.m < 0) p.m = 0;
+            }
+            p.lbeg = p.chunk0 = 0;
+            if (pb0 + u == block) {
+                rec = p;
+            } else {
+                const int cap = rec_cap(p, a.add_self);
+                c_cap += cap;
+                c[0] += (cap + CHUNK - 1) / CHUNK;
+                c[1 + row_tier(p.d, p.m > 0 || a.add_self)] += 1;
+            }
+        }
+    }
+    if (block > 0) {                         // (workgroup-uniform)
+        long long x = c_cap;
+        for (int o = 1; o < PCG_WAVE; o <<= 1) x += __shfl_xor(x, o);
+        int t[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) t[j] = __builtin_amdgcn_readlane(wave_incl_scan(c[j], lane), PCG_WAVE - 1);
+        if (lane == 0) {
+            s_part[wave][0] = x;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) s_part[wave][1 + j] = t[j];
+        }
+        __syncthreads();
+        if (tid < 7) {
+            long long sum = 0;
+            for (int wv = 0; wv < PLAN_THREADS / PCG_WAVE; ++wv) sum += s_part[wv][tid];
+            s_run[tid] = sum;
+        }
+        __syncthreads();
+    }
+    const long long run_cap = block > 0 ? s_run[0] : 0;
+    const int run_chunk = block > 0 ? (int)s_run[1] : 0;
+    TierCounts run = {0, 0, 0, 0, 0};
+    if (block > 0) run = {(int)s_run[2], (int)s_run[3], (int)s_run[4], (int)s_run[5], (int)s_run[6]};
+    SLOT_STAMP(1);
+    // ---- 2. this workgroup's rows
+    const int row = block * PLAN_THREADS + tid;
+    const int cap = row < rows ? rec_cap(rec, a.add_self) : 0;
+    const int nch = (cap + CHUNK - 1) / CHUNK;
+    const int tier = row < rows ? row_tier(rec.d, rec.m > 0 || a.add_self) : -1;
+    PlanScan pre, tot;
+    block_excl_scan_plan(cap, nch, tier, lds4, pre, tot);
+    SLOT_STAMP(2);
+    const long long o_cap = run_cap + pre.cap;
+    const int o_chunk = run_chunk + pre.chunk;
+    TierCounts o = pre.t;
+    tier_add(o, run);
+    if (row < rows) {
+        w.row_begin[row] = o_cap;
+        w.chunk_begin[row] = o_chunk;
+        rec.lbeg = (int)(o_cap < (long long)INT_MAX ? o_cap : (long long)INT_MAX);
+        rec.chunk0 = o_chunk;
+        w.recs[row] = rec;
+        if (o_cap + cap <= w.list_capacity && (long long)o_chunk + nch <= w.chunk_cap) {
+            write_chunk_desc(w, row, o_chunk, o_cap, cap);
+            tier_push(w, tier, row, o);
+        }
+    }
+    if (block == nb - 1 && tid == 0) {       // the batch's last workgroup: the totals
+        const long long all_cap = run_cap + tot.cap;
+        const int all_chunk = run_chunk + tot.chunk;
+        TierCounts all = tot.t;
+        tier_add(all, run);
+        const bool overflow = all_cap > w.list_capacity || (long long)all_chunk > w.chunk_cap;
+        w.row_begin[rows] = all_cap;
+        w.chunk_begin[rows] = all_chunk;
+        tier_finish(w, all, overflow);
+        w.counters[C_NCHUNK] = overflow ? 0 : all_chunk;
+        if (overflow && a.status) atomicOr(a.status, (uint32_t)PCG_ST_SEL_OVERFLOW);
+    }
+    SLOT_STAMP(3);
+#undef SLOT_STAMP
 }
-__global__ void __launch_bounds__(PLAN_THREADS) plan_batches_count(const ChooseArgs full, const ChooseArgs tail, int n_slots,
-                                                                   int tail_slot, int64_t stride, int nb_full,
-                                                                   unsigned long long *__restrict__ bump) {
+__global__ void __launch_bounds__(PLAN_THREADS) plan_batches_kernel(const ChooseArgs full, const ChooseArgs tail, int n_slots,
+                                                                    int tail_slot, int64_t stride, int nb_full,
+                                                                    unsigned long long *__restrict__ bump) {
     if (blockIdx.x == 0 && threadIdx.x == 0 && bump) bump[0] += 1ull;
     const int s = (int)blockIdx.x / nb_full, block = (int)blockIdx.x - s * nb_full;
     if (s >= n_slots) return;
-    if (s == tail_slot) plan_slot<false>(tail, s, block, stride, full.B);
-    else plan_slot<false>(full, s, block, stride, full.B);
-}
-__global__ void __launch_bounds__(PLAN_THREADS) plan_batches_write(const ChooseArgs full, const ChooseArgs tail, int n_slots,
-                                                                   int tail_slot, int64_t stride, int nb_full) {
-    const int s = (int)blockIdx.x / nb_full, block = (int)blockIdx.x - s * nb_full;
-    if (s >= n_slots) return;
-    if (s == tail_slot) plan_slot<true>(tail, s, block, stride, full.B);
-    else plan_slot<true>(full, s, block, stride, full.B);
+    if (s == tail_slot) plan_slot(tail, s, block, stride, full.B);
+    else plan_slot(full, s, block, stride, full.B);
 }
 
 // The front of a training step in two launches instead of four: the plan's two passes ride along the score pass
@@ -629,7 +746,7 @@ int pcg_choose_select_planned(const pcg_graph_desc *g, const int32_t *nodes, con
                          workspace, list_capacity, status, stream, x);
 }
 
-/* The plans of all batches of an epoch (or of one batch: n_total <= B): two launches per EPOCH, off every step's critical path. */
+/* The plans of all batches of an epoch (or of one batch: n_total <= B): ONE launch per epoch, off every step's critical path. */
 int pcg_plan_batches(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t n_total, int32_t B,
                      const double *thresholds, const double *rho, int32_t train_flag, int32_t add_self, void *plans,
                      int64_t plan_stride, int64_t list_capacity, uint32_t *status, uint64_t *bump_counter, void *stream) {
@@ -649,11 +766,8 @@ int pcg_plan_batches(const pcg_graph_desc *g, const int32_t *nodes, const int32_
     const int nb_full = (g->n_rel * B + pcg::PLAN_THREADS - 1) / pcg::PLAN_THREADS;
     const int tail_slot = B_tail == B ? -1 : n_slots - 1;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(pcg::plan_batches_count, dim3(n_slots * nb_full), dim3(pcg::PLAN_THREADS), 0, st, full, tail, n_slots, tail_slot,
+    hipLaunchKernelGGL(pcg::plan_batches_kernel, dim3(n_slots * nb_full), dim3(pcg::PLAN_THREADS), 0, st, full, tail, n_slots, tail_slot,
                        plan_stride, nb_full, reinterpret_cast<unsigned long long *>(bump_counter));
-    PCG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(pcg::plan_batches_write, dim3(n_slots * nb_full), dim3(pcg::PLAN_THREADS), 0, st, full, tail, n_slots, tail_slot,
-                       plan_stride, nb_full);
     PCG_LAUNCH_CHECK();
     return PCG_OK;
 }

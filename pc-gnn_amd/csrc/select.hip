@@ -960,6 +960,9 @@ __device__ __forceinline__ void select_wg_row(const ChooseArgs &a, int row, uint
 // its use (its latency hides behind the work).  Eight head words on cache lines of their own keep the pulls of the 768
 // workgroups from serialising on one address (one word serves ~90 atomics per microsecond); per-wave pulls would be
 // thousands.  A workgroup busy with long rows simply pulls fewer units; nothing else is assigned in advance.
+#ifndef PCG_WG_ROW_PRIO
+#define PCG_WG_ROW_PRIO 2
+#endif
 constexpr int SEL_SHARDS = 8;
 constexpr int SORT_TILE = 4096;          // keys per LDS tile of the in-kernel train-pos sort (32 KB of the 40 KB key area)
 
@@ -1107,7 +1110,11 @@ __global__ void __launch_bounds__(SEL_NW *PCG_WAVE) __attribute__((amdgpu_waves_
         if (u < n_wg) {
             const int row = __builtin_amdgcn_readfirstlane(u < n16 ? a.w.q16[u] : a.w.q4[u - n16]);     // one row per workgroup: scalar
             const int d = a.w.recs[row].d;
+            // (a workgroup row is the launch's long pole and shares its CU with two workgroups of short rows: it goes first)
+            static_assert(true, "");
+            if (PCG_WG_ROW_PRIO) __builtin_amdgcn_s_setprio(PCG_WG_ROW_PRIO);
             if (d <= WG_KEYCAP) select_wg_row<true>(a, row, lds, hist, cand, red, tid, keys_ok, sortw);      // (longer rows: select_long_rows)
+            if (PCG_WG_ROW_PRIO) __builtin_amdgcn_s_setprio(0);
         } else {
             const int j = wave < bs ? (u - n_wg) * bs + wave : n_items;
             if (j < n1) {

@@ -19,6 +19,14 @@ rows = g.R * B
 in_select = os.environ.get("PROBE_SORT", "select") == "select"
 stamps = torch.zeros(rows + 1, 8, dtype=torch.int64, device="cuda")
 plan = fz._enqueue_plan_one(ids, lab, B, True)
+torch.cuda.synchronize()
+lib.pcg_debug_set_stamps(C.c_void_p(stamps.data_ptr()))
+plan = fz._enqueue_plan_one(ids, lab, B, True)
+torch.cuda.synchronize()
+lib.pcg_debug_set_stamps(None)
+pl = stamps[rows].cpu().numpy().astype(np.float64) * 0.01
+print("plan (last workgroup of the batch, us): prefix recount %.2f, own rows + scan %.2f, writes %.2f" % (pl[1] - pl[0], pl[2] - pl[1], pl[3] - pl[2]))
+stamps.zero_()
 for it in range(3):
     keys = fz._enqueue_scores_train() if in_select else fz._enqueue_scores(True)
     torch.cuda.synchronize()
