@@ -340,10 +340,21 @@ int pcg_adam_step(float *theta, float *m, float *v, const float *slabs, int32_t 
  *   [train-pos keys from their feature rows -> pos_keys' scratch half || that deferred update || score pass -> s0]; it zeroes
  *   sync_words[3]; the sort is left to pcg_choose_gather_planned(..., sync_words) (n_pos > 16384: the bucket sort's launches
  *   follow here instead and pos_keys is sorted on return).  Replaces src/layers.py:230-237.
+ *   touched (may be NULL = score every row): this batch's byte map from pcg_mark_touched - only rows whose byte is set are
+ *   scored (bit for bit the scores pcg_score_table gives them); the other entries of s0 keep whatever they held - the batch's
+ *   selection never reads them.  For graphs whose feature table is far larger than what a batch touches.
  * pcg_adam_flush applies a still-deferred update now (two small launches) - before parameters are read or saved. */
 int pcg_step_scores_train(const pcg_graph_desc *g, float *theta, float *m, float *v, int32_t emb, float *s0,
                           uint64_t *pos_keys, const float *slabs, const int32_t *step_counter, uint32_t *sync_words,
-                          double lr, double beta1, double beta2, double eps, double weight_decay, void *stream);
+                          double lr, double beta1, double beta2, double eps, double weight_decay, const uint8_t *touched,
+                          void *stream);
+/* Which rows the batches nodes[s * B, min((s + 1) * B, n_total)) can read the score of (src/layers.py:226-237 scores exactly
+ * `unique_nodes` = batch + neighbours): one byte map per batch at maps + s * map_stride (map_stride >= pcg_touched_bytes(n_nodes),
+ * a multiple of 16; maps 16-byte aligned) - zeroed, then 1 for every centre of the batch and every neighbour it has in any
+ * relation.  Two launches for ALL batches: per epoch, like pcg_plan_batches - it depends on the picks and the CSR only. */
+int64_t pcg_touched_bytes(int64_t n_nodes);
+int pcg_mark_touched(const pcg_graph_desc *g, const int32_t *nodes, int32_t n_total, int32_t B, uint8_t *maps,
+                     int64_t map_stride, void *stream);
 int pcg_train_dense(const pcg_graph_desc *g, float *theta, float *m, float *v, int32_t emb, const int32_t *ids,
                     const int32_t *labels, int32_t B, const float *agg, int32_t agg_stride, const int32_t *cnt,
                     const void *workspace, const void *plan, int64_t list_capacity, float lambda_1, float inv_count, float *logits,

@@ -541,8 +541,10 @@ __global__ void __launch_bounds__(FRONT_COUNT_THREADS) front_a_kernel(const Choo
                                                                       const float *__restrict__ W, const float *__restrict__ bias,
                                                                       int64_t row_begin, int64_t row_end, float *__restrict__ s0,
                                                                       const DeferredAdam ad, int n_adam_blocks,
-                                                                      const int32_t *__restrict__ row_ids, int64_t pos_row_base) {
+                                                                      const int32_t *__restrict__ row_ids, int64_t pos_row_base,
+                                                                      const unsigned char *__restrict__ touched) {
     __shared__ float part[4][PCG_WAVE];
+    __shared__ unsigned short sel[4 * MARK_GROUP];       // score_marked_body
     const int b = (int)blockIdx.x;
     if (a.sort_done && b == 0 && threadIdx.x == 0) a.sort_done[0] = 0u;
     if (b < n_plan_blocks)
@@ -554,7 +556,11 @@ __global__ void __launch_bounds__(FRONT_COUNT_THREADS) front_a_kernel(const Choo
         if (ad.pending[0] != 0u)                    // (one word, the same for every thread)
             adam_reduce_body(ad.theta, ad.m, ad.v, ad.slabs, (int)ad.pending[1], ad.n_params, 0, ad.p_end, ad.step_counter, ad.h,
                              nullptr, 1, b - n_plan_blocks - n_key_blocks, part);
-    } else
+    } else if (touched)       // only the rows the batch's selection can read (the whole table: row_begin == 0, no row_ids)
+        score_marked_body(a.g.X, a.g.feat_dim, a.g.feat_stride, W, bias, row_end, s0, touched,
+                          b - n_plan_blocks - n_key_blocks - n_adam_blocks,
+                          (int)gridDim.x - n_plan_blocks - n_key_blocks - n_adam_blocks, sel);
+    else
         score_table_body(a.g.X, a.g.feat_dim, a.g.feat_stride, W, bias, row_begin, row_end, s0,
                          b - n_plan_blocks - n_key_blocks - n_adam_blocks,
                          (int)gridDim.x - n_plan_blocks - n_key_blocks - n_adam_blocks, row_ids);
@@ -778,7 +784,8 @@ static int front_a(const pcg_graph_desc *g, const float *W, const float *b, int6
                    float *s0_out, const int32_t *row_ids, uint64_t *pos_keys, const int32_t *nodes, const int32_t *labels, int32_t B,
                    const double *thresholds, const double *rho, int32_t train_flag, int32_t add_self, void *workspace,
                    int64_t list_capacity, uint32_t *status, const pcg::DeferredAdam *ad, void *stream, bool no_plan = false,
-                   uint32_t *zero_word = nullptr, int64_t pos_row_base = -1) {
+                   uint32_t *zero_word = nullptr, int64_t pos_row_base = -1, const uint8_t *touched = nullptr) {
+    if (touched && (row_ids || row_begin != 0 || g->feat_stride > 512)) return PCG_E_ARG;
     if (!g || !g->X || !W || !b || !s0_out || B < 0) return PCG_E_ARG;
     if (g->feat_dim < 1 || g->feat_stride < g->feat_dim || g->feat_stride % 4 != 0) return PCG_E_ARG;
     if ((reinterpret_cast<uintptr_t>(g->X) & 15u) != 0) return PCG_E_ARG;
@@ -810,7 +817,7 @@ static int front_a(const pcg_graph_desc *g, const float *W, const float *b, int6
     const int n_adam = ad ? (int)((ad->p_end + PCG_WAVE - 1) / PCG_WAVE) : 0;
     hipLaunchKernelGGL(pcg::front_a_kernel, dim3(n_count + n_key + n_adam + n_score), dim3(pcg::FRONT_COUNT_THREADS), 0,
                        static_cast<hipStream_t>(stream), a, tot, n_count, n_key, raw_keys, W, b, row_begin, row_end, s0_out,
-                       ad ? *ad : none, n_adam, row_ids, pos_row_base);
+                       ad ? *ad : none, n_adam, row_ids, pos_row_base, touched);
     PCG_LAUNCH_CHECK();
     return PCG_OK;
 }
@@ -891,7 +898,7 @@ int pcg_step_front_train(const pcg_graph_desc *g, float *theta, float *m, float 
  * positives: the bucket sort's own launches follow here and the keys are sorted on return. */
 int pcg_step_scores_train(const pcg_graph_desc *g, float *theta, float *m, float *v, int32_t emb, float *s0, uint64_t *pos_keys,
                           const float *slabs, const int32_t *step_counter, uint32_t *sync_words, double lr, double beta1,
-                          double beta2, double eps, double weight_decay, void *stream) {
+                          double beta2, double eps, double weight_decay, const uint8_t *touched, void *stream) {
     if (!g || !theta || !m || !v || !slabs || !step_counter || !sync_words) return PCG_E_ARG;
     if (g->n_pos > 0 && (!pos_keys || !g->train_pos)) return PCG_E_ARG;
     const int64_t n_params = pcg_dense_n_params(g->feat_dim, emb, g->n_rel);
@@ -906,7 +913,7 @@ int pcg_step_scores_train(const pcg_graph_desc *g, float *theta, float *m, float
     ad.pending = sync_words + 1;
     ad.h = {(float)lr, (float)beta1, (float)beta2, (float)eps, (float)weight_decay};
     const int rc = front_a(g, theta + o_clf, theta + o_b, 0, g->n_nodes, s0, nullptr, pos_keys, nullptr, nullptr, 0, nullptr, nullptr, 1, 0,
-                           nullptr, 1, nullptr, &ad, stream, true, sync_words + 3);
+                           nullptr, 1, nullptr, &ad, stream, true, sync_words + 3, -1, touched);
     if (rc != PCG_OK) return rc;
     if (g->n_pos > pcg::RANK_MAX) return pcg_pos_sort(g, s0, pos_keys, stream);
     return PCG_OK;

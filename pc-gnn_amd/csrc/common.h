@@ -193,6 +193,103 @@ __device__ __forceinline__ void score_table_body(const float *__restrict__ X, in
     }
 }
 
+// The same scores for the rows a byte map marks (touched[row] != 0), and only for them: what a large graph's training step
+// needs - a batch's selection reads the scores of its centres' neighbours, a fraction of the table (10 M nodes, batch 4096: ~15 %
+// of the rows; streaming all 1.28 GB was 42 % of the step).  A wave takes 512 rows at a time: their marks are one 8-byte load per
+// lane, the marked rows' offsets are compacted into the wave's LDS list (prefix sum over the lanes' counts), and the list is
+// worked off like score_table_body works off consecutive rows - the same lanes-per-row geometry, the same fma chain, the same
+// butterfly: the score of a marked row is bit for bit score_table_body's.  The map is padded: 8-byte loads up to
+// touched_bytes(n) never leave it, and rows beyond the table are unmarked.  sel: 4 x 512 uint16 of LDS per 256-thread workgroup.
+constexpr int MARK_GROUP = 512;
+__host__ __device__ __forceinline__ int64_t touched_bytes(int64_t n_rows) { return (n_rows + 2 * MARK_GROUP - 1) / MARK_GROUP * MARK_GROUP; }
+__device__ __forceinline__ void score_marked_body(const float *__restrict__ X, int feat_dim, int stride, const float *__restrict__ W,
+                                                  const float *__restrict__ bias, int64_t n_rows, float *__restrict__ s0,
+                                                  const unsigned char *__restrict__ touched, int block, int n_blocks,
+                                                  unsigned short *sel_all) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int lane = lane_id();
+    const int lpr = lanes_per_row(stride);
+    const int rpw = PCG_WAVE / lpr;
+    const int slot = lane / lpr, sub = lane % lpr;
+    const int64_t wave_global = (int64_t)block * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)n_blocks * (blockDim.x >> 6);
+    unsigned short *sel = sel_all + (threadIdx.x >> 6) * MARK_GROUP;
+    const float b0 = bias[0];
+    const int nch = stride >> 2;
+    constexpr int SCORE_K = 2;
+    bool has[SCORE_K];
+    int chc[SCORE_K];
+    float wv[SCORE_K][4];
+#pragma unroll
+    for (int k = 0; k < SCORE_K; ++k) {                                   // (as score_table_body: a lane's weights, loaded once)
+        const int ch = sub + k * lpr;
+        has[k] = ch < nch;
+        chc[k] = has[k] ? ch : nch - 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = 4 * chc[k] + j;
+            const float wj = W[f < feat_dim ? f : feat_dim - 1];
+            wv[k][j] = __int_as_float(__float_as_int(wj) & ((has[k] && f < feat_dim) ? -1 : 0));
+        }
+    }
+    const bool two = lpr < nch;
+    for (int64_t base = wave_global * MARK_GROUP; base < n_rows; base += n_waves * MARK_GROUP) {
+        const uint64_t mk = *reinterpret_cast<const uint64_t *>(touched + base + 8 * lane);
+        int cnt = 0;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) cnt += ((mk >> (8 * b)) & 0xFFull) != 0ull;
+        // inclusive scan of the lanes' counts (DPP row shifts inside every 16-lane row, then the rows' totals)
+        int inc = cnt;
+        inc += (int)__builtin_amdgcn_update_dpp(0, inc, 0x111, 0xF, 0xF, false);
+        inc += (int)__builtin_amdgcn_update_dpp(0, inc, 0x112, 0xF, 0xF, false);
+        inc += (int)__builtin_amdgcn_update_dpp(0, inc, 0x114, 0xF, 0xF, false);
+        inc += (int)__builtin_amdgcn_update_dpp(0, inc, 0x118, 0xF, 0xF, false);
+        const int t0 = __builtin_amdgcn_readlane(inc, 15), t1 = __builtin_amdgcn_readlane(inc, 31), t2 = __builtin_amdgcn_readlane(inc, 47);
+        const int rw = lane >> 4;
+        inc += (rw > 0 ? t0 : 0) + (rw > 1 ? t1 : 0) + (rw > 2 ? t2 : 0);
+        const int total = __builtin_amdgcn_readlane(inc, PCG_WAVE - 1);
+        if (total == 0) continue;                                         // (wave-uniform)
+        int at = inc - cnt;
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+            if (((mk >> (8 * b)) & 0xFFull) != 0ull) sel[at++] = (unsigned short)(8 * lane + b);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // (this wave's own LDS list: written above, read below)
+        __builtin_amdgcn_wave_barrier();
+        for (int i0 = 0; i0 < total; i0 += rpw * SCORE_UNROLL) {
+            f4 xv[SCORE_UNROLL][SCORE_K];
+            int64_t rid[SCORE_UNROLL];
+#pragma unroll
+            for (int u = 0; u < SCORE_UNROLL; ++u) {                       // (unconditional loads: a slot beyond the list re-reads its last row)
+                const int j = i0 + u * rpw + slot;
+                const int64_t row = base + sel[j < total ? j : total - 1];
+                rid[u] = j < total ? row : -1;
+                const float *xrow = X + row * stride;
+                xv[u][0] = *reinterpret_cast<const f4 *>(xrow + 4 * chc[0]);
+                if (two) xv[u][1] = *reinterpret_cast<const f4 *>(xrow + 4 * chc[1]);
+            }
+#pragma unroll
+            for (int u = 0; u < SCORE_UNROLL; ++u) {
+                float q = 0.f;
+                if (has[0]) {
+                    q = fmaf(xv[u][0].x, wv[0][0], q);
+                    q = fmaf(xv[u][0].y, wv[0][1], q);
+                    q = fmaf(xv[u][0].z, wv[0][2], q);
+                    q = fmaf(xv[u][0].w, wv[0][3], q);
+                }
+                if (two && has[1]) {
+                    q = fmaf(xv[u][1].x, wv[1][0], q);
+                    q = fmaf(xv[u][1].y, wv[1][1], q);
+                    q = fmaf(xv[u][1].z, wv[1][2], q);
+                    q = fmaf(xv[u][1].w, wv[1][3], q);
+                }
+                const float sc = score_reduce(q, lpr);
+                if (sub == 0 && rid[u] >= 0) s0[rid[u]] = sc + b0;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                                   // (the list is rewritten by the next group)
+    }
+}
+
 // number of 256-thread workgroups score_table uses for n rows (8 per CU at most, grid-stride beyond)
 __host__ __forceinline__ int64_t score_table_blocks(int64_t n_rows, int stride) {
     const int rpw = PCG_WAVE / lanes_per_row(stride);

@@ -56,6 +56,56 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const float *__restric
     }
 }
 
+// ---- which rows a batch's selection can read: a byte map per batch, built once per epoch (it depends on the picked ids and the
+// CSR rows only, like the plan): the centres and every neighbour they have in any relation
+__global__ void __launch_bounds__(256) zero_bytes_kernel(uint4 *__restrict__ p, int64_t n16) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+struct MarkArgs {
+    const int32_t *nodes;
+    int32_t n_total, B, n_rel;
+    const int64_t *indptr[PCG_MAX_REL];
+    const int32_t *indices[PCG_MAX_REL];
+    unsigned char *maps;
+    int64_t map_stride, n_nodes;
+};
+__global__ void __launch_bounds__(256) mark_touched_kernel(const MarkArgs a) {
+    const int lane = lane_id();
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    // items in batch-major order: the waves in flight work on two or three batches' maps (a map is one byte per node: 10 MB at
+    // 10 M nodes), not on all of them at once - the scattered one-byte stores then mostly find their line in a cache
+    const int n_slots = (a.n_total + a.B - 1) / a.B;
+    const int64_t per_slot = (int64_t)a.n_rel * a.B;
+    const int64_t items = per_slot * n_slots;
+    for (int64_t it = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); it < items; it += nwaves) {
+        const int slot = (int)(it / per_slot);
+        const int rem = (int)(it - (int64_t)slot * per_slot);
+        const int r = rem / a.B;
+        const int i = slot * a.B + (rem - r * a.B);
+        if (i >= a.n_total) continue;                                       // (the last batch may be shorter)
+        const int32_t node = a.nodes[i];
+        unsigned char *__restrict__ map = a.maps + (int64_t)(i / a.B) * a.map_stride;
+        if (r == 0 && lane == 0) map[node] = 1;                              // the centre's own score is read too
+        const int64_t beg = a.indptr[r][node], end = a.indptr[r][node + 1];
+        const int32_t *__restrict__ nbr = a.indices[r];
+        constexpr int CU = 4;                                               // four loads of 64 ids in flight (unconditional: clamped)
+        for (int64_t j0 = beg; j0 < end; j0 += CU * PCG_WAVE) {
+            int32_t idv[CU];
+#pragma unroll
+            for (int u = 0; u < CU; ++u) {
+                const int64_t j = j0 + u * PCG_WAVE + lane;
+                idv[u] = nbr[j < end ? j : end - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < CU; ++u) {
+                const int64_t j = j0 + u * PCG_WAVE + lane;
+                if (j < end && (uint32_t)idv[u] < (uint64_t)a.n_nodes) map[idv[u]] = 1;
+            }
+        }
+    }
+}
+
 static int check_graph_features(const pcg_graph_desc *g) {
     if (!g || !g->X || g->feat_dim < 1 || g->feat_stride < g->feat_dim || g->feat_stride % 4 != 0) return PCG_E_ARG;
     if ((reinterpret_cast<uintptr_t>(g->X) & 15u) != 0) return PCG_E_ARG;
@@ -74,6 +124,44 @@ int pcg_score_table(const pcg_graph_desc *g, const float *W, const float *b, int
     const int64_t blocks = pcg::score_table_blocks(row_end - row_begin, g->feat_stride);
     hipLaunchKernelGGL(pcg::score_table_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
                        g->X, g->feat_dim, g->feat_stride, W, b, row_begin, row_end, s0);
+    PCG_LAUNCH_CHECK();
+    return PCG_OK;
+}
+
+int64_t pcg_touched_bytes(int64_t n_nodes) { return n_nodes < 0 ? PCG_E_ARG : pcg::touched_bytes(n_nodes); }
+
+/* byte maps of the rows the batches nodes[s * B, min((s + 1) * B, n_total)) can read the score of: maps + s * map_stride
+ * (map_stride >= pcg_touched_bytes(n_nodes), a multiple of 16) is zeroed, then map[v] = 1 for every centre v of batch s and every
+ * neighbour of v in any relation.  Two launches for all batches (per epoch, like pcg_plan_batches). */
+int pcg_mark_touched(const pcg_graph_desc *g, const int32_t *nodes, int32_t n_total, int32_t B, uint8_t *maps, int64_t map_stride,
+                     void *stream) {
+    if (!g || !nodes || n_total < 0 || B < 1 || !maps || g->n_rel < 1 || g->n_rel > PCG_MAX_REL) return PCG_E_ARG;
+    if (map_stride < pcg::touched_bytes(g->n_nodes) || (map_stride & 15) != 0 || (reinterpret_cast<uintptr_t>(maps) & 15u) != 0)
+        return PCG_E_ARG;
+    if (n_total == 0) return PCG_OK;
+    const int n_slots = (n_total + B - 1) / B;
+    pcg::MarkArgs a;
+    a.nodes = nodes;
+    a.n_total = n_total;
+    a.B = B;
+    a.n_rel = g->n_rel;
+    for (int r = 0; r < PCG_MAX_REL; ++r) {
+        a.indptr[r] = r < g->n_rel ? g->indptr[r] : nullptr;
+        a.indices[r] = r < g->n_rel ? g->indices[r] : nullptr;
+        if (r < g->n_rel && (!a.indptr[r] || !a.indices[r])) return PCG_E_ARG;
+    }
+    a.maps = maps;
+    a.map_stride = map_stride;
+    a.n_nodes = g->n_nodes;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t n16 = (int64_t)n_slots * map_stride / 16;
+    int zb = (int)((n16 + 255) / 256);
+    zb = zb > 4096 ? 4096 : zb;
+    hipLaunchKernelGGL(pcg::zero_bytes_kernel, dim3(zb), dim3(256), 0, st, reinterpret_cast<uint4 *>(maps), n16);
+    PCG_LAUNCH_CHECK();
+    int64_t mb = ((int64_t)g->n_rel * n_total + 3) / 4;
+    mb = mb > 2048 ? 2048 : mb;
+    hipLaunchKernelGGL(pcg::mark_touched_kernel, dim3((int)mb), dim3(256), 0, st, a);
     PCG_LAUNCH_CHECK();
     return PCG_OK;
 }

@@ -85,6 +85,15 @@ class FusedPCGNN:
         self.sync = torch.zeros(int(lib.pcg_sync_words_count()), dtype=torch.int32, device=self.dev)
         self.n_rest = int(lib.pcg_dense_param_offset(self.F, self.E, self.R, 3, 0))   # parameters before the label classifier
 
+        # Score only the rows a batch's selection can read (its centres and their neighbours: a byte map per batch, built per epoch
+        # beside the plans) instead of the whole table - worth it when the table is far larger than what a batch touches
+        # (PCG_TOUCHED=0/1 overrides; default: tables of 512 MB and more.  Measured, power-law graphs, batch 4096: 10 M nodes
+        #  (1.28 GB): score pass 232 -> 63 us per step for ~35 us per step of map building; 2 M nodes (256 MB): 48 -> 25 us for
+        #  ~30 us - not worth it there)
+        import os
+        env = os.environ.get("PCG_TOUCHED")
+        self.touched_on = (env == "1") if env in ("0", "1") else g.n_nodes * g.X.stride(0) * 4 >= (512 << 20)
+        self._touch_stride = int(lib.pcg_touched_bytes(g.n_nodes)) if self.touched_on else 0
         self._list_capacity_arg = list_capacity  # entries of the selection list (None: worst case of the graph)
         self.status = torch.zeros(1, dtype=torch.int32, device=self.dev)   # ONE device status word
         self._graphs = {}
@@ -118,6 +127,7 @@ class FusedPCGNN:
             raise _lib.PcgnnLibraryError("pcg_choose_data_bytes rejected the arguments")
         self.data = torch.zeros(int(nbytes), dtype=torch.uint8, device=dev)     # list | partial sums | key scratch: shared by every plan
         self._plans = {}                                                        # batch size -> a single plan slot (calls outside an epoch)
+        self._touch_one = None                                                  # ... and their byte map of touched rows
         self.agg = torch.empty(g.R, B, g.feat_dim, dtype=torch.float32, device=dev)
         self.cnt = torch.empty(g.R, B, dtype=torch.int32, device=dev)
         self.logits = torch.empty(B, 2, dtype=torch.float32, device=dev)
@@ -153,10 +163,21 @@ class FusedPCGNN:
             _p(plans), stride, self.list_capacity, _p(self.status), _p(bump_counter), self._stream()), "pcg_plan_batches")
 
     def _enqueue_plan_one(self, ids, labels, B, train_flag) -> int:
-        """plan of ONE batch into this batch size's own slot; returns the slot's address"""
+        """plan of ONE batch into this batch size's own slot (+ its touched-row map); returns the slot's address"""
         slot = self._plan_slot(B)
         self._enqueue_plan(ids, labels, B, B, slot, slot.numel(), train_flag)
+        if self.touched_on and train_flag:
+            if self._touch_one is None:
+                if torch.cuda.is_current_stream_capturing():
+                    raise _lib.PcgnnLibraryError("first use of the touched-row map inside a graph capture: warm up before capturing")
+                self._touch_one = torch.zeros(self._touch_stride, dtype=torch.uint8, device=self.dev)
+            self._enqueue_mark(ids, B, B, self._touch_one)
         return slot.data_ptr()
+
+    def _enqueue_mark(self, ids, n_total, B, maps: torch.Tensor):
+        """byte maps of the rows each batch's selection can read (two launches for all batches)"""
+        _lib.check(self.lib.pcg_mark_touched(self.g.desc_ref(), _p(ids), n_total, B, _p(maps), self._touch_stride, self._stream()),
+                   "pcg_mark_touched")
 
     def _enqueue_scores(self, train_flag):
         """label-aware score table + per-step sort of the train positives (the calls of their own: evaluation, parity)."""
@@ -164,14 +185,15 @@ class FusedPCGNN:
         ops.score_table(g, self.w_clf, self.b_clf, out=self.s0)
         return ops.pos_sort(g, self.s0, self.keys) if (train_flag and g.n_pos) else None
 
-    def _enqueue_scores_train(self):
-        """the front of a training step: score pass || train-pos keys (unsorted) || the previous step's deferred Adam update."""
+    def _enqueue_scores_train(self, touched: Optional[int] = None):
+        """the front of a training step: score pass || train-pos keys (unsorted) || the previous step's deferred Adam update.
+        touched: address of the batch's byte map - only the rows it marks are scored."""
         g = self.g
         b1, b2 = self.betas
         _lib.check(self.lib.pcg_step_scores_train(
             g.desc_ref(), _p(self.theta), _p(self.m), _p(self.v), self.E, _p(self.s0), _p(self.keys) if g.n_pos else None,
-            _p(self.slabs), _p(self.step_counter), _p(self.sync), self.lr, b1, b2, self.eps, self.wd, self._stream()),
-            "pcg_step_scores_train")
+            _p(self.slabs), _p(self.step_counter), _p(self.sync), self.lr, b1, b2, self.eps, self.wd,
+            None if touched is None else C.c_void_p(touched), self._stream()), "pcg_step_scores_train")
         return self.keys if g.n_pos else None
 
     def _enqueue_choose(self, ids, labels, B, keys, train_flag, plan: int, sort_in_kernel: bool):
@@ -218,9 +240,9 @@ class FusedPCGNN:
             _p(self.theta), _p(self.m), _p(self.v), _p(self.slabs), 0, self.n_params, self.n_rest, _p(self.step_counter),
             _p(self.sync), self.lr, b1, b2, self.eps, self.wd, self._stream()), "pcg_adam_flush")
 
-    def _enqueue_step(self, ids, labels, B, plan: int, defer: bool):
+    def _enqueue_step(self, ids, labels, B, plan: int, defer: bool, touched: Optional[int] = None):
         """the four launches of one training step over an existing plan (+ the flush unless deferred)."""
-        keys = self._enqueue_scores_train()
+        keys = self._enqueue_scores_train(touched)
         agg, _ = self._enqueue_choose(ids, labels, B, keys, True, plan, sort_in_kernel=True)
         self._enqueue_tail(ids, labels, B, agg, plan, True)
         if not defer:
@@ -243,7 +265,8 @@ class FusedPCGNN:
         self._enqueue_tail(ids, labels, B, agg, plan, True, adam_clf=False)
 
     # ------------------------------------------------------------------
-    def train_step(self, ids: torch.Tensor, labels: torch.Tensor, allreduce=None, defer: bool = False, plan: Optional[int] = None):
+    def train_step(self, ids: torch.Tensor, labels: torch.Tensor, allreduce=None, defer: bool = False, plan: Optional[int] = None,
+                   touched: Optional[int] = None):
         """zero_grad + loss + backward + Adam step for one batch (model_handler.py:149-153).
         ids / labels: int32 device tensors.  Nothing is returned and nothing syncs;
         ``last_loss()`` reads the batch loss afterwards.  ``allreduce(flat_grad)`` (data-parallel
@@ -260,7 +283,8 @@ class FusedPCGNN:
         if allreduce is None:
             if plan is None:
                 plan = self._enqueue_plan_one(ids, labels, B, True)
-            self._enqueue_step(ids, labels, B, plan, defer)
+                touched = self._touch_one.data_ptr() if self.touched_on else None
+            self._enqueue_step(ids, labels, B, plan, defer, touched)
             return
         # data-parallel ranks: gradient of the local batch -> all-reduce -> the same Adam on every rank
         self.flush()
@@ -331,7 +355,7 @@ class FusedPCGNN:
 
         def pre():
             self._enqueue_plan_one(ids, lab, B, True)
-            self._enqueue_scores_train()
+            self._enqueue_scores_train(self._touch_one.data_ptr() if self.touched_on else None)
 
         def post():
             self._enqueue_tail(ids, lab, B, agg, plan, True)
@@ -380,7 +404,9 @@ class FusedPCGNN:
                 raise _lib.PcgnnLibraryError("stage_epoch with a new shape inside a graph capture")
             self._ep_sets = [dict(ids=torch.zeros(n, dtype=torch.int32, device=self.dev),
                                   lab=torch.zeros(n, dtype=torch.int32, device=self.dev),
-                                  plans=torch.zeros(nb * stride, dtype=torch.uint8, device=self.dev)) for _ in range(2)]
+                                  plans=torch.zeros(nb * stride, dtype=torch.uint8, device=self.dev),
+                                  touched=torch.zeros(nb * self._touch_stride, dtype=torch.uint8, device=self.dev)
+                                  if self.touched_on else None) for _ in range(2)]
             self._ep_stride = stride
             self._cur, self._cur_ready = 0, False
             self._ep_graphs.clear()
@@ -398,9 +424,16 @@ class FusedPCGNN:
         the epoch's first step).  bump_counter: the sampler's device epoch counter, incremented by the first of them."""
         st = self._ep_sets[self._cur if which is None else which]
         self._enqueue_plan(st["ids"], st["lab"], self._ep_n, self._ep_bs, st["plans"], self._ep_stride, True, bump_counter)
+        if self.touched_on:
+            self._enqueue_mark(st["ids"], self._ep_n, self._ep_bs, st["touched"])
 
     def _ep_plan(self, b: int, which: Optional[int] = None) -> int:
         return self._ep_sets[self._cur if which is None else which]["plans"].data_ptr() + b * self._ep_stride
+
+    def _ep_touch(self, b: int, which: Optional[int] = None) -> Optional[int]:
+        if not self.touched_on:
+            return None
+        return self._ep_sets[self._cur if which is None else which]["touched"].data_ptr() + b * self._touch_stride
 
     def begin_epoch(self, ids: torch.Tensor, labels: torch.Tensor, batch_size: int):
         """Stage an epoch's (already shuffled) ids and labels and plan its batches; afterwards ``epoch_step(b)`` is exactly
@@ -426,7 +459,7 @@ class FusedPCGNN:
         gr = self._ep_graphs.get(key)
         if gr is None:
             ids, lab = self._ep_ids[lo:lo + B], self._ep_lab[lo:lo + B]
-            gr = self._capture_graphs([lambda: self.train_step(ids, lab, defer=defer, plan=self._ep_plan(b))])[0]
+            gr = self._capture_graphs([lambda: self.train_step(ids, lab, defer=defer, plan=self._ep_plan(b), touched=self._ep_touch(b))])[0]
             self._ep_graphs[key] = gr
         gr.replay()
 
@@ -449,8 +482,9 @@ class FusedPCGNN:
         agg = self.agg.view(-1)[:g.R * B * g.feat_dim].view(g.R, B, g.feat_dim)
         keys = self.keys if g.n_pos else None
         last = lo + B >= self._ep_n               # the epoch's last batch: nothing follows that would apply the deferred update
+        touched = self._ep_touch(b)
         if eager:
-            self._enqueue_scores_train()
+            self._enqueue_scores_train(touched)
             self._enqueue_choose(ids, lab, B, keys, True, plan, sort_in_kernel=True)     # (records the two events itself)
             self._enqueue_tail(ids, lab, B, agg, plan, True)
             if last:
@@ -458,7 +492,7 @@ class FusedPCGNN:
             self.last_counts = self.cnt.view(-1)[:g.R * B].view(g.R, B)
             return
         if grs is None:
-            parts = (lambda: self._enqueue_scores_train(),
+            parts = (lambda: self._enqueue_scores_train(touched),
                      lambda: self._enqueue_choose(ids, lab, B, keys, True, plan, sort_in_kernel=True),
                      lambda: (self._enqueue_tail(ids, lab, B, agg, plan, True), self.flush() if last else None))
             grs = self._capture_graphs(list(parts))
@@ -500,7 +534,8 @@ class FusedPCGNN:
                 for b in range(n_steps):
                     lo = b * self._ep_bs
                     B = min(self._ep_bs, n - lo)
-                    self.train_step(st["ids"][lo:lo + B], st["lab"][lo:lo + B], defer=True, plan=self._ep_plan(b, cur))
+                    self.train_step(st["ids"][lo:lo + B], st["lab"][lo:lo + B], defer=True, plan=self._ep_plan(b, cur),
+                                    touched=self._ep_touch(b, cur))
                 if flush:
                     self.flush()
             def warm_run():                      # (the warm-up leaves the staged ids - and the epoch counter - as they are)

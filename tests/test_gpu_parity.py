@@ -988,7 +988,7 @@ def test_epoch_plans_and_in_kernel_sort_equal_separate_calls(P, B, n_pos):
         # the planned path: scores + unsorted keys, then select (sorting inside) + gather over slot s and the shared data part
         keys_b.zero_()
         _lib.check(lib.pcg_step_scores_train(g.desc_ref(), _p(theta), _p(m), _p(v), E, _p(s0_b), _p(keys_b), _p(slabs), _p(step), _p(sync),
-                                             0.01, 0.9, 0.999, 1e-8, 0.0, st), "pcg_step_scores_train")
+                                             0.01, 0.9, 0.999, 1e-8, 0.0, None, st), "pcg_step_scores_train")
         agg_b = torch.full((R, Bs, F), float("nan"), device=dev())
         cnt_b = torch.zeros(R, Bs, dtype=torch.int32, device=dev())
         _lib.check(lib.pcg_choose_gather_planned(g.desc_ref(), _p(ids[sl]), _p(lab[sl]), Bs, _p(s0_b), None, _p(keys_b), thr_c, rho_c, 1, 0,
@@ -1021,6 +1021,95 @@ def test_epoch_plans_and_in_kernel_sort_equal_separate_calls(P, B, n_pos):
         single = torch.from_numpy(np.diff(chunks) == 1).cuda().view(R, Bs)
         assert single.any() and torch.equal(agg_a.view(torch.int32)[single], agg_b.view(torch.int32)[single])
     assert int(bump[0].item()) == 1
+
+
+def test_touched_rows_only_scoring(P, monkeypatch):
+    """Large-table mode: pcg_mark_touched builds a byte map per batch (centres + all their neighbours) and
+    pcg_step_scores_train(touched) scores only the rows it marks - bit for bit the whole-table scores on those rows, the other
+    entries of s0 untouched; the marks are exactly the batch's centres and neighbours; and two epochs of training with the mode
+    forced on leave bit for bit the parameters of two epochs without it."""
+    from pcgnn_amd import _lib, synth
+    from pcgnn_amd.handler import PCGNNTrainer
+    lib = _lib.load()
+    ops = P.ops
+    _p = ops._p
+    w = synth.make_workload("mini", 9000, 32, (6000, 40000, 120000), 0.12, seed=3)
+    g = P.DeviceGraph(w.X, w.csr, w.train_pos, dev())
+    F, E, R = 32, 16, 3
+    gen = torch.Generator().manual_seed(2)
+    W, b = torch.randn(2, F, generator=gen).cuda(), torch.randn(2, generator=gen).cuda()
+    n_params = int(lib.pcg_dense_n_params(F, E, R))
+    theta = torch.zeros(n_params, device=dev())
+    o_w, o_b = int(lib.pcg_dense_param_offset(F, E, R, 3, 0)), int(lib.pcg_dense_param_offset(F, E, R, 4, 0))
+    theta[o_w:o_w + 2 * F] = W.reshape(-1)
+    theta[o_b:o_b + 2] = b
+    m, v, slabs = torch.zeros_like(theta), torch.zeros_like(theta), torch.zeros(4, n_params, device=dev())
+    step = torch.zeros(1, dtype=torch.int32, device=dev())
+    sync = torch.zeros(int(lib.pcg_sync_words_count()), dtype=torch.int32, device=dev())
+    B, n_total = 300, 700
+    rs = np.random.RandomState(1)
+    nodes = rs.randint(0, w.n, size=n_total).astype(np.int32)
+    ids = torch.from_numpy(nodes).cuda()
+    stride = int(lib.pcg_touched_bytes(w.n))
+    assert stride >= w.n + 8 and stride % 512 == 0
+    maps = torch.full((3 * stride,), 7, dtype=torch.uint8, device=dev())          # (garbage: the call zeroes the maps itself)
+    st = ops._stream(dev())
+    _lib.check(lib.pcg_mark_touched(g.desc_ref(), _p(ids), n_total, B, _p(maps), stride, st), "pcg_mark_touched")
+    s0_full = ops.score_table(g, W, b)
+    keys = torch.zeros(int(lib.pcg_pos_sort_capacity(g.n_pos)), dtype=torch.int64, device=dev())
+    for s_ in range(3):
+        sl = nodes[s_ * B:(s_ + 1) * B]
+        want = np.zeros(stride, dtype=np.uint8)
+        want[sl] = 1
+        for ip, ix in w.csr:
+            for v_ in sl:
+                want[ix[ip[v_]:ip[v_ + 1]]] = 1
+        got = maps[s_ * stride:(s_ + 1) * stride].cpu().numpy()
+        assert np.array_equal(got, want), f"batch {s_}: marks = centres + neighbours"
+        s0 = torch.full((w.n,), -12345.0, device=dev())
+        _lib.check(lib.pcg_step_scores_train(g.desc_ref(), _p(theta), _p(m), _p(v), E, _p(s0), _p(keys), _p(slabs), _p(step), _p(sync),
+                                             0.01, 0.9, 0.999, 1e-8, 0.0, ctypes_ptr(maps, s_ * stride), st), "pcg_step_scores_train")
+        torch.cuda.synchronize()
+        mk = torch.from_numpy(want[:w.n].astype(bool)).cuda()
+        assert 0 < int(mk.sum()) < w.n
+        assert torch.equal(s0[mk], s0_full[mk]), "touched rows: the whole-table scores, bit for bit"
+        assert bool((s0[~mk] == -12345.0).all()), "the other rows are left alone"
+    # training: the mode forced on == off, bit for bit (the selection never reads an unscored row)
+    cfg = dict(engine="graph", batch_size=256, seed=5)
+    monkeypatch.setenv("PCG_TOUCHED", "0")
+    a = PCGNNTrainer(w, cfg, dev())
+    monkeypatch.setenv("PCG_TOUCHED", "1")
+    t = PCGNNTrainer(w, cfg, dev())
+    assert t.fused.touched_on and not a.fused.touched_on
+    t.fused.theta.copy_(a.fused.theta)
+    for ep in range(2):
+        a.run_epoch_one_graph()
+        if ep == 0:
+            t.run_epoch_one_graph()
+        else:                                        # ... batch by batch too (per-batch graphs, an eager step, a stand-alone step)
+            ids_e = t.start_epoch_staged()
+            nb = t.batches_per_epoch()
+            for k in range(nb):
+                if k == 1:
+                    t.fused.epoch_step_timed(k)
+                else:
+                    t.fused.epoch_step(k, defer=True)
+    a.fused.flush(); t.fused.flush()
+    torch.cuda.synchronize()
+    t.fused.check()
+    for name in ("theta", "m", "v", "step_counter"):
+        assert torch.equal(getattr(a.fused, name), getattr(t.fused, name)), name
+    ids1 = a.fused._ep_ids[:256].clone()
+    lab1 = a.labels_i32[ids1.long()]
+    a.fused.train_step(ids1, lab1)
+    t.fused.train_step(ids1, lab1)
+    torch.cuda.synchronize()
+    assert torch.equal(a.fused.theta, t.fused.theta)
+
+
+def ctypes_ptr(t, byte_offset=0):
+    import ctypes as C
+    return C.c_void_p(t.data_ptr() + byte_offset)
 
 
 def test_fused_trajectory_tracks_oracle(P, case):
