@@ -559,16 +559,17 @@ def main():
         abytes = [algorithmic_bytes(tr.graph, i.cpu().numpy().astype(np.int64), c.cpu().numpy()) for i, c in used_ev]
         avg_ms = float(np.mean(kern_ms))
         achieved = float(np.mean(abytes)) / (avg_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_commit = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
                 # the PMC passes were run on one batch size per workload: yelp 1024, amazon 256 (their defaults)
                 tkey = (f"powerlaw_{args.nodes}_{args.edges}_b{B}" if args.workload == "powerlaw"
                         else args.workload if B == default_b else f"{args.workload}_b{B}")
-                traffic = json.load(open(tpath)).get(tkey, {}).get("choose_agg_bytes_per_launch")
+                entry = json.load(open(tpath)).get(tkey, {})
+                traffic, traffic_commit = entry.get("choose_agg_bytes_per_launch"), entry.get("commit")
             except Exception:
-                traffic = None
+                traffic, traffic_commit = None, None
         out = {
             "metric": "sampled-nodes/sec", "value": nodes_total / elapsed, "unit": "nodes/s",
             "n_gpus": world, "steps": args.steps, "warmup": warmup, "warmup_requested": args.warmup,
@@ -585,8 +586,10 @@ def main():
                        "global_batch": B * world, "parallelism": "single" if world == 1 else f"dp{world}-replicated-graph",
                        "engine": engine,
                        "nodes_processed": int(nodes_total)},
-            "roofline": {"bound": "hbm", "kernel": "pcg_choose_gather_planned (select_rows + gather_chunks; the plan rides along the score pass and the sort in pcg_step_front_train, multi-chunk sums are finished in the dense kernel's prologue)", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "pcg_choose_gather_planned (select_rows - which also sorts the train positives - + gather_chunks; the plan is made per epoch beside the sampler, multi-chunk sums are finished in the dense kernel's prologue)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_from": ("profiles/pmc_traffic.json: two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of this command at commit "
+                                          f"{traffic_commit}") if traffic is not None else None,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": float(np.mean(abytes)),
                          "launches_timed": len(kern_ms)},
         }
