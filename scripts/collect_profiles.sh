@@ -1,7 +1,8 @@
 #!/bin/bash
 # Runs on the GPU box (gpurun): bench lines, rocprofv3 kernel stats and the two PMC passes the numbers in DESIGN.md /
 # profiles/README.md come from.  Output under gpurun_out/$TAG/ (copied into profiles/rNN/ afterwards).
-#   PCG_COMMIT=<hash of the commit being profiled> bash scripts/collect_profiles.sh [TAG] [quick]
+#   PCG_COMMIT=<hash of the commit being profiled> bash scripts/collect_profiles.sh [TAG] [quick|big]
+#   quick: everything but the 10 M-node graph; big: the 10 M-node graph only (two calls fit gpurun's 20-minute limit)
 # (the box has no .git: every stats file gets a `# commit` line / a COMMIT file from PCG_COMMIT)
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -14,6 +15,7 @@ cd /tmp && export TMPDIR=/tmp
 stamp() { for f in "$@"; do [ -f "$f" ] && sed -i "1i # commit $PCG_COMMIT" "$f"; done; }
 PL="--workload powerlaw --nodes 2000000 --edges 40000000 --batch-size 4096"
 PL10="--workload powerlaw --nodes 10000000 --edges 200000000 --batch-size 4096"
+if [ "$2" != "big" ]; then
 echo "[collect] bench yelp"; python3 $R/bench.py > $O/bench_yelp.log 2>&1 || exit 1
 echo "[collect] bench yelp, as the driver runs it"; python3 $R/bench.py --steps 20 --warmup 5 > $O/bench_yelp_driver_style.log 2>&1 || exit 1
 echo "[collect] kernel trace yelp"; rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_yelp -o y -- python3 $R/bench.py --cpu-batches 0 > $O/trace_yelp.log 2>&1 || exit 1
@@ -36,6 +38,7 @@ stamp $O/trace_e128/y_kernel_stats.csv
 echo "[collect] partitioned path, world size 1"; rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_part -o y -- python3 $R/bench.py --force-partitioned --cpu-batches 0 > $O/bench_partitioned_w1.log 2>&1 || exit 1
 stamp $O/trace_part/y_kernel_stats.csv
 echo "[collect] two ranks on one GPU (gloo-staged collectives: plumbing only)"; PCG_BENCH_BACKEND=gloo python3 $R/bench.py --gpus 2 --steps 20 --warmup 5 > $O/bench_gloo_2ranks.log 2>&1 || exit 1
+fi
 if [ "$2" != "quick" ]; then
 echo "[collect] bench powerlaw 10M / 200M"; python3 $R/bench.py $PL10 --steps 60 --cpu-batches 0 > $O/bench_powerlaw_10m_200m.log 2>&1 || exit 1
 echo "[collect] kernel trace powerlaw 10M / 200M"; rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_pl10m -o y -- python3 $R/bench.py $PL10 --steps 40 --cpu-batches 0 --report-epochs 0 --verify-batches 0 > $O/trace_pl10m.log 2>&1 || exit 1
