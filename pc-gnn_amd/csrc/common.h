@@ -425,13 +425,14 @@ __device__ __forceinline__ void rank_sort_body(const float *__restrict__ s0, con
 // ---- Adam update of a range of the flat parameter buffer from per-tile gradient slabs -----------------------------------
 // (torch.optim.Adam with coupled L2 weight decay, src/model_handler.py:124,153).  Shared by the stand-alone kernel
 // (dense.hip) and the step-front kernel, where the update of the previous step rides along the score pass (choose.hip).
-// g = sum over slabs in a fixed order (8 interleaved partial sums per wave, then a fixed tree), so 8 slab reads are in
-// flight per thread and the result is bitwise reproducible.  Workgroup `block` (256 threads) owns 64 parameters
+// g = sum over slabs in a fixed order (ADAM_ACC interleaved partial sums per wave, then a fixed tree), so ADAM_ACC slab reads
+// are in flight per thread and the result is bitwise reproducible.  (16: a wave's share of a 64-tile batch's slabs is one round
+// of loads, not two.)  Workgroup `block` (256 threads) owns 64 parameters
 // [p_begin + 64 * block, ...) below p_end; the slabs are split over its 4 waves.  part: 4 * 64 floats of LDS.
 struct AdamHyper {
     float lr, beta1, beta2, eps, wd;
 };
-constexpr int ADAM_ACC = 8;
+constexpr int ADAM_ACC = 16;
 __device__ __forceinline__ void adam_reduce_body(float *__restrict__ theta, float *__restrict__ m, float *__restrict__ v,
                                                  const float *__restrict__ slabs, int n_slabs, int64_t n_params,
                                                  int64_t p_begin, int64_t p_end, const int32_t *__restrict__ step_counter,
@@ -461,7 +462,9 @@ __device__ __forceinline__ void adam_reduce_body(float *__restrict__ theta, floa
         }
         for (int u = 0; s < s_end; ++s, ++u) acc[u] += slabs[(size_t)s * n_params + i];
     }
-    part[w][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    static_assert(ADAM_ACC == 16, "the tree below adds sixteen partial sums");
+    part[w][lane] = (((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]))) +
+                    (((acc[8] + acc[9]) + (acc[10] + acc[11])) + ((acc[12] + acc[13]) + (acc[14] + acc[15])));
     __syncthreads();
     if (w != 0 || !ok) return;
     float g = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);

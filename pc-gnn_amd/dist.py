@@ -467,7 +467,7 @@ class DistributedPCGNN:
 
     # -- one step ---------------------------------------------------------------------------------
     def _plan(self, ids, labels, n_total, B, plans: torch.Tensor, train_flag: bool):
-        """plans of the batches ids[s * B : (s + 1) * B] into consecutive plan slots (two launches for all of them)"""
+        """plans of the batches ids[s * B : (s + 1) * B] into consecutive plan slots (one launch for all of them)"""
         _p = self.ops._p
         self._libmod.check(self.lib.pcg_plan_batches(
             self.g.desc_ref(), _p(ids), _p(labels if train_flag else None), n_total, B, self._thr, self._rhos, 1 if train_flag else 0, 0,
@@ -625,7 +625,7 @@ class DistributedPCGNN:
         if use_graphs and n <= self.win_ids.numel():
             self.win_ids[:n].copy_(ids_window_local)
             self.win_lab[:n].copy_(labels_window)
-            self._plan(self.win_ids, self.win_lab, n, self.B, self.win_plans, True)     # every batch of the window: two launches
+            self._plan(self.win_ids, self.win_lab, n, self.B, self.win_plans, True)     # every batch of the window: one launch
             for slot, b0 in enumerate(range(0, n, self.B)):
                 B = min(self.B, n - b0)
                 gr, ids = self._graph_for(B, slot)

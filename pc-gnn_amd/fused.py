@@ -420,8 +420,8 @@ class FusedPCGNN:
         return ready
 
     def plan_staged(self, bump_counter: Optional[torch.Tensor] = None, which: Optional[int] = None):
-        """Plan every batch of the staged epoch (set `which`, default the current one): two launches (after the sampler, before
-        the epoch's first step).  bump_counter: the sampler's device epoch counter, incremented by the first of them."""
+        """Plan every batch of the staged epoch (set `which`, default the current one): one launch (after the sampler, before
+        the epoch's first step).  bump_counter: the sampler's device epoch counter, incremented by it."""
         st = self._ep_sets[self._cur if which is None else which]
         self._enqueue_plan(st["ids"], st["lab"], self._ep_n, self._ep_bs, st["plans"], self._ep_stride, True, bump_counter)
         if self.touched_on:
