@@ -350,8 +350,8 @@ int pcg_step_scores_train(const pcg_graph_desc *g, float *theta, float *m, float
                           void *stream);
 /* Which rows the batches nodes[s * B, min((s + 1) * B, n_total)) can read the score of (src/layers.py:226-237 scores exactly
  * `unique_nodes` = batch + neighbours): one byte map per batch at maps + s * map_stride (map_stride >= pcg_touched_bytes(n_nodes),
- * a multiple of 16; maps 16-byte aligned) - zeroed, then 1 for every centre of the batch and every neighbour it has in any
- * relation.  Two launches for ALL batches: per epoch, like pcg_plan_batches - it depends on the picks and the CSR only. */
+ * a multiple of 16; maps 16-byte aligned) - zeroed, then 1 for every centre of the batch, every neighbour it has in any
+ * relation, and every train positive (their scores feed pcg_pos_sort when there are more than 16384 of them).  Two launches for ALL batches: per epoch, like pcg_plan_batches - it depends on the picks and the CSR only. */
 int64_t pcg_touched_bytes(int64_t n_nodes);
 int pcg_mark_touched(const pcg_graph_desc *g, const int32_t *nodes, int32_t n_total, int32_t B, uint8_t *maps,
                      int64_t map_stride, void *stream);

@@ -69,6 +69,8 @@ struct MarkArgs {
     const int32_t *indices[PCG_MAX_REL];
     unsigned char *maps;
     int64_t map_stride, n_nodes;
+    const int32_t *train_pos;          // their scores are read too: by the train-pos sort when there are too many of them for the
+    int32_t n_pos;                     // front launch to form the keys from the feature rows (pcg_pos_sort reads s0[train_pos])
 };
 __global__ void __launch_bounds__(256) mark_touched_kernel(const MarkArgs a) {
     const int lane = lane_id();
@@ -76,6 +78,14 @@ __global__ void __launch_bounds__(256) mark_touched_kernel(const MarkArgs a) {
     // items in batch-major order: the waves in flight work on two or three batches' maps (a map is one byte per node: 10 MB at
     // 10 M nodes), not on all of them at once - the scattered one-byte stores then mostly find their line in a cache
     const int n_slots = (a.n_total + a.B - 1) / a.B;
+    {
+        const int64_t nthreads = (int64_t)gridDim.x * blockDim.x, tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        for (int64_t i = tid; i < (int64_t)a.n_pos * n_slots; i += nthreads) {
+            const int slot = (int)(i / a.n_pos);
+            const int32_t v = a.train_pos[i - (int64_t)slot * a.n_pos];
+            if ((uint32_t)v < (uint64_t)a.n_nodes) a.maps[(int64_t)slot * a.map_stride + v] = 1;
+        }
+    }
     const int64_t per_slot = (int64_t)a.n_rel * a.B;
     const int64_t items = per_slot * n_slots;
     for (int64_t it = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); it < items; it += nwaves) {
@@ -131,8 +141,8 @@ int pcg_score_table(const pcg_graph_desc *g, const float *W, const float *b, int
 int64_t pcg_touched_bytes(int64_t n_nodes) { return n_nodes < 0 ? PCG_E_ARG : pcg::touched_bytes(n_nodes); }
 
 /* byte maps of the rows the batches nodes[s * B, min((s + 1) * B, n_total)) can read the score of: maps + s * map_stride
- * (map_stride >= pcg_touched_bytes(n_nodes), a multiple of 16) is zeroed, then map[v] = 1 for every centre v of batch s and every
- * neighbour of v in any relation.  Two launches for all batches (per epoch, like pcg_plan_batches). */
+ * (map_stride >= pcg_touched_bytes(n_nodes), a multiple of 16) is zeroed, then map[v] = 1 for every centre v of batch s, every
+ * neighbour of v in any relation, and every train positive.  Two launches for all batches (per epoch, like pcg_plan_batches). */
 int pcg_mark_touched(const pcg_graph_desc *g, const int32_t *nodes, int32_t n_total, int32_t B, uint8_t *maps, int64_t map_stride,
                      void *stream) {
     if (!g || !nodes || n_total < 0 || B < 1 || !maps || g->n_rel < 1 || g->n_rel > PCG_MAX_REL) return PCG_E_ARG;
@@ -153,6 +163,8 @@ int pcg_mark_touched(const pcg_graph_desc *g, const int32_t *nodes, int32_t n_to
     a.maps = maps;
     a.map_stride = map_stride;
     a.n_nodes = g->n_nodes;
+    a.train_pos = g->train_pos;
+    a.n_pos = g->train_pos ? g->n_pos : 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t n16 = (int64_t)n_slots * map_stride / 16;
     int zb = (int)((n16 + 255) / 256);

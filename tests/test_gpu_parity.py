@@ -1061,11 +1061,12 @@ def test_touched_rows_only_scoring(P, monkeypatch):
         sl = nodes[s_ * B:(s_ + 1) * B]
         want = np.zeros(stride, dtype=np.uint8)
         want[sl] = 1
+        want[np.asarray(w.train_pos)] = 1
         for ip, ix in w.csr:
             for v_ in sl:
                 want[ix[ip[v_]:ip[v_ + 1]]] = 1
         got = maps[s_ * stride:(s_ + 1) * stride].cpu().numpy()
-        assert np.array_equal(got, want), f"batch {s_}: marks = centres + neighbours"
+        assert np.array_equal(got, want), f"batch {s_}: marks = centres + neighbours + train positives"
         s0 = torch.full((w.n,), -12345.0, device=dev())
         _lib.check(lib.pcg_step_scores_train(g.desc_ref(), _p(theta), _p(m), _p(v), E, _p(s0), _p(keys), _p(slabs), _p(step), _p(sync),
                                              0.01, 0.9, 0.999, 1e-8, 0.0, ctypes_ptr(maps, s_ * stride), st), "pcg_step_scores_train")
@@ -1105,6 +1106,25 @@ def test_touched_rows_only_scoring(P, monkeypatch):
     t.fused.train_step(ids1, lab1)
     torch.cuda.synchronize()
     assert torch.equal(a.fused.theta, t.fused.theta)
+    # more train positives than the front launch forms keys for (> 16384): the bucket sort reads s0[train_pos] - those rows
+    # must be scored in touched mode too.  One epoch each way on a graph with ~18 K train positives.
+    w2 = synth.make_workload("manypos", 60000, 32, (40000, 200000), 0.75, seed=9)
+    assert len(w2.train_pos) > 16384
+    cfg2 = dict(engine="graph", batch_size=1024, seed=2)
+    monkeypatch.setenv("PCG_TOUCHED", "0")
+    a2 = PCGNNTrainer(w2, cfg2, dev())
+    monkeypatch.setenv("PCG_TOUCHED", "1")
+    t2 = PCGNNTrainer(w2, cfg2, dev())
+    t2.fused.theta.copy_(a2.fused.theta)
+    a2.fused.stage_epoch(a2.pick_size, 1024); t2.fused.stage_epoch(t2.pick_size, 1024)
+    for tr_ in (a2, t2):
+        tr_.start_epoch_staged()
+        for k in range(6):
+            tr_.fused.epoch_step(k, defer=True)
+        tr_.fused.flush()
+    torch.cuda.synchronize()
+    t2.fused.check()
+    assert torch.equal(a2.fused.theta, t2.fused.theta) and torch.isfinite(a2.fused.theta).all()
 
 
 def ctypes_ptr(t, byte_offset=0):
