@@ -10,6 +10,7 @@
 // Reference lines replaced: src/layers.py:217-219, 246-262, 587-624, 633-738;
 // src/graphsage.py:62-96, 200-232 (keep-all + add_self + sqrt normalisation).
 #include <limits.h>
+#include <stddef.h>
 
 #include "choose.h"
 
@@ -382,114 +383,97 @@ __global__ void __launch_bounds__(PLAN_THREADS) plan_write(const ChooseArgs a, c
 // The plans of ALL batches of an epoch in ONE launch (they depend on the picked ids, their labels and the CSR degrees only - not on
 // any parameter - so they do not belong on a step's critical path): batch s = nodes[s * B_full, min((s + 1) * B_full, n_total))
 // is planned into plan slot s (slot 0's plan part + s * stride bytes) by its own nb_full workgroups, one row per thread.
-// Workgroup j of a batch needs the sums (list entries, chunks, tier counts) over the rows of workgroups 0 .. j - 1: it counts
-// them itself (j passes of the same dependent loads, all in flight per pass; j <= 2 at batch 1024, <= 11 at 4096) instead of
-// waiting for a count launch - per epoch, one launch of ~6 us instead of two of 7 + 11.  The batch's last workgroup then knows the
-// batch's totals: it writes the counters, the select kernel's queue heads and the overflow verdict.  Rows are guarded one by one
-// against the list / chunk capacities (a prefix is all a workgroup knows), so nothing is written out of bounds when a batch
-// overflows; its counters are zeroed then and nothing is selected.  `full` is carved for B_full rows per relation, `tail` for
-// the last, shorter batch (its layout differs; same slot pitch).
+// Workgroup j of a batch needs the sums (list entries, chunks, tier counts) over the rows of workgroups 0 .. j - 1.  Every
+// workgroup works out its own rows' records and totals first and PUBLISHES the totals (write-through stores, then this launch's
+// tag); then it reads its predecessors' totals - lane t of wave 0 waits for workgroup t's tag - and adds them up: one pass of the
+// dependent loads (centre, then its two row offsets: ~2 us each, the picks and the offsets come from HBM) and one hand-off,
+// whatever the batch size (a workgroup recounting its predecessors' rows itself took 17 us per epoch at batch 1024 and 32-39 us
+// at 4096; a count launch + a write launch 7 + 11 us).  Nobody waits on a workgroup that itself waits before publishing, and a
+// batch's workgroups have consecutive ids; the wait is bounded (PCG_ST_SYNC_TIMEOUT).  The tag is one more than the launches
+// that have planned into this slot so far (heads[H_PLAN_SEQ], moved on by the batch's last workgroup once it has read every
+// predecessor).  The batch's last workgroup then knows the batch's totals: it writes the counters, the select kernel's queue
+// heads and the overflow verdict.  Rows are guarded one by one against the list / chunk capacities (a prefix is all a workgroup
+// knows), so nothing is written out of bounds when a batch overflows; its counters are zeroed then and nothing is selected.
+// `full` is carved for B_full rows per relation, `tail` for the last, shorter batch (its layout differs; same slot pitch).
 // bump: a device counter incremented once per epoch (the sampler's epoch number: the picks were made before this launch).
 // (the arguments are used in place - no per-slot copy, no pointer to them: the relation arrays inside are indexed per lane, and
 //  a copy, or an argument whose address is taken, lives in scratch)
+constexpr int H_PLAN_SEQ = 12;           // word of Workspace::heads
+constexpr int PLAN_SPIN_MAX = 1 << 21;
 __device__ __forceinline__ void plan_slot(const ChooseArgs &a, int s, int block, int64_t stride, int64_t full_B) {
     __shared__ int4 lds4[PLAN_THREADS / PCG_WAVE];
-    __shared__ long long s_part[PLAN_THREADS / PCG_WAVE][8];
+    __shared__ long long s_part[PCG_WAVE][8];
     __shared__ long long s_run[8];
     const int rows = a.g.n_rel * a.B;
     const int nb = (rows + PLAN_THREADS - 1) / PLAN_THREADS;
     if (block >= nb) return;
     Workspace w = a.w;                       // the slot's plan part (pointers only)
     shift_plan(w, (int64_t)s * stride);
-    const int64_t node_off = (int64_t)s * full_B;
     const int tid = (int)threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    PlanTotals *totals = reinterpret_cast<PlanTotals *>(w.plan_totals);
+    const int tag = (int)w.heads[H_PLAN_SEQ] + 1;
 #define SLOT_STAMP(k) do { if (a.stamps && tid == 0 && block == nb - 1 && s == 0) a.stamps[(size_t)rows * 8 + (k)] = wall_clock64(); } while (0)
     SLOT_STAMP(0);
-    // ---- 1. the sums over the rows of the workgroups before this one
-    long long c_cap = 0;
-    int c[6] = {0, 0, 0, 0, 0, 0};           // chunks, na, n0, n1, n4, n16
-    // (four workgroups' worth of rows per iteration - this workgroup's own rows are the last of them -, their dependent loads -
-    //  centre, then its two row offsets - issued level by level and unconditionally (index clamped, the surplus not counted): one
-    //  pass of memory latency (two levels of ~2 us: the picks and the row offsets come from HBM) per four workgroups)
-    constexpr int PBU = 4;
-    RowRec rec;                              // this thread's own row
-    rec.node = 0; rec.start = 0; rec.d = rec.k = rec.m = rec.lbeg = rec.chunk0 = 0;
-    for (int pb0 = 0; pb0 <= block; pb0 += PBU) {
-        int rel[PBU], nodev[PBU], labv[PBU];
-        long long b0v[PBU], b1v[PBU];
-#pragma unroll
-        for (int u = 0; u < PBU; ++u) {
-            const int pb = pb0 + u <= block ? pb0 + u : block;
-            int row = pb * PLAN_THREADS + tid;
-            row = row < rows ? row : rows - 1;                                // (only the batch's last workgroup has rows beyond the batch)
-            rel[u] = row / a.B;
-            const int64_t b = node_off + (row - rel[u] * a.B);
-            nodev[u] = a.nodes[b];
-            labv[u] = (a.train_flag && a.labels) ? a.labels[b] : 0;
-        }
-#pragma unroll
-        for (int u = 0; u < PBU; ++u) {
-            const int64_t *ip = a.g.indptr[rel[u]];
-            b0v[u] = ip[nodev[u]];
-            b1v[u] = ip[nodev[u] + 1];
-        }
-#pragma unroll
-        for (int u = 0; u < PBU; ++u) {
-            if (pb0 + u > block) break;                                       // (workgroup-uniform)
-            RowRec p;
-            p.node = nodev[u];
-            p.start = b0v[u];
-            p.d = (int)(b1v[u] - b0v[u]);
-            p.k = (int)ceil((double)p.d * a.thr[rel[u]]);                     // layers.py:260
-            p.m = 0;
-            if (a.train_flag && labv[u] == 1) {                               // layers.py:675
-                p.m = (int)((double)p.k * a.rho[rel[u]]);                     // layers.py:681
-                if (p.m > a.g.n_pos) p.m = a.g.n_pos;
-                if (p.m < 0) p.m = 0;
-            }
-            p.lbeg = p.chunk0 = 0;
-            if (pb0 + u == block) {
-                rec = p;
-            } else {
-                const int cap = rec_cap(p, a.add_self);
-                c_cap += cap;
-                c[0] += (cap + CHUNK - 1) / CHUNK;
-                c[1 + row_tier(p.d, p.m > 0 || a.add_self)] += 1;
-            }
-        }
-    }
-    if (block > 0) {                         // (workgroup-uniform)
-        long long x = c_cap;
-        for (int o = 1; o < PCG_WAVE; o <<= 1) x += __shfl_xor(x, o);
-        int t[6];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) t[j] = __builtin_amdgcn_readlane(wave_incl_scan(c[j], lane), PCG_WAVE - 1);
-        if (lane == 0) {
-            s_part[wave][0] = x;
-#pragma unroll
-            for (int j = 0; j < 6; ++j) s_part[wave][1 + j] = t[j];
-        }
-        __syncthreads();
-        if (tid < 7) {
-            long long sum = 0;
-            for (int wv = 0; wv < PLAN_THREADS / PCG_WAVE; ++wv) sum += s_part[wv][tid];
-            s_run[tid] = sum;
-        }
-        __syncthreads();
-    }
-    const long long run_cap = block > 0 ? s_run[0] : 0;
-    const int run_chunk = block > 0 ? (int)s_run[1] : 0;
-    TierCounts run = {0, 0, 0, 0, 0};
-    if (block > 0) run = {(int)s_run[2], (int)s_run[3], (int)s_run[4], (int)s_run[5], (int)s_run[6]};
-    SLOT_STAMP(1);
-    // ---- 2. this workgroup's rows
+    // ---- 1. this workgroup's rows: records, totals; the totals are published at once
     const int row = block * PLAN_THREADS + tid;
+    RowRec rec = row_plan(a, row < rows ? row : rows - 1, (int64_t)s * full_B);
     const int cap = row < rows ? rec_cap(rec, a.add_self) : 0;
     const int nch = (cap + CHUNK - 1) / CHUNK;
     const int tier = row < rows ? row_tier(rec.d, rec.m > 0 || a.add_self) : -1;
     PlanScan pre, tot;
     block_excl_scan_plan(cap, nch, tier, lds4, pre, tot);
+    if (tid == 0 && block + 1 < nb) {                                       // (the last workgroup has no successor)
+        int *dst = reinterpret_cast<int *>(&totals[block]);
+        const int v[8] = {(int)(tot.cap & 0xFFFFFFFFll), (int)(tot.cap >> 32), tot.chunk, tot.t.n0, tot.t.n1, tot.t.n4, tot.t.n16, tot.t.na};
+        static_assert(offsetof(PlanTotals, chunk) == 8 && offsetof(PlanTotals, na) == 28 && offsetof(PlanTotals, pad) == 32, "PlanTotals layout");
+#pragma unroll
+        for (int j = 0; j < 8; ++j) __hip_atomic_store(dst + j, v[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(dst + 8, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // pad[0]: "published in this launch"
+    }
+    SLOT_STAMP(1);
+    // ---- 2. the predecessors' totals
+    long long run_cap = 0;
+    int run_chunk = 0;
+    TierCounts run = {0, 0, 0, 0, 0};
+    if (block > 0) {                         // (workgroup-uniform)
+        if (wave == 0) {
+            for (int t0 = 0; t0 < block; t0 += PCG_WAVE) {
+                const int t = t0 + lane;
+                long long q[7] = {0, 0, 0, 0, 0, 0, 0};
+                if (t < block) {
+                    const int *src = reinterpret_cast<const int *>(&totals[t]);
+                    for (int spins = 0;; ++spins) {
+                        if (__hip_atomic_load(src + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tag) break;
+                        if (spins >= PLAN_SPIN_MAX) {                        // (cannot happen short of a lost workgroup: reported, not hung)
+                            if (a.status) atomicOr(a.status, (uint32_t)PCG_ST_SYNC_TIMEOUT);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(4);
+                    }
+                    int v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = __hip_atomic_load(src + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    q[0] = ((long long)v[1] << 32) | (unsigned int)v[0];
+                    q[1] = v[2]; q[2] = v[7]; q[3] = v[3]; q[4] = v[4]; q[5] = v[5]; q[6] = v[6];      // chunk, na, n0, n1, n4, n16
+                }
+#pragma unroll
+                for (int j = 0; j < 7; ++j) s_part[lane][j] = (t0 == 0 ? 0 : s_part[lane][j]) + q[j];
+            }
+        }
+        __syncthreads();
+        if (tid < 7) {
+            long long sum = 0;
+            for (int l = 0; l < PCG_WAVE; ++l) sum += s_part[l][tid];
+            s_run[tid] = sum;
+        }
+        __syncthreads();
+        run_cap = s_run[0];
+        run_chunk = (int)s_run[1];
+        run = {(int)s_run[2], (int)s_run[3], (int)s_run[4], (int)s_run[5], (int)s_run[6]};
+    }
     SLOT_STAMP(2);
+    // ---- 3. offsets, queues, chunk table
     const long long o_cap = run_cap + pre.cap;
     const int o_chunk = run_chunk + pre.chunk;
     TierCounts o = pre.t;
@@ -515,6 +499,7 @@ __device__ __forceinline__ void plan_slot(const ChooseArgs &a, int s, int block,
         w.chunk_begin[rows] = all_chunk;
         tier_finish(w, all, overflow);
         w.counters[C_NCHUNK] = overflow ? 0 : all_chunk;
+        w.heads[H_PLAN_SEQ] = (uint32_t)tag;                                 // (every predecessor has published - and read the old value long ago)
         if (overflow && a.status) atomicOr(a.status, (uint32_t)PCG_ST_SEL_OVERFLOW);
     }
     SLOT_STAMP(3);

@@ -33,9 +33,11 @@ python3 $R/scripts/pmc_traffic.py $O/pmc_fetch_pl2m/y_counter_collection.csv $O/
 rm -rf $O/pmc_fetch_pl2m $O/pmc_write_pl2m
 echo "[collect] bench amazon"; python3 $R/bench.py --workload amazon --cpu-batches 4 > $O/bench_amazon.log 2>&1 || exit 1
 for rho in 0.2 0.8; do echo "[collect] bench amazon rho $rho"; python3 $R/bench.py --workload amazon --rho $rho --cpu-batches 0 > $O/bench_amazon_rho$rho.log 2>&1 || exit 1; done
-echo "[collect] bench emb128 b4096"; rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_e128 -o y -- python3 $R/bench.py --emb 128 --batch-size 4096 --cpu-batches 0 > $O/bench_yelp_emb128_b4096.log 2>&1 || exit 1
+echo "[collect] bench emb128 b4096"; python3 $R/bench.py --emb 128 --batch-size 4096 --cpu-batches 0 > $O/bench_yelp_emb128_b4096.log 2>&1 || exit 1
+echo "[collect] kernel trace emb128 b4096"; rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_e128 -o y -- python3 $R/bench.py --emb 128 --batch-size 4096 --cpu-batches 0 --report-epochs 0 --verify-batches 0 > $O/trace_e128.log 2>&1 || exit 1
 stamp $O/trace_e128/y_kernel_stats.csv
-echo "[collect] partitioned path, world size 1"; rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_part -o y -- python3 $R/bench.py --force-partitioned --cpu-batches 0 > $O/bench_partitioned_w1.log 2>&1 || exit 1
+echo "[collect] partitioned path, world size 1"; python3 $R/bench.py --force-partitioned --cpu-batches 0 > $O/bench_partitioned_w1.log 2>&1 || exit 1
+echo "[collect] kernel trace partitioned path"; rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_part -o y -- python3 $R/bench.py --force-partitioned --cpu-batches 0 > $O/trace_part.log 2>&1 || exit 1
 stamp $O/trace_part/y_kernel_stats.csv
 echo "[collect] two ranks on one GPU (gloo-staged collectives: plumbing only)"; PCG_BENCH_BACKEND=gloo python3 $R/bench.py --gpus 2 --steps 20 --warmup 5 > $O/bench_gloo_2ranks.log 2>&1 || exit 1
 fi

@@ -25,7 +25,7 @@ plan = fz._enqueue_plan_one(ids, lab, B, True)
 torch.cuda.synchronize()
 lib.pcg_debug_set_stamps(None)
 pl = stamps[rows].cpu().numpy().astype(np.float64) * 0.01
-print("plan (last workgroup of the batch, us): prefix recount %.2f, own rows + scan %.2f, writes %.2f" % (pl[1] - pl[0], pl[2] - pl[1], pl[3] - pl[2]))
+print("plan (last workgroup of the batch, us): own rows + totals published %.2f, predecessors' totals %.2f, writes %.2f" % (pl[1] - pl[0], pl[2] - pl[1], pl[3] - pl[2]))
 stamps.zero_()
 for it in range(3):
     keys = fz._enqueue_scores_train() if in_select else fz._enqueue_scores(True)
