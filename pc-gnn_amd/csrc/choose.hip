@@ -920,7 +920,7 @@ int32_t pcg_pos_sort_in_select(int32_t n_pos) { return n_pos > 0 && n_pos <= pcg
 
 /* uint32 words of the `sync_words` buffer: [0] dense ticket, [1] update pending, [2] its slab count, [3] the in-kernel sort's group
  * counter, then the sort's rank accumulators (one per train positive, up to RANK_MAX) and group tickets */
-int32_t pcg_sync_words_count(void) { return 4 + pcg::RANK_MAX + pcg::RANK_MAX / PCG_WAVE; }
+int32_t pcg_sync_words_count(void) { return 4 + pcg::RANK_MAX + pcg::RANK_MAX / PCG_WAVE + 4; }     // (+ 4: the dense kernel's "staged" counter)
 
 int pcg_step_front(const pcg_graph_desc *g, const float *W, const float *b, float *s0, uint64_t *pos_keys,
                    const int32_t *nodes, const int32_t *labels, int32_t B, const double *thresholds, const double *rho,

@@ -61,6 +61,7 @@ struct DenseArgs {
     // optional: Adam for the label classifier's parameters by the workgroup whose gradient arrives last
     float *theta, *m, *v;       // null => off
     uint32_t *ticket;           // device word, 0 between launches
+    uint32_t *staged;           // device word, 0 between launches: workgroups that take no ticket (sp != 0) and have read the classifier
     uint32_t *pending;          // two device words: [0] = 1 "the slabs hold a gradient not yet applied to the other parameters", [1] = its slab count
     AdamHyper h;
     unsigned long long *stamps; // diagnostic only (pcg_debug_set_dense_stamps): [tiles][16] wall-clock ticks, else null
@@ -395,6 +396,9 @@ __global__ void __launch_bounds__(DENSE_THREADS) dense_step_kernel(const DenseAr
     }
     __syncthreads();
     DENSE_STAMP(1);
+    // (a workgroup that takes no ticket says here that it has read the classifier's weights - the last ticket holder overwrites
+    //  them.  These arrivals are ~10 us ahead of their only reader: their serialisation on the counter costs nobody anything)
+    if (a.theta && sp != 0 && tid == 0) __hip_atomic_fetch_add(a.staged, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     // ---- forward: h_r = relu([self | agg_r] W_r) for every relation   (layers.py:625-629) ---------
     for (int tile = wave; tile < R * ntile_e; tile += DENSE_WAVES) {
@@ -554,11 +558,14 @@ __global__ void __launch_bounds__(DENSE_THREADS) dense_step_kernel(const DenseAr
     }
     __syncthreads();
     DENSE_STAMP(6);
-    // arrival ticket, taken by EVERY workgroup (its classifier gradient - wave 0's stores, issued a phase ago - is
-    // write-through and drained; and a workgroup that has arrived has long read the classifier's weights).  The answer
-    // is not needed before the end of the kernel, so nobody waits for it here.
+    // arrival ticket (the workgroup's classifier gradient - its clf wave's stores, issued a phase ago - is write-through and
+    // drained; and a workgroup that has arrived has long read the classifier's weights).  The answer is not needed before the
+    // end of the kernel, so nobody waits for it here.
+    // Only the workgroups that stored a share of the classifier's gradient (sp == 0: one per tile) arrive: the other slab
+    // entries are read by the NEXT launch.  (Every workgroup arriving was 256 same-address atomics at B = 1024 - a counter
+    // takes ~88 per microsecond, so the last arriver learned that it was the last ~3 us after the first one asked.)
     unsigned ticket_old = 0u;
-    if (adam_clf && wave == clf_wave) {
+    if (adam_clf && wave == clf_wave && sp == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) ticket_old = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -581,13 +588,15 @@ __global__ void __launch_bounds__(DENSE_THREADS) dense_step_kernel(const DenseAr
     // ---- the workgroup whose ticket was the last: sum of every tile's share of the classifier gradient (tile order), Adam
     //      for those 2F + 2 parameters (model_handler.py:153) - the only ones the next step's score pass reads ----------
     if (!adam_clf) return;
-    if (wave == clf_wave && lane == 0) s_flag[0] = ticket_old == (unsigned)gridDim.x - 1u;
+    if (wave == clf_wave && lane == 0) s_flag[0] = sp == 0 && ticket_old == (unsigned)gridDim.x / (unsigned)S - 1u;
     __syncthreads();
     if (s_flag[0]) {
         if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        DENSE_STAMP(14);
         const int n_tiles = (int)gridDim.x / S;
+        unsigned staged_seen = (tid == 0 && S > 1) ? __hip_atomic_load(a.staged, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         const int64_t oc = off_clf(F, E, R);
         const int NC = 2 * F + 2;
         // G threads per parameter: thread (g, i) adds up the tiles s = g, g + G, ... of parameter i in that order (the loads of
@@ -603,17 +612,19 @@ __global__ void __launch_bounds__(DENSE_THREADS) dense_step_kernel(const DenseAr
             float acc = 0.f;
             if (g < G && i < NC) {
                 const float *src = a.slabs + oc + i;
-                int s2 = g;
-                for (; s2 + 7 * G < n_tiles; s2 += 8 * G) {
+                // (every batch of eight loads is issued whole - indices clamped, the surplus not added: at 64 tiles and fifteen
+                //  threads per parameter a thread has five tiles, and a loop of single agent-scope loads waited for each of them in
+                //  turn: five memory round trips on the step's critical path instead of one)
+                for (int s2 = g; s2 < n_tiles; s2 += 8 * G) {
                     float x[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        x[u] = __hip_atomic_load(src + (size_t)(s2 + u * G) * a.n_params, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int u = 0; u < 8; ++u) {
+                        const int t2 = s2 + u * G;
+                        x[u] = __hip_atomic_load(src + (size_t)(t2 < n_tiles ? t2 : n_tiles - 1) * a.n_params, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) acc += x[u];
+                    for (int u = 0; u < 8; ++u) acc = (s2 + u * G < n_tiles) ? acc + x[u] : acc;
                 }
-                for (; s2 < n_tiles; s2 += G)
-                    acc += __hip_atomic_load(src + (size_t)s2 * a.n_params, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (G > 1) {
                 if (g < G && i < NC) s_red[g * NC + i] = acc;
@@ -624,13 +635,27 @@ __global__ void __launch_bounds__(DENSE_THREADS) dense_step_kernel(const DenseAr
                 }
             }
             const int ip = G > 1 ? tid : i;
+            if (i0 == 0 && S > 1) {
+                // every workgroup without a ticket has long staged the old classifier (it said so ~10 us ago); the count was
+                // requested before the gradient's loads, so the check costs nothing in all but pathological schedules; bounded
+                if (tid == 0)
+                    for (int spins = 0; staged_seen < (unsigned)gridDim.x - (unsigned)n_tiles && spins < (1 << 20); ++spins) {
+                        __builtin_amdgcn_s_sleep(4);
+                        staged_seen = __hip_atomic_load(a.staged, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                __syncthreads();
+            }
             if (ip < NC) {
                 // t: the step this launch counted (block 0 incremented the counter at its start; read it past the L1)
                 const float t = (float)__hip_atomic_load(a.step_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 adam_apply_one(a.theta, a.m, a.v, oc + ip, acc, t, a.h);
             }
         }
-        if (tid == 0) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+            __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.staged, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        DENSE_STAMP(15);
     }
 }
 
@@ -696,7 +721,7 @@ struct DenseExtra {          // the optional parts of a launch
     const int32_t *cnt = nullptr;
     int32_t partial_stride = 0;
     float *theta_rw = nullptr, *m = nullptr, *v = nullptr;
-    uint32_t *ticket = nullptr, *pending = nullptr;
+    uint32_t *ticket = nullptr, *pending = nullptr, *staged = nullptr;
     AdamHyper h = {0.f, 0.f, 0.f, 0.f, 0.f};
 };
 
@@ -748,6 +773,7 @@ static int launch_dense(const pcg_graph_desc *g, const float *theta, int32_t emb
     a.m = x.m;
     a.v = x.v;
     a.ticket = x.ticket;
+    a.staged = x.staged;
     a.pending = x.pending;
     a.h = x.h;
     // few tiles (small batches): up to 4 workgroups per tile, so that the weight-gradient tiles of a 16-row tile are not one
@@ -837,6 +863,7 @@ int pcg_train_dense(const pcg_graph_desc *g, float *theta, float *m, float *v, i
         x.m = m;
         x.v = v;
         x.ticket = sync_words;
+        x.staged = sync_words + pcg_sync_words_count() - 4;
         x.pending = sync_words + 1;
         x.h = {(float)lr, (float)beta1, (float)beta2, (float)eps, (float)weight_decay};
     }

@@ -97,3 +97,7 @@ for s_ in order[1:]:
     print(f"   {names[s_]:16s} mean {np.mean(cur - prev):6.2f} us   max {np.max(cur - prev):6.2f}")
     prev = cur
 print("   total per tile   mean %.2f us  max %.2f" % (np.mean(d[:, 7] - d[:, 0]), np.max(d[:, 7] - d[:, 0])))
+la = d[:, 14].max()
+if la > 0:
+    print("   the last arriver (tile %d): entered the classifier's Adam %.2f us after the first tile's start (last tile done at %.2f), finished at %.2f" % (
+        int(d[:, 14].argmax()), la - t0d, d[:, 7].max() - t0d, d[:, 15].max() - t0d))
