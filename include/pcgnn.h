@@ -230,9 +230,37 @@ int pcg_choose_gather_planned(const pcg_graph_desc *g, const int32_t *nodes, con
 int32_t pcg_pos_sort_in_select(int32_t n_pos);      /* 1: 0 < n_pos <= 16384 (host helper) */
 /* scores of rows [row_begin, row_end) (-> s0_out[row], or s0_out[row_ids[row]]) || the UNSORTED train-pos keys into pos_keys'
  * scratch half (pos_keys may be NULL; pos_row_base >= 0: train positive i's feature row is table row pos_row_base + i - required
- * with row_ids -, else row train_pos[i]); zeroes sync_words[3].  ONE launch, no plan, no parameter update. */
+ * with row_ids -, else row train_pos[i]); zeroes sync_words[3].  ONE launch, no plan, no parameter update.
+ * touched (may be NULL; needs row_ids == NULL, row_begin == 0): only the rows the byte map marks (pcg_mark_touched) are scored.
+ * Train positives by node id (no row_ids / pos_row_base) and more than 16384 of them: the bucket sort's launches follow and
+ * pos_keys is sorted on return. */
 int pcg_step_scores(const pcg_graph_desc *g, const float *W, const float *b, int64_t row_begin, int64_t row_end, float *s0_out,
-                    const int32_t *row_ids, uint64_t *pos_keys, int64_t pos_row_base, uint32_t *sync_words, void *stream);
+                    const int32_t *row_ids, uint64_t *pos_keys, int64_t pos_row_base, uint32_t *sync_words, const uint8_t *touched,
+                    void *stream);
+/* select + gather of a TRAINING step with the label classifier stepped on its own: the THREE-launch step
+ *       pcg_choose_gather_train (select_rows, gather_train_kernel)  ->  pcg_train_dense(adam_clf = 2).
+ * The label classifier (src/layers.py:230-243; its loss term src/model.py:54-61) gets gradient from nothing but the batch
+ * centres' feature rows and labels - not from the selection, the aggregates or the GNN weights.  So
+ *   - ONE workgroup of the select launch does the classifier's whole step for THIS batch: logits of the centres' rows, the
+ *     lambda_1 / global-batch weighted cross-entropy gradient summed over the batch in a fixed order, torch.optim.Adam's update
+ *     (t = step_counter[0] + 1; m, v in place at the classifier's offset).  clf_next [2 * feat_dim + 2] (W row-major, then b):
+ *     in: the classifier s0 was scored with; out: the updated one.  The in-value is copied to theta's classifier (the dense
+ *     kernel computes this step's loss term with it);
+ *   - the gather launch carries, in extra workgroups, the previous step's deferred Adam update of every OTHER parameter (from
+ *     slabs, if sync_words[1] is set - the dense kernel that follows reads the result) and, if score_next, the NEXT step's score
+ *     pass -> s0 and unsorted train-pos keys -> pos_keys' scratch half, computed with the new clf_next (next_touched != NULL:
+ *     only the rows that byte map marks; n_pos > 16384: the bucket sort's launches follow).  It zeroes sync_words[3].
+ * Nothing waits inside a launch for any of this.  On entry s0 / pos_keys hold THIS step's scores / unsorted keys (from the
+ * previous step's call with score_next = 1, or from pcg_step_scores(W = clf_next, b = clf_next + 2 * feat_dim)).
+ * pcg_adam_flush(..., clf_next) afterwards brings theta up to date (deferred update + the stepped classifier).
+ * inv_count = 1 / global batch size.  Selection, lists and aggregates: exactly pcg_choose_gather_planned(train_flag = 1). */
+int pcg_choose_gather_train(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B, float *s0,
+                            uint64_t *pos_keys, const double *thresholds, const double *rho, int32_t add_self, float *agg,
+                            int32_t agg_stride, int32_t *cnt, void *workspace, const void *plan, int64_t list_capacity,
+                            uint32_t *status, uint32_t *sync_words, float *theta, float *m, float *v, int32_t emb, float *clf_next,
+                            const float *slabs, const int32_t *step_counter, float lambda_1, float inv_count, double lr, double beta1,
+                            double beta2, double eps, double weight_decay, int32_t score_next, const uint8_t *next_touched,
+                            void *stream);
 int32_t pcg_sync_words_count(void);                 /* uint32 words of a `sync_words` buffer (zero-initialised ONCE by the caller; the
                                                         kernels leave every word but [1], [2] zero between launches) */
 int pcg_aggregate_lists_planned(const float *X, int32_t feat_dim, int32_t feat_stride, int64_t table_rows, int32_t n_rows,
@@ -327,7 +355,10 @@ int pcg_adam_step(float *theta, float *m, float *v, const float *slabs, int32_t 
  * pcg_train_dense = pcg_dense_step, plus
  *   - workspace != NULL (with cnt, plan, list_capacity as given to pcg_choose_gather_planned): aggregates of rows the gather
  *     left as partial sums are added up here (no combine launch);
- *   - adam_clf != 0 (training: slabs, m, v, sync_words required): the workgroup that arrives last (device-scope ticket,
+ *   - adam_clf == 2 (training; slabs, sync_words required): gradient slabs only, marked as waiting (sync_words[1] = 1,
+ *     sync_words[2] = #slabs) for the deferred update of the next pcg_choose_gather_train / pcg_adam_flush; the label
+ *     classifier's own step is pcg_choose_gather_train's (its share of the slabs is written but not used);
+ *   - adam_clf == 1 (training: slabs, m, v, sync_words required): the workgroup that arrives last (device-scope ticket,
  *     write-through partial gradients) sums the label classifier's gradient over the tiles in tile order and applies
  *     Adam to those 2 * feat_dim + 2 parameters - the only ones the next step's score pass reads - and the launch marks the
  *     slabs as holding a gradient the OTHER parameters have not seen yet: sync_words[1] = 1, sync_words[2] = #slabs.
@@ -343,7 +374,9 @@ int pcg_adam_step(float *theta, float *m, float *v, const float *slabs, int32_t 
  *   touched (may be NULL = score every row): this batch's byte map from pcg_mark_touched - only rows whose byte is set are
  *   scored (bit for bit the scores pcg_score_table gives them); the other entries of s0 keep whatever they held - the batch's
  *   selection never reads them.  For graphs whose feature table is far larger than what a batch touches.
- * pcg_adam_flush applies a still-deferred update now (two small launches) - before parameters are read or saved. */
+ * pcg_adam_flush applies a still-deferred update now (two or three small launches) - before parameters are read or saved;
+ *   clf_next != NULL (the pcg_choose_gather_train step): the stepped label classifier is copied into theta [p_end, n_params) too,
+ *   if an update was pending. */
 int pcg_step_scores_train(const pcg_graph_desc *g, float *theta, float *m, float *v, int32_t emb, float *s0,
                           uint64_t *pos_keys, const float *slabs, const int32_t *step_counter, uint32_t *sync_words,
                           double lr, double beta1, double beta2, double eps, double weight_decay, const uint8_t *touched,
@@ -379,7 +412,7 @@ int pcg_adam_apply_pending(float *theta, float *m, float *v, const float *grad, 
                            void *stream);
 int pcg_adam_flush(float *theta, float *m, float *v, const float *slabs, int32_t n_slabs, int64_t n_params, int64_t p_end,
                    const int32_t *step_counter, uint32_t *sync_words, double lr, double beta1, double beta2, double eps,
-                   double weight_decay, void *stream);
+                   double weight_decay, const float *clf_next, void *stream);
 
 /* ---- multi-GPU halo exchange helpers (no counterpart in the reference) ----------
  * A rank of a partitioned run holds the table [ owned rows | train-pos rows | halo ]; CSR rows and selection lists hold

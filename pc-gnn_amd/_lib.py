@@ -60,7 +60,10 @@ PROTOTYPES = {
                                    _P, _I64, _P]),
     "pcg_choose_select_planned": (C.c_int, [_G, _P, _P, _I32, _P, _P, _P, C.POINTER(_F64), C.POINTER(_F64), _I32, _I32,
                                             _P, _P, _P, _I64, _P, _P, _I64, _P]),
-    "pcg_step_scores": (C.c_int, [_G, _P, _P, _I64, _I64, _P, _P, _P, _I64, _P, _P]),
+    "pcg_step_scores": (C.c_int, [_G, _P, _P, _I64, _I64, _P, _P, _P, _I64, _P, _P, _P]),
+    "pcg_choose_gather_train": (C.c_int, [_G, _P, _P, _I32, _P, _P, C.POINTER(_F64), C.POINTER(_F64), _I32, _P, _I32, _P, _P, _P,
+                                          _I64, _P, _P, _P, _P, _P, _I32, _P, _P, _P, C.c_float, C.c_float, _F64, _F64, _F64, _F64,
+                                          _F64, _I32, _P, _P]),
     "pcg_choose_plan_bytes": (_I64, [_G, _I32, _I64]),
     "pcg_choose_data_bytes": (_I64, [_G, _I32, _I64]),
     "pcg_plan_batches": (C.c_int, [_G, _P, _P, _I32, _I32, C.POINTER(_F64), C.POINTER(_F64), _I32, _I32, _P, _I64, _I64, _P, _P,
@@ -83,7 +86,7 @@ PROTOTYPES = {
                                        _I64, _P, _P, _P, _P, _F64, _F64, _F64, _F64, _F64, _P]),
     "pcg_grad_reduce": (C.c_int, [_P, _I32, _I64, _P, _P, _P]),
     "pcg_adam_apply_pending": (C.c_int, [_P, _P, _P, _P, _I64, _P, _P, _I32, _F64, _F64, _F64, _F64, _F64, _P]),
-    "pcg_adam_flush": (C.c_int, [_P, _P, _P, _P, _I32, _I64, _I64, _P, _P, _F64, _F64, _F64, _F64, _F64, _P]),
+    "pcg_adam_flush": (C.c_int, [_P, _P, _P, _P, _I32, _I64, _I64, _P, _P, _F64, _F64, _F64, _F64, _F64, _P, _P]),
     "pcg_debug_set_stamps": (None, [_P]),
     "pcg_debug_set_dense_stamps": (None, [_P]),
     "pcg_sel_capacity_row": (_I64, [_I64, _F64, _F64, _I32, _I32, _I32]),

@@ -15,7 +15,8 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fno-gpu-rdc", 
 
 
 def lib_path() -> str:
-    return os.path.join(LIBDIR, LIBNAME)
+    # PCG_LIB: a developer's A/B build of the same sources (scripts/ab_build.sh); unset = the in-tree library
+    return os.environ.get("PCG_LIB") or os.path.join(LIBDIR, LIBNAME)
 
 
 def _stale(target, deps):

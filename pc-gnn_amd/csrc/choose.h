@@ -130,6 +130,20 @@ __host__ __device__ __forceinline__ void shift_plan(Workspace &w, int64_t bytes)
     shift_ptr(w.qa, bytes); shift_ptr(w.recs, bytes); shift_ptr(w.plan_totals, bytes); shift_ptr(w.chunk_desc, bytes);
 }
 
+// The label classifier's own training step (src/layers.py:230-243 forward, src/model.py:54-61 its loss term, model_handler.py:153
+// its Adam update), riding in the select launch.  Its 2F + 2 parameters get gradient from nothing but the batch centres' feature
+// rows - not from the selection, the aggregates or the GNN weights - so step t's update can be worked out at the START of step t,
+// and the scores that step t + 1 selects by can be formed beside step t's gather instead of behind its dense kernel.
+//   clf_next [2F + 2]: in: the classifier step t scores / selects by; out: the classifier after step t's update.  theta_clf gets
+//   the in-value (the dense kernel of step t reads it for the loss); m, v: the classifier's Adam state; t = step_counter[0] + 1.
+struct ClfStep {
+    float *clf_next;           // null: off
+    float *theta_clf, *m, *v;
+    const int32_t *step_counter;
+    float scale;               // lambda_1 / global batch size: what a row's d loss / d logit is multiplied by
+    AdamHyper h;
+};
+
 struct ChooseArgs {
     pcg_graph_desc g;
     const int32_t *nodes;
@@ -150,6 +164,7 @@ struct ChooseArgs {
     uint32_t *sort_done, *rank_acc, *group_ticket;
     int32_t n_sort, sort_cap, sort_slices, sort_slice_len;
     uint32_t *pending_clear;   // device word the select kernel zeroes ("the deferred Adam update has been applied"), or null
+    ClfStep clf;               // the label classifier's step for this batch (one workgroup), or clf.clf_next == null
     double thr[PCG_MAX_REL];
     double rho[PCG_MAX_REL];
     int32_t train_flag, add_self;
@@ -179,5 +194,22 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 
 // select.hip
 int launch_select_rows(const ChooseArgs &a, hipStream_t st);
+
+// What rides along the gather launch of a training step (gather.hip: gather_train_kernel): the deferred Adam update of every
+// parameter but the label classifier's (from the previous step's slabs; the dense kernel that follows reads the result), and the
+// NEXT step's score pass + unsorted train-pos keys with the classifier the select launch has just stepped.
+struct SideJob {
+    DeferredAdam ad;
+    int32_t n_adam_blocks;     // 0: no update
+    const float *W, *bias;     // the classifier to score with (ClfStep::clf_next), or null: no score pass
+    float *s0;
+    const unsigned char *touched;   // byte map of the rows the next batch reads, or null: the whole table
+    uint64_t *raw_keys;        // the train positives' unsorted keys, or null
+    int32_t n_key_blocks, n_score_blocks;
+    uint32_t *zero_word;       // the select kernel's arrival counter, zeroed for its next launch
+};
+int launch_gather_train(const float *X, int32_t feat_dim, int32_t feat_stride, int64_t table_rows, const int32_t *cnt,
+                        const pcg_graph_desc *g, int32_t B, const Workspace &w, float *agg, int32_t agg_stride, uint32_t *status,
+                        const SideJob &side, hipStream_t st);
 
 }  // namespace pcg

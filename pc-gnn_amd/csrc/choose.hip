@@ -673,6 +673,7 @@ static int choose_args(pcg::ChooseArgs &a, const pcg_graph_desc *g, const int32_
     a.sort_done = a.rank_acc = a.group_ticket = nullptr;
     a.n_sort = a.sort_cap = a.sort_slices = a.sort_slice_len = 0;
     a.pending_clear = nullptr;
+    a.clf.clf_next = nullptr;
     pcg::carve1(g, B, list_capacity, static_cast<unsigned char *>(workspace), &a.w,
                 static_cast<unsigned char *>(const_cast<void *>(plan)));
     return PCG_OK;
@@ -908,12 +909,17 @@ int pcg_step_scores_train(const pcg_graph_desc *g, float *theta, float *m, float
  * rows are [owned | train-pos | halo] and whose scores are indexed by global node id (row_ids), and of any caller that plans its
  * batches with pcg_plan_batches and updates its parameters itself. */
 int pcg_step_scores(const pcg_graph_desc *g, const float *W, const float *b, int64_t row_begin, int64_t row_end, float *s0_out,
-                    const int32_t *row_ids, uint64_t *pos_keys, int64_t pos_row_base, uint32_t *sync_words, void *stream) {
+                    const int32_t *row_ids, uint64_t *pos_keys, int64_t pos_row_base, uint32_t *sync_words, const uint8_t *touched,
+                    void *stream) {
     if (!g || !sync_words) return PCG_E_ARG;
     if (pos_keys && row_ids && pos_row_base < 0) return PCG_E_ARG;     // (with row_ids a node id is not a table row)
     if (pos_row_base >= 0 && pos_row_base + g->n_pos > g->n_nodes) return PCG_E_ARG;
-    return front_a(g, W, b, row_begin, row_end, s0_out, row_ids, pos_keys, nullptr, nullptr, 0, nullptr, nullptr, 1, 0, nullptr, 1, nullptr,
-                   nullptr, stream, true, sync_words + 3, pos_row_base);
+    const int rc = front_a(g, W, b, row_begin, row_end, s0_out, row_ids, pos_keys, nullptr, nullptr, 0, nullptr, nullptr, 1, 0, nullptr, 1,
+                           nullptr, nullptr, stream, true, sync_words + 3, pos_row_base, touched);
+    if (rc != PCG_OK) return rc;
+    // (too many train positives for the select kernel's own sort: the bucket sort's launches, by node id - not for row_ids tables)
+    if (pos_keys && !row_ids && pos_row_base < 0 && g->n_pos > pcg::RANK_MAX) return pcg_pos_sort(g, s0_out, pos_keys, stream);
+    return PCG_OK;
 }
 
 int32_t pcg_pos_sort_in_select(int32_t n_pos) { return n_pos > 0 && n_pos <= pcg::RANK_MAX ? 1 : 0; }
@@ -964,6 +970,78 @@ int pcg_choose_gather_planned(const pcg_graph_desc *g, const int32_t *nodes, con
     if (rc != PCG_OK) return rc;
     return pcg_gather_lists_planned(g->X, g->feat_dim, g->feat_stride, g->n_nodes, g->n_rel * B, cnt, g, B, workspace, plan, list_capacity,
                                     agg, agg_stride, status, stream);
+}
+
+/* select + gather of a TRAINING step whose label classifier is stepped on its own (ClfStep / SideJob in choose.h): two launches,
+ *   select_rows         [+ one workgroup: the classifier's forward / loss / Adam for THIS batch: clf_next <- the updated classifier]
+ *   gather_train_kernel [+ the previous step's deferred Adam update of every other parameter || (score_next) the NEXT step's
+ *                          score pass and unsorted train-pos keys with clf_next]
+ * followed by pcg_train_dense(adam_clf = 2).  s0 / pos_keys: read by the select launch (this step's scores; unsorted keys in the
+ * scratch half), rewritten by the gather launch for the next step. */
+int pcg_choose_gather_train(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B, float *s0,
+                            uint64_t *pos_keys, const double *thresholds, const double *rho, int32_t add_self, float *agg,
+                            int32_t agg_stride, int32_t *cnt, void *workspace, const void *plan, int64_t list_capacity,
+                            uint32_t *status, uint32_t *sync_words, float *theta, float *m, float *v, int32_t emb, float *clf_next,
+                            const float *slabs, const int32_t *step_counter, float lambda_1, float inv_count, double lr, double beta1,
+                            double beta2, double eps, double weight_decay, int32_t score_next, const uint8_t *next_touched,
+                            void *stream) {
+    if (!g || B < 0) return PCG_E_ARG;
+    if (B == 0) return PCG_OK;
+    if (!g->X || !agg || !s0 || !sync_words || !theta || !m || !v || !clf_next || !slabs || !step_counter || !labels) return PCG_E_ARG;
+    if (g->feat_stride > 512) return PCG_E_UNSUPPORTED;
+    const int64_t n_params = pcg_dense_n_params(g->feat_dim, emb, g->n_rel);
+    const int64_t o_clf = pcg_dense_param_offset(g->feat_dim, emb, g->n_rel, 3, 0);
+    if (n_params < 0 || o_clf < 0) return PCG_E_ARG;
+    pcg::ChooseArgs a;
+    int rc = choose_args(a, g, nodes, labels, B, s0, nullptr, pos_keys, thresholds, rho, 1, add_self, cnt, workspace, list_capacity,
+                         status, false, plan);
+    if (rc != PCG_OK) return rc;
+    if (!cnt) return PCG_E_ARG;
+    const bool rank = g->n_pos > 0 && g->n_pos <= pcg::RANK_MAX;
+    const int64_t cap = g->n_pos > 0 ? pcg_pos_sort_capacity(g->n_pos) / 2 : 0;
+    if (rank) {                                        // the select kernel sorts the unsorted keys itself
+        a.sort_out = pos_keys;
+        a.raw_keys = pos_keys + cap;
+        a.sort_cap = (int32_t)cap;
+        a.n_sort = (g->n_pos + PCG_WAVE - 1) / PCG_WAVE;
+        a.sort_done = sync_words + 3;
+        a.rank_acc = sync_words + 4;
+        a.group_ticket = sync_words + 4 + pcg::RANK_MAX;
+    }
+    const pcg::AdamHyper h = {(float)lr, (float)beta1, (float)beta2, (float)eps, (float)weight_decay};
+    a.clf.clf_next = clf_next;
+    a.clf.theta_clf = theta + o_clf;
+    a.clf.m = m + o_clf;
+    a.clf.v = v + o_clf;
+    a.clf.step_counter = step_counter;
+    a.clf.scale = inv_count * lambda_1;
+    a.clf.h = h;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    rc = pcg::launch_select(a, st, true);
+    if (rc != PCG_OK) return rc;
+    pcg::SideJob sd;
+    sd.ad.theta = theta; sd.ad.m = m; sd.ad.v = v;
+    sd.ad.slabs = slabs;
+    sd.ad.n_params = n_params;
+    sd.ad.p_end = o_clf;
+    sd.ad.step_counter = step_counter;
+    sd.ad.pending = sync_words + 1;
+    sd.ad.h = h;
+    sd.n_adam_blocks = (int)((o_clf + PCG_WAVE - 1) / PCG_WAVE);
+    sd.W = score_next ? clf_next : nullptr;
+    sd.bias = clf_next + 2 * g->feat_dim;
+    sd.s0 = s0;
+    sd.touched = next_touched;
+    sd.raw_keys = (score_next && rank && g->train_pos) ? pos_keys + cap : nullptr;
+    const int rows_per_block = 4 * (PCG_WAVE / pcg::lanes_per_row(g->feat_stride));
+    int n_key = sd.raw_keys ? (g->n_pos + rows_per_block - 1) / rows_per_block : 0;
+    sd.n_key_blocks = n_key > 256 ? 256 : n_key;
+    sd.n_score_blocks = score_next ? (int)pcg::score_table_blocks(g->n_nodes, g->feat_stride) : 0;
+    sd.zero_word = sync_words + 3;
+    rc = pcg::launch_gather_train(g->X, g->feat_dim, g->feat_stride, g->n_nodes, cnt, g, B, a.w, agg, agg_stride, status, sd, st);
+    if (rc != PCG_OK) return rc;
+    if (score_next && g->n_pos > pcg::RANK_MAX) return pcg_pos_sort(g, s0, pos_keys, stream);
+    return PCG_OK;
 }
 
 int pcg_choose_aggregate_planned(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B,

@@ -104,6 +104,9 @@ constexpr int SCORE_UNROLL = PCG_SCORE_UNROLL;
 // class-0 logit of rows [row_begin, row_end): workgroup `block` of `n_blocks` (256 threads each), grid-stride.
 // row_ids == nullptr: s0[row] = score(row);  else: s0[row_ids[row]] = score(row), rows with row_ids[row] < 0 skipped (the
 // partitioned path: a rank's table rows are owned / train-pos / halo rows, scores are looked up by global node id)
+// SCORE_K: float4 chunks of a row a lane may hold (2 covers rows of up to 512 floats; 1 - rows of up to 256 - halves the
+// registers the rows in flight take)
+template <int SCORE_K = 2>
 __device__ __forceinline__ void score_table_body(const float *__restrict__ X, int feat_dim, int stride,
                                                  const float *__restrict__ W, const float *__restrict__ bias,
                                                  int64_t row_begin, int64_t row_end, float *__restrict__ s0, int block,
@@ -122,7 +125,6 @@ __device__ __forceinline__ void score_table_body(const float *__restrict__ X, in
     // a load inside a conditional is compiled into a branch that first waits for every load in flight: the row loads of the
     // unrolled iterations would go out one at a time.  Same fma order as score_partial => the same bits.
     const int nch = stride >> 2;
-    constexpr int SCORE_K = 2;
     bool has[SCORE_K];
     int chc[SCORE_K];
     float wv[SCORE_K][4];
@@ -140,7 +142,7 @@ __device__ __forceinline__ void score_table_body(const float *__restrict__ X, in
             wv[k][j] = __int_as_float(__float_as_int(wj) & ((has[k] && f < feat_dim) ? -1 : 0));
         }
     }
-    const bool two = lpr < nch;                                           // (wave-uniform)
+    const bool two = SCORE_K > 1 && lpr < nch;                            // (wave-uniform)
     for (int64_t base = row_begin + wave_global * rows_per_iter; base < row_end; base += n_waves * rows_per_iter) {
         f4 xv[SCORE_UNROLL][SCORE_K];
 #pragma unroll
@@ -149,9 +151,10 @@ __device__ __forceinline__ void score_table_body(const float *__restrict__ X, in
             const float *xrow = X + (row < row_end ? row : row_end - 1) * stride;
             xv[u][0] = PCG_SCORE_NT != 0 ? __builtin_nontemporal_load(reinterpret_cast<const f4 *>(xrow + 4 * chc[0]))
                                          : *reinterpret_cast<const f4 *>(xrow + 4 * chc[0]);
-            if (two)
-                xv[u][1] = PCG_SCORE_NT != 0 ? __builtin_nontemporal_load(reinterpret_cast<const f4 *>(xrow + 4 * chc[1]))
-                                             : *reinterpret_cast<const f4 *>(xrow + 4 * chc[1]);
+            if constexpr (SCORE_K > 1)
+                if (two)
+                    xv[u][1] = PCG_SCORE_NT != 0 ? __builtin_nontemporal_load(reinterpret_cast<const f4 *>(xrow + 4 * chc[1]))
+                                                 : *reinterpret_cast<const f4 *>(xrow + 4 * chc[1]);
         }
         float p[SCORE_UNROLL];
 #pragma unroll
@@ -163,12 +166,13 @@ __device__ __forceinline__ void score_table_body(const float *__restrict__ X, in
                 q = fmaf(xv[u][0].z, wv[0][2], q);
                 q = fmaf(xv[u][0].w, wv[0][3], q);
             }
-            if (two && has[1]) {
-                q = fmaf(xv[u][1].x, wv[1][0], q);
-                q = fmaf(xv[u][1].y, wv[1][1], q);
-                q = fmaf(xv[u][1].z, wv[1][2], q);
-                q = fmaf(xv[u][1].w, wv[1][3], q);
-            }
+            if constexpr (SCORE_K > 1)
+                if (two && has[1]) {
+                    q = fmaf(xv[u][1].x, wv[1][0], q);
+                    q = fmaf(xv[u][1].y, wv[1][1], q);
+                    q = fmaf(xv[u][1].z, wv[1][2], q);
+                    q = fmaf(xv[u][1].w, wv[1][3], q);
+                }
             p[u] = q;
         }
         // after the butterfly every lane of a row-group holds that row's sum: lane `sub` keeps the result of
@@ -202,6 +206,7 @@ __device__ __forceinline__ void score_table_body(const float *__restrict__ X, in
 // touched_bytes(n) never leave it, and rows beyond the table are unmarked.  sel: 4 x 512 uint16 of LDS per 256-thread workgroup.
 constexpr int MARK_GROUP = 512;
 __host__ __device__ __forceinline__ int64_t touched_bytes(int64_t n_rows) { return (n_rows + 2 * MARK_GROUP - 1) / MARK_GROUP * MARK_GROUP; }
+template <int SCORE_K = 2>
 __device__ __forceinline__ void score_marked_body(const float *__restrict__ X, int feat_dim, int stride, const float *__restrict__ W,
                                                   const float *__restrict__ bias, int64_t n_rows, float *__restrict__ s0,
                                                   const unsigned char *__restrict__ touched, int block, int n_blocks,
@@ -216,7 +221,6 @@ __device__ __forceinline__ void score_marked_body(const float *__restrict__ X, i
     unsigned short *sel = sel_all + (threadIdx.x >> 6) * MARK_GROUP;
     const float b0 = bias[0];
     const int nch = stride >> 2;
-    constexpr int SCORE_K = 2;
     bool has[SCORE_K];
     int chc[SCORE_K];
     float wv[SCORE_K][4];
@@ -232,7 +236,7 @@ __device__ __forceinline__ void score_marked_body(const float *__restrict__ X, i
             wv[k][j] = __int_as_float(__float_as_int(wj) & ((has[k] && f < feat_dim) ? -1 : 0));
         }
     }
-    const bool two = lpr < nch;
+    const bool two = SCORE_K > 1 && lpr < nch;
     for (int64_t base = wave_global * MARK_GROUP; base < n_rows; base += n_waves * MARK_GROUP) {
         const uint64_t mk = *reinterpret_cast<const uint64_t *>(touched + base + 8 * lane);
         int cnt = 0;
@@ -265,7 +269,8 @@ __device__ __forceinline__ void score_marked_body(const float *__restrict__ X, i
                 rid[u] = j < total ? row : -1;
                 const float *xrow = X + row * stride;
                 xv[u][0] = *reinterpret_cast<const f4 *>(xrow + 4 * chc[0]);
-                if (two) xv[u][1] = *reinterpret_cast<const f4 *>(xrow + 4 * chc[1]);
+                if constexpr (SCORE_K > 1)
+                    if (two) xv[u][1] = *reinterpret_cast<const f4 *>(xrow + 4 * chc[1]);
             }
 #pragma unroll
             for (int u = 0; u < SCORE_UNROLL; ++u) {
@@ -276,12 +281,13 @@ __device__ __forceinline__ void score_marked_body(const float *__restrict__ X, i
                     q = fmaf(xv[u][0].z, wv[0][2], q);
                     q = fmaf(xv[u][0].w, wv[0][3], q);
                 }
-                if (two && has[1]) {
-                    q = fmaf(xv[u][1].x, wv[1][0], q);
-                    q = fmaf(xv[u][1].y, wv[1][1], q);
-                    q = fmaf(xv[u][1].z, wv[1][2], q);
-                    q = fmaf(xv[u][1].w, wv[1][3], q);
-                }
+                if constexpr (SCORE_K > 1)
+                    if (two && has[1]) {
+                        q = fmaf(xv[u][1].x, wv[1][0], q);
+                        q = fmaf(xv[u][1].y, wv[1][1], q);
+                        q = fmaf(xv[u][1].z, wv[1][2], q);
+                        q = fmaf(xv[u][1].w, wv[1][3], q);
+                    }
                 const float sc = score_reduce(q, lpr);
                 if (sub == 0 && rid[u] >= 0) s0[rid[u]] = sc + b0;
             }
@@ -478,6 +484,21 @@ __device__ __forceinline__ void adam_reduce_body(float *__restrict__ theta, floa
     const float bc1 = 1.f - powf(h.beta1, t), bc2 = 1.f - powf(h.beta2, t);
     const float denom = sqrtf(vi) / sqrtf(bc2) + h.eps;
     theta[i] = p - (h.lr / bc1) * (mi / denom);
+}
+
+// two-class cross entropy and its gradient from the logit difference: one v_exp_f32, one v_log_f32, one v_rcp_f32
+// (this runs on a single lane per row, on the critical path between forward and backward: the library expf / logf /
+// division sequences are hundreds of dependent instructions there).  Absolute error ~1e-7: far inside the 1e-4 / 2e-5
+// the parity tests allow for logits / gradients.
+__device__ __forceinline__ void xent2(float a, float b, int y, float &loss, float &da, float &db) {
+    const float d = b - a;
+    const float e = __expf(-fabsf(d));                   // in (0, 1]
+    const float inv = __frcp_rn(1.f + e);
+    const float p_hi = inv, p_lo = e * inv;              // softmax of the larger / the smaller logit
+    const float pa = d > 0.f ? p_lo : p_hi, pb = d > 0.f ? p_hi : p_lo;
+    loss = fmaxf(a, b) + __logf(1.f + e) - (y == 1 ? b : a);
+    da = pa - (y == 0 ? 1.f : 0.f);
+    db = pb - (y == 1 ? 1.f : 0.f);
 }
 
 // the same update for one parameter whose summed gradient g is already known

@@ -184,21 +184,6 @@ __device__ __forceinline__ f32x4 tile_ldsT_lds(const float *At, int lda, int m0,
     return acc;
 }
 
-// two-class cross entropy and its gradient from the logit difference: one v_exp_f32, one v_log_f32, one v_rcp_f32
-// (this runs on a single lane per row, on the critical path between forward and backward: the library expf / logf /
-// division sequences are hundreds of dependent instructions there).  Absolute error ~1e-7: far inside the 1e-4 / 2e-5
-// the parity tests allow for logits / gradients.
-__device__ __forceinline__ void xent2(float a, float b, int y, float &loss, float &da, float &db) {
-    const float d = b - a;
-    const float e = __expf(-fabsf(d));                   // in (0, 1]
-    const float inv = __frcp_rn(1.f + e);
-    const float p_hi = inv, p_lo = e * inv;              // softmax of the larger / the smaller logit
-    const float pa = d > 0.f ? p_lo : p_hi, pb = d > 0.f ? p_hi : p_lo;
-    loss = fmaxf(a, b) + __logf(1.f + e) - (y == 1 ? b : a);
-    da = pa - (y == 0 ? 1.f : 0.f);
-    db = pb - (y == 1 ? 1.f : 0.f);
-}
-
 // sum over the 16 lanes of a DPP row (every lane gets it): quad permutes, then the half-row / row mirrors
 __device__ __forceinline__ float row16_sum(float p) {
     p = dpp_add<0xB1>(p);
@@ -673,6 +658,12 @@ __global__ void __launch_bounds__(256) adam_reduce_kernel(float *__restrict__ th
 }
 
 __global__ void clear_word_kernel(uint32_t *w) { w[0] = 0u; }
+// dst[i] = src[i] if an update is pending (pcg_adam_flush: the stepped label classifier -> the parameter buffer)
+__global__ void __launch_bounds__(256) copy_if_pending_kernel(float *__restrict__ dst, const float *__restrict__ src, int n,
+                                                              const uint32_t *__restrict__ pending) {
+    if (pending[0] == 0u) return;
+    for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) dst[i] = src[i];
+}
 
 // The partitioned path's two optimizer launches (its gradient goes through an all-reduce between them):
 //   grad_reduce   : slabs summed in tile order -> grad; marks "a gradient is waiting" (flag[0] = 1)
@@ -857,7 +848,10 @@ int pcg_train_dense(const pcg_graph_desc *g, float *theta, float *m, float *v, i
         x.cnt = cnt;
         x.partial_stride = g->feat_stride;
     }
-    if (adam_clf) {
+    if (adam_clf == 2) {                     // the label classifier is stepped elsewhere (pcg_choose_gather_train): slabs + "pending" only
+        if (!slabs || !sync_words) return PCG_E_ARG;
+        x.pending = sync_words + 1;
+    } else if (adam_clf) {
         if (!slabs || !m || !v || !sync_words) return PCG_E_ARG;
         x.theta_rw = theta;
         x.m = m;
@@ -911,7 +905,7 @@ int pcg_adam_apply_pending(float *theta, float *m, float *v, const float *grad, 
 
 int pcg_adam_flush(float *theta, float *m, float *v, const float *slabs, int32_t n_slabs, int64_t n_params, int64_t p_end,
                    const int32_t *step_counter, uint32_t *sync_words, double lr, double beta1, double beta2, double eps,
-                   double weight_decay, void *stream) {
+                   double weight_decay, const float *clf_next, void *stream) {
     if (!theta || !m || !v || !slabs || !step_counter || !sync_words || n_slabs < 0 || n_params < 1 || p_end < 0 ||
         p_end > n_params)
         return PCG_E_ARG;
@@ -920,6 +914,11 @@ int pcg_adam_flush(float *theta, float *m, float *v, const float *slabs, int32_t
     if (p_end > 0) {
         hipLaunchKernelGGL(pcg::adam_reduce_kernel, dim3((unsigned)((p_end + PCG_WAVE - 1) / PCG_WAVE)), dim3(256), 0, st, theta, m,
                            v, slabs, n_slabs, n_params, (int64_t)0, p_end, step_counter, h, (float *)nullptr, 1,
+                           (const uint32_t *)(sync_words + 1));
+        PCG_LAUNCH_CHECK();
+    }
+    if (clf_next && p_end < n_params) {      // (pcg_choose_gather_train keeps the stepped label classifier outside theta until now)
+        hipLaunchKernelGGL(pcg::copy_if_pending_kernel, dim3(1), dim3(256), 0, st, theta + p_end, clf_next, (int)(n_params - p_end),
                            (const uint32_t *)(sync_words + 1));
         PCG_LAUNCH_CHECK();
     }

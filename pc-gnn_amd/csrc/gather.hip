@@ -60,12 +60,13 @@ __device__ __forceinline__ void store_row(float *out, const float4 (&acc)[NACC],
     }
 }
 
+// workgroup `block` of `n_blocks` (256 threads each)
 template <int NACC>
-__global__ void __launch_bounds__(256) gather_chunks(const AggArgs a) {
+__device__ __forceinline__ void gather_chunks_body(const AggArgs &a, uint32_t block, uint32_t n_blocks) {
     const int lane = lane_id();
     const RowGeom q = row_geom(a.feat_stride, lane);
-    const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
-    const uint32_t ch0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t nwaves = n_blocks * (blockDim.x >> 6);
+    const uint32_t ch0 = block * (blockDim.x >> 6) + (threadIdx.x >> 6);
     // the chunk's descriptor (written by the plan) is requested together with the chunk count: one load level instead of
     // four (count -> row -> offsets -> list).  n = the entries of the chunk the select kernel filled (it overwrites the
     // capacity share the plan put there; nothing fills a region's unused tail).
@@ -149,6 +150,52 @@ __global__ void __launch_bounds__(256) gather_chunks(const AggArgs a) {
     }
 }
 
+template <int NACC>
+__global__ void __launch_bounds__(256) gather_chunks(const AggArgs a) {
+    gather_chunks_body<NACC>(a, blockIdx.x, gridDim.x);
+}
+
+// The gather launch of a TRAINING step, with what else fits beside it (SideJob, choose.h): workgroups
+//   [gather chunks | the previous step's deferred Adam update (all parameters but the label classifier's) |
+//    the next step's train-pos keys | the next step's score pass]
+// The dense kernel that follows needs the first two; the select kernel of the NEXT step needs the last two, which read the
+// classifier the select launch of THIS step has just stepped (ClfStep) - nothing here waits for anything inside the launch.
+#ifndef PCG_GT_WPE          // (A/B switch: 1 = cap the registers at the gather's own 80 - 6 waves per SIMD - at the price of a few spills)
+#define PCG_GT_WPE 0
+#endif
+#if PCG_GT_WPE
+#define PCG_GT_ATTR __attribute__((amdgpu_waves_per_eu(6, 8)))
+#else
+#define PCG_GT_ATTR
+#endif
+template <int NACC>
+__global__ void __launch_bounds__(256) PCG_GT_ATTR gather_train_kernel(const AggArgs a, const SideJob s, int n_gather_blocks, int64_t n_nodes,
+                                                           const int32_t *__restrict__ train_pos, int n_pos) {
+    __shared__ float part[4][PCG_WAVE];
+    __shared__ unsigned short sel[4 * MARK_GROUP];            // score_marked_body
+    int b = (int)blockIdx.x;
+    if (s.zero_word && b == 0 && threadIdx.x == 0) s.zero_word[0] = 0u;     // the select kernel's arrival counter, for its next launch
+    if (b < n_gather_blocks) {
+        gather_chunks_body<NACC>(a, (uint32_t)b, (uint32_t)n_gather_blocks);
+        return;
+    }
+    b -= n_gather_blocks;
+    if (b < s.n_adam_blocks) {
+        if (s.ad.pending[0] != 0u)                            // (one word, the same for every thread)
+            adam_reduce_body(s.ad.theta, s.ad.m, s.ad.v, s.ad.slabs, (int)s.ad.pending[1], s.ad.n_params, 0, s.ad.p_end,
+                             s.ad.step_counter, s.ad.h, nullptr, 1, b, part);
+        return;
+    }
+    b -= s.n_adam_blocks;
+    if (b < s.n_key_blocks) {
+        pos_key_body(a.X, a.feat_dim, a.feat_stride, s.W, s.bias, train_pos, n_pos, s.raw_keys, b, s.n_key_blocks);
+        return;
+    }
+    b -= s.n_key_blocks;
+    if (s.touched) score_marked_body<NACC>(a.X, a.feat_dim, a.feat_stride, s.W, s.bias, n_nodes, s.s0, s.touched, b, s.n_score_blocks, sel);
+    else score_table_body<NACC>(a.X, a.feat_dim, a.feat_stride, s.W, s.bias, 0, n_nodes, s.s0, b, s.n_score_blocks);
+}
+
 // rows longer than one chunk: add the partial sums in chunk order
 template <int NACC>
 __global__ void __launch_bounds__(256) combine_rows(const AggArgs a) {
@@ -207,6 +254,48 @@ static int launch_aggregate(const AggArgs &g, hipStream_t st, bool combine) {
     return PCG_OK;
 }
 
+static void fill_agg_args(AggArgs &a, const float *X, int32_t feat_dim, int32_t feat_stride, int64_t table_rows, int32_t n_rows,
+                          const int32_t *cnt, const Workspace &w, int32_t norm, float *agg, int32_t agg_stride, uint32_t *status) {
+    a.X = X;
+    a.feat_dim = feat_dim;
+    a.feat_stride = feat_stride;
+    a.n_rows = n_rows;
+    a.row_begin = w.row_begin;
+    a.chunk_begin = w.chunk_begin;
+    a.len = w.len;
+    a.cnt = cnt;
+    a.chunk_desc = w.chunk_desc;
+    a.chunk_cap = (int32_t)w.chunk_cap;
+    a.list = w.list;
+    a.n_chunks = w.counters + C_NCHUNK;
+    a.partial = w.partial;
+    a.agg = agg;
+    a.agg_stride = agg_stride;
+    a.norm = norm;
+    a.table_rows = table_rows;
+    a.status = status;
+}
+
+int launch_gather_train(const float *X, int32_t feat_dim, int32_t feat_stride, int64_t table_rows, const int32_t *cnt,
+                        const pcg_graph_desc *g, int32_t B, const Workspace &w, float *agg, int32_t agg_stride, uint32_t *status,
+                        const SideJob &side, hipStream_t st) {
+    if (!X || !cnt || !g || !agg || B < 1 || table_rows < 1) return PCG_E_ARG;
+    if (feat_stride % 4 != 0 || feat_stride < feat_dim || agg_stride < feat_dim) return PCG_E_ARG;
+    if (feat_stride > 512) return PCG_E_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(X) & 15u) != 0) return PCG_E_ARG;
+    AggArgs a;
+    fill_agg_args(a, X, feat_dim, feat_stride, table_rows, g->n_rel * B, cnt, w, PCG_NORM_COUNT, agg, agg_stride, status);
+    const int extra = side.n_adam_blocks + side.n_key_blocks + side.n_score_blocks;
+    if (feat_stride <= 256)
+        hipLaunchKernelGGL(gather_train_kernel<1>, dim3(GATHER_BLOCKS + extra), dim3(256), 0, st, a, side, GATHER_BLOCKS, g->n_nodes,
+                           g->train_pos, g->n_pos);
+    else
+        hipLaunchKernelGGL(gather_train_kernel<2>, dim3(GATHER_BLOCKS + extra), dim3(256), 0, st, a, side, GATHER_BLOCKS, g->n_nodes,
+                           g->train_pos, g->n_pos);
+    PCG_LAUNCH_CHECK();
+    return PCG_OK;
+}
+
 }  // namespace pcg
 
 extern "C" {
@@ -223,24 +312,7 @@ static int aggregate(const float *X, int32_t feat_dim, int32_t feat_stride, int6
     pcg::Workspace w;
     pcg::carve1(g, B, list_capacity, static_cast<unsigned char *>(workspace), &w, static_cast<unsigned char *>(const_cast<void *>(plan)));
     pcg::AggArgs a;
-    a.X = X;
-    a.feat_dim = feat_dim;
-    a.feat_stride = feat_stride;
-    a.n_rows = n_rows;
-    a.row_begin = w.row_begin;
-    a.chunk_begin = w.chunk_begin;
-    a.len = w.len;
-    a.cnt = cnt;
-    a.chunk_desc = w.chunk_desc;
-    a.chunk_cap = (int32_t)w.chunk_cap;
-    a.list = w.list;
-    a.n_chunks = w.counters + pcg::C_NCHUNK;
-    a.partial = w.partial;
-    a.agg = agg;
-    a.agg_stride = agg_stride;
-    a.norm = norm;
-    a.table_rows = table_rows;
-    a.status = status;
+    pcg::fill_agg_args(a, X, feat_dim, feat_stride, table_rows, n_rows, cnt, w, norm, agg, agg_stride, status);
     hipStream_t st = static_cast<hipStream_t>(stream);
     return feat_stride <= 256 ? pcg::launch_aggregate<1>(a, st, combine) : pcg::launch_aggregate<2>(a, st, combine);
 }

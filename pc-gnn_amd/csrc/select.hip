@@ -28,6 +28,13 @@
 namespace pcg {
 
 constexpr int KEY_UNROLL = 8;    // neighbour-score gathers in flight per lane
+// every gather of a neighbour's score: a plain load.  (Measured: non-temporal gathers - in the workgroup rows only, or in every
+// row - cost the power-law 2 M batch +17 us per step and the YelpChi-like one +0.6 / +2.7: neighbours are popular nodes, and
+// their score lines are re-used out of the L1 / L2 by the rows that follow.)
+template <int LEVEL>
+__device__ __forceinline__ float s0_ld(const float *__restrict__ s0, uint32_t id) {
+    return s0[id];
+}
 constexpr int KPT = T1_CAP / PCG_WAVE;   // keys per lane of a single-wave register row
 
 #define PCG_STAMP(slot)                                                                \
@@ -465,7 +472,7 @@ __device__ __forceinline__ void select_four_short_rows(const ChooseArgs &a, int 
     const uint32_t id = (uint32_t)nbr[pos < p.d ? pos : (p.d > 0 ? p.d - 1 : 0)];
     const float c = a.center_s0 ? a.center_s0[row - r * a.B] : a.s0[p.node + a.center_off];
     const bool keep_all = rec_keep_all(p);
-    const float sc = a.s0[id];
+    const float sc = s0_ld<2>(a.s0, id);
     const uint32_t key = have ? dist_key(c, sc) : 0xFFFFFFFFu;     // (valid keys have bit 31 clear)
     int rank = 0;
     PCG_ROR_STEP(1); PCG_ROR_STEP(2); PCG_ROR_STEP(3); PCG_ROR_STEP(4); PCG_ROR_STEP(5);
@@ -492,7 +499,7 @@ __device__ __forceinline__ void select_lane_row(const ChooseArgs &a, int row, ui
     const bool tail = p.m > 0 || a.add_self;
     const bool have = lane < d;
     const uint32_t id = (uint32_t)nbr[have ? lane : (d > 0 ? d - 1 : 0)];   // unconditional load (clamped)
-    const float sc = a.s0[id];
+    const float sc = s0_ld<2>(a.s0, id);
     const uint32_t mine = have ? dist_key(c, sc) : 0xFFFFFFFFu;
     PCG_STAMP(1);
     int rank = 0;
@@ -554,7 +561,7 @@ __device__ __forceinline__ void select_wave_row(const ChooseArgs &a, int row, ui
             id[u] = (uint32_t)nbr[i < d ? i : d - 1];                    // unconditional loads (clamped): all in flight together
         }
 #pragma unroll
-        for (int u = 0; u < KPT; ++u) sc[u] = a.s0[id[u]];
+        for (int u = 0; u < KPT; ++u) sc[u] = s0_ld<2>(a.s0, id[u]);
 #pragma unroll
         for (int u = 0; u < KPT; ++u) key[u] = (u * PCG_WAVE + lane < d) ? dist_key(c, sc[u]) : 0xFFFFFFFFu;
     }
@@ -715,7 +722,7 @@ __device__ __forceinline__ void select_wg_row(const ChooseArgs &a, int row, uint
                 id[u] = (uint32_t)nbr[i < d ? i : d - 1];
             }
 #pragma unroll
-            for (int u = 0; u < KU1; ++u) sc[u] = s0[id[u]];
+            for (int u = 0; u < KU1; ++u) sc[u] = s0_ld<1>(s0, id[u]);
 #pragma unroll
             for (int u = 0; u < KU1; ++u) {
                 const int i = base + u * NT;
@@ -1046,6 +1053,178 @@ __device__ __forceinline__ void sort_share(const ChooseArgs &a, int w, uint64_t 
     }
     __syncthreads();                                                       // (the LDS is the row paths' again)
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The label classifier's own training step for this batch (ClfStep, choose.h), by ONE workgroup of the select launch:
+//   logits of the centres' feature rows (layers.py:230-243) -> cross entropy against the labels (model.py:54-61, the term
+//   weighted lambda_1) -> d loss / d W, d b summed over the batch in a fixed order -> Adam (model_handler.py:153).
+// The classifier's parameters get no gradient from anything this launch or the two after it compute, so the update of step t
+// does not have to wait for step t's dense kernel - and the scores of step t + 1 can be formed beside step t's gather.
+// Geometry as in the score pass: lanes_per_row lanes share a feature row, each its float4 chunk(s); row slots x waves x
+// iterations add up in registers, then slots (butterfly), then waves (LDS, wave order).  lds: (SEL_NW + 1) * (2F + 2) floats.
+// ---------------------------------------------------------------------------------------------------------------------
+// (not inlined, and handed its few arguments by value: a reference to the kernel's argument block would be a stack copy of it)
+// K: float4 chunks of a row per lane (2 only for rows of more than 256 floats), U: rows in flight per lane.  Everything the
+// step reads that depends on nothing else (the classifier, its Adam state, the step count, the batch's ids and labels) is
+// requested up front; the ids and labels are staged in LDS a block of rows at a time, so that the feature rows of half a batch
+// of 1024 are one memory round trip; every (wave, row slot) leaves its partial gradient in LDS and 2F + 2 threads add them up in
+// (wave, slot) order - no cross-lane traffic.  lds: NC4 + SEL_NW * rpw * NC4 + 2 * RB words (NC4 = 2F + 2 rounded up to 4).
+template <int K, int U>
+__device__ __noinline__ void clf_step_body(const ClfStep c, const float *__restrict__ X, int F, int stride,
+                                           const int32_t *__restrict__ nodes, const int32_t *__restrict__ labels, int B,
+                                           uint32_t *lds_u, int tid, unsigned long long *st) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    constexpr int NT = SEL_NW * PCG_WAVE;
+    const int NC = 2 * F + 2, NC4 = (NC + 3) & ~3;
+    const int lane = tid & (PCG_WAVE - 1), wave = tid >> 6;
+    const int lpr = lanes_per_row(stride), rpw = PCG_WAVE / lpr, slot = lane / lpr, sub = lane % lpr, nch = stride >> 2;
+    const int n_part = SEL_NW * rpw;                            // partial gradients: one per (wave, row slot)
+    float *wl = reinterpret_cast<float *>(lds_u);              // [NC] the classifier this step scores / selects by
+    float *red = wl + NC4;                                      // [n_part][NC4]
+    int *idl = reinterpret_cast<int *>(red + n_part * NC4);     // [RB] a block of the batch's ids, [RB] its labels
+    int RB = ((WG_KEYCAP - (n_part + 1) * NC4) / 2) & ~(PCG_WAVE - 1);          // (>= 2048: feat_stride <= 512, host-checked)
+    RB = RB < 6 * NT ? RB : 6 * NT;
+    int *yl = idl + RB;
+    // this thread's parameter (threads < NC; a loop covers NC > NT), its Adam state, the step count: requested now
+    const bool mine = tid < NC;
+    const int ic = mine ? tid : 0;
+    const float p_old = c.clf_next[ic], m_old = c.m[ic], v_old = c.v[ic];
+    const float t = (float)(c.step_counter[0] + 1);             // this step's dense launch counts it; it has not run yet
+    constexpr int NPRE = 6;                                     // ids / labels per thread of a block: RB <= NPRE * NT
+    int nb = B < RB ? B : RB;
+    int id_pre[NPRE], y_pre[NPRE];
+#pragma unroll
+    for (int q = 0; q < NPRE; ++q) {                            // the first block's ids / labels (clamped: unconditional loads)
+        const int i = tid + q * NT;
+        id_pre[q] = nodes[i < nb ? i : nb - 1];
+        y_pre[q] = labels[i < nb ? i : nb - 1];
+    }
+    for (int i = tid; i < NC; i += NT) {
+        const float w = i == tid ? p_old : c.clf_next[i];
+        wl[i] = w;
+        c.theta_clf[i] = w;                                     // what this step's dense kernel computes the loss term with
+    }
+#pragma unroll
+    for (int q = 0; q < NPRE; ++q) {
+        const int i = tid + q * NT;
+        if (i < nb) {
+            idl[i] = id_pre[q];
+            yl[i] = y_pre[q];
+        }
+    }
+    const float bc1 = 1.f - powf(c.h.beta1, t), bc2 = 1.f - powf(c.h.beta2, t);   // (behind the loads, ahead of the rows)
+    __syncthreads();
+    if (st && tid == 0) st[0] = wall_clock64();
+    bool has[K];
+    int chc[K];
+    float w0[K][4], w1[K][4];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int ch = sub + k * lpr;
+        has[k] = ch < nch;
+        chc[k] = has[k] ? ch : nch - 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = 4 * chc[k] + j;
+            const bool ok = has[k] && f < F;
+            w0[k][j] = ok ? wl[f] : 0.f;
+            w1[k][j] = ok ? wl[F + f] : 0.f;
+        }
+    }
+    const float b0 = wl[2 * F], b1 = wl[2 * F + 1];
+    float g0[K][4], g1[K][4], gb0 = 0.f, gb1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g0[k][j] = g1[k][j] = 0.f;
+    const int per_iter = SEL_NW * rpw;                          // rows the workgroup covers per load round
+    for (int blk = 0; blk < B; blk += RB) {
+        if (blk > 0) {                                          // (batches beyond one block: staged here, one more round trip each)
+            nb = B - blk < RB ? B - blk : RB;
+            __syncthreads();
+            for (int i = tid; i < nb; i += NT) {
+                idl[i] = nodes[blk + i];
+                yl[i] = labels[blk + i];
+            }
+            __syncthreads();
+        }
+        for (int base = wave * rpw; base < nb; base += per_iter * U) {
+            f4 x[U][K];
+            int y[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {                       // (unconditional loads: index clamped, the result not counted)
+                const int b = base + u * per_iter + slot;
+                const int bc = b < nb ? b : nb - 1;
+                y[u] = b < nb ? yl[bc] : -1;
+                const float *xrow = X + (size_t)idl[bc] * stride;
+#pragma unroll
+                for (int k = 0; k < K; ++k) x[u][k] = *reinterpret_cast<const f4 *>(xrow + 4 * chc[k]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    p0 = fmaf(x[u][k].x, w0[k][0], p0); p0 = fmaf(x[u][k].y, w0[k][1], p0);
+                    p0 = fmaf(x[u][k].z, w0[k][2], p0); p0 = fmaf(x[u][k].w, w0[k][3], p0);
+                    p1 = fmaf(x[u][k].x, w1[k][0], p1); p1 = fmaf(x[u][k].y, w1[k][1], p1);
+                    p1 = fmaf(x[u][k].z, w1[k][2], p1); p1 = fmaf(x[u][k].w, w1[k][3], p1);
+                }
+                p0 = score_reduce(p0, lpr);
+                p1 = score_reduce(p1, lpr);
+                float loss, d0, d1;
+                xent2(p0 + b0, p1 + b1, y[u], loss, d0, d1);
+                d0 = y[u] >= 0 ? d0 * c.scale : 0.f;
+                d1 = y[u] >= 0 ? d1 * c.scale : 0.f;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    g0[k][0] = fmaf(d0, x[u][k].x, g0[k][0]); g0[k][1] = fmaf(d0, x[u][k].y, g0[k][1]);
+                    g0[k][2] = fmaf(d0, x[u][k].z, g0[k][2]); g0[k][3] = fmaf(d0, x[u][k].w, g0[k][3]);
+                    g1[k][0] = fmaf(d1, x[u][k].x, g1[k][0]); g1[k][1] = fmaf(d1, x[u][k].y, g1[k][1]);
+                    g1[k][2] = fmaf(d1, x[u][k].z, g1[k][2]); g1[k][3] = fmaf(d1, x[u][k].w, g1[k][3]);
+                }
+                gb0 += d0;
+                gb1 += d1;
+            }
+        }
+    }
+    if (st && tid == 0) st[1] = wall_clock64();
+    {
+        float *mine_red = red + (wave * rpw + slot) * NC4;
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int f = 4 * chc[k] + j;
+                if (has[k] && f < F) {
+                    mine_red[f] = g0[k][j];
+                    mine_red[F + f] = g1[k][j];
+                }
+            }
+        if (sub == 0) {
+            mine_red[2 * F] = gb0;
+            mine_red[2 * F + 1] = gb1;
+        }
+    }
+    __syncthreads();
+    if (st && tid == 0) st[2] = wall_clock64();
+    for (int i = tid; i < NC; i += NT) {
+        float g = red[i];
+        for (int w = 1; w < n_part; ++w) g += red[w * NC4 + i];
+        const bool first = i == tid;                             // (its state came with the first loads)
+        const float p = first ? p_old : wl[i];
+        const float mo = first ? m_old : c.m[i], vo = first ? v_old : c.v[i];
+        g = fmaf(c.h.wd, p, g);                                 // torch.optim.Adam, coupled weight decay (as adam_apply_one)
+        const float mi = c.h.beta1 * mo + (1.f - c.h.beta1) * g;
+        const float vi = c.h.beta2 * vo + (1.f - c.h.beta2) * g * g;
+        c.m[i] = mi;
+        c.v[i] = vi;
+        const float denom = sqrtf(vi) / sqrtf(bc2) + c.h.eps;
+        c.clf_next[i] = p - (c.h.lr / bc1) * (mi / denom);
+    }
+    __syncthreads();                                             // (the LDS is the row paths' again)
+}
+
 __global__ void __launch_bounds__(SEL_NW *PCG_WAVE) __attribute__((amdgpu_waves_per_eu(6, 8))) select_rows(const ChooseArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t *lds = reinterpret_cast<uint32_t *>(smem);
@@ -1065,20 +1244,32 @@ __global__ void __launch_bounds__(SEL_NW *PCG_WAVE) __attribute__((amdgpu_waves_
     const int n_wg = n16 + n4, n_items = n1 + n0 + (na + 3) / 4;
     // single-wave items per unit: eight (one per wave) when there is plenty of them, fewer when the batch is so small that
     // the items can be spread over more workgroups (more CUs' load paths) than eight per workgroup would use
-    const int grid = (int)gridDim.x;
+    // (training: workgroup 0 does the label classifier's step and nothing else; the row workgroups are the others)
+    const int clf_wg = a.clf.clf_next ? 1 : 0;
+    const int grid = (int)gridDim.x - clf_wg, bid = (int)blockIdx.x - clf_wg;
     const int avail = grid - n_wg > grid / 4 ? grid - n_wg : grid / 4;
     int bs = (n_items + avail - 1) / avail;
     bs = bs < 1 ? 1 : (bs > SEL_NW ? SEL_NW : bs);
     const int n_units = n_wg + (n_items + bs - 1) / bs;
     const bool pull = n_units > grid;                                      // otherwise unit = workgroup: no atomics at all
-    const int shard = (int)blockIdx.x % SEL_SHARDS;
+    const int shard = (bid < 0 ? 0 : bid) % SEL_SHARDS;
     uint32_t *head = a.w.heads + 16 * shard;                               // (64 bytes apart)
-    if (a.pending_clear && blockIdx.x == 0 && leader) a.pending_clear[0] = 0u;   // the launch before has applied the deferred update
+    if (a.pending_clear && bid == 0 && leader) a.pending_clear[0] = 0u;   // the launch before has applied the deferred update
     __syncthreads();
+    // the label classifier's step for this batch (training): one workgroup, before its share of the rows
+    if (bid < 0) {
+        // (one workgroup, as long as the launch's longest rows, sharing its CU with two workgroups of rows: it goes first)
+        __builtin_amdgcn_s_setprio(3);
+        if (a.stamps && leader) a.stamps[(size_t)a.g.n_rel * a.B * 8 + 2] = wall_clock64();
+        if (a.g.feat_stride > 256) clf_step_body<2, 2>(a.clf, a.g.X, a.g.feat_dim, a.g.feat_stride, a.nodes, a.labels, a.B, lds, (int)threadIdx.x, a.stamps ? a.stamps + (size_t)a.g.n_rel * a.B * 8 + 8 : nullptr);
+        else clf_step_body<1, 4>(a.clf, a.g.X, a.g.feat_dim, a.g.feat_stride, a.nodes, a.labels, a.B, lds, (int)threadIdx.x, a.stamps ? a.stamps + (size_t)a.g.n_rel * a.B * 8 + 8 : nullptr);
+        if (a.stamps && leader) a.stamps[(size_t)a.g.n_rel * a.B * 8 + 3] = wall_clock64();
+        return;
+    }
 
     // The train positives' sort, inside this launch and shared by its workgroups (sort_share), before the rows: only rows with
     // minority picks ever wait for the result (wait_sorted_keys), and they are busy with their own distance keys meanwhile.
-    int u = (int)blockIdx.x;
+    int u = bid;
     if (a.n_sort > 0) {
         const int helpers = a.n_sort * a.sort_slices;
         if (u < helpers) {
@@ -1099,7 +1290,7 @@ __global__ void __launch_bounds__(SEL_NW *PCG_WAVE) __attribute__((amdgpu_waves_
         // batch runs; behind a workgroup row (up to tens of microseconds) it is made afterwards - a busy workgroup must not sit
         // on a unit that an idle one could take
         const bool ahead = u >= n_wg;
-        if (leader && pull && ahead) pending = shard + SEL_SHARDS * (grid / SEL_SHARDS + (int)atomicAdd(head, 1u));
+        if (leader && pull && ahead) pending = grid + shard + SEL_SHARDS * (int)atomicAdd(head, 1u);
         // the thread index goes through an opaque move once per unit: everything the row paths derive from it (lane masks,
         // quarter-wave indices, LDS offsets) is then recomputed per unit - a few VALU ops - instead of being hoisted out of
         // this loop and kept alive across every path, which costs more registers than the 80 the occupancy allows (spills)
@@ -1126,7 +1317,7 @@ __global__ void __launch_bounds__(SEL_NW *PCG_WAVE) __attribute__((amdgpu_waves_
             }
         }
         if (!pull) break;
-        if (leader) claim[slot] = ahead ? pending : shard + SEL_SHARDS * (grid / SEL_SHARDS + (int)atomicAdd(head, 1u));
+        if (leader) claim[slot] = ahead ? pending : grid + shard + SEL_SHARDS * (int)atomicAdd(head, 1u);
         __syncthreads();
         u = claim[slot];
         slot ^= 1;
@@ -1134,7 +1325,7 @@ __global__ void __launch_bounds__(SEL_NW *PCG_WAVE) __attribute__((amdgpu_waves_
     // the last workgroup out puts the heads back to zero, so that the kernel can be launched again on the same plan
     if (leader && pull) {
         const unsigned done = atomicAdd(a.w.heads + 15, 1u);
-        if (done == gridDim.x - 1) {
+        if (done == (unsigned)grid - 1u) {
             for (int i = 0; i < SEL_SHARDS; ++i) atomicExch(a.w.heads + 16 * i, 0u);
             atomicExch(a.w.heads + 15, 0u);
         }
@@ -1203,8 +1394,9 @@ int launch_select_rows(const ChooseArgs &a, hipStream_t st) {
         blocks = (v >= SEL_SHARDS && v <= SEL_BLOCKS && v % SEL_SHARDS == 0) ? v : SEL_BLOCKS;
     }
     ChooseArgs as = a;
+    const int row_blocks = blocks - (a.clf.clf_next ? 1 : 0);      // (training: one of the workgroups steps the label classifier)
     if (a.n_sort > 0) {                      // how the sort is shared: slices per key group, keys per slice (>= 128)
-        if (a.n_sort > blocks) return PCG_E_ARG;
+        if (a.n_sort > row_blocks) return PCG_E_ARG;
         // (PCG_SORT_SLICES: tuning knob.  More slices = fewer compares per workgroup, but accumulator atomics and a ticket hop,
         //  and more workgroups that start on their rows late; measured on the YelpChi-like batch: see DESIGN.md)
         static int knob = -1;
@@ -1213,7 +1405,7 @@ int launch_select_rows(const ChooseArgs &a, hipStream_t st) {
             knob = e ? atoi(e) : 0;
         }
         int slices = knob > 0 ? knob : 4;
-        if (slices > blocks / a.n_sort) slices = blocks / a.n_sort;
+        if (slices > row_blocks / a.n_sort) slices = row_blocks / a.n_sort;
         const int most = (a.g.n_pos + 127) / 128;
         slices = slices > most ? most : slices;
         as.sort_slices = slices < 1 ? 1 : slices;

@@ -494,7 +494,7 @@ class DistributedPCGNN:
         sort = train_flag and P > 0
         in_select = sort and bool(lib.pcg_pos_sort_in_select(P))
         check(lib.pcg_step_scores(g.desc_ref(), _p(self.w_clf), _p(self.b_clf), 0, g.n_nodes, _p(self.s0_full), _p(self.row_gid),
-                                  _p(self.keys) if in_select else None, part.n_local, _p(self.sync), st), "pcg_step_scores")
+                                  _p(self.keys) if in_select else None, part.n_local, _p(self.sync), None, st), "pcg_step_scores")
         if sort and not in_select:           # too many positives for the in-kernel sort: the bucket sort's launches
             ops.pos_sort(g, self.s0_full, self.keys)
         check(lib.pcg_choose_select_planned(

@@ -84,6 +84,12 @@ class FusedPCGNN:
         #  rank accumulators and group tickets]
         self.sync = torch.zeros(int(lib.pcg_sync_words_count()), dtype=torch.int32, device=self.dev)
         self.n_rest = int(lib.pcg_dense_param_offset(self.F, self.E, self.R, 3, 0))   # parameters before the label classifier
+        # The label classifier is stepped on its own, one step ahead of the rest (pcg_choose_gather_train): clf_next is the
+        # classifier the NEXT select launch scores by; theta's copy is the one the current step's loss is computed with.  flush()
+        # makes them equal.  _fresh: s0 / the unsorted train-pos keys hold the scores of clf_next (a training step with
+        # score_next leaves them so); anything else that touches s0, the keys or the parameters clears it.
+        self.clf_next = self.theta[self.n_rest:].clone()
+        self._fresh = False
 
         # Score only the rows a batch's selection can read (its centres and their neighbours: a byte map per batch, built per epoch
         # beside the plans) instead of the whole table - worth it when the table is far larger than what a batch touches
@@ -115,6 +121,7 @@ class FusedPCGNN:
         self._graphs.clear()
         self._ep_graphs.clear()
         self._ep_sets = None
+        self._fresh = False
         self.maxB = B
         if self._list_capacity_arg is None:
             self.list_capacity, self.clipped = default_list_capacity(g, B)
@@ -182,6 +189,7 @@ class FusedPCGNN:
     def _enqueue_scores(self, train_flag):
         """label-aware score table + per-step sort of the train positives (the calls of their own: evaluation, parity)."""
         g = self.g
+        self._fresh = False                         # (s0 / the keys are overwritten: theta's classifier, sorted keys)
         ops.score_table(g, self.w_clf, self.b_clf, out=self.s0)
         return ops.pos_sort(g, self.s0, self.keys) if (train_flag and g.n_pos) else None
 
@@ -190,11 +198,55 @@ class FusedPCGNN:
         touched: address of the batch's byte map - only the rows it marks are scored."""
         g = self.g
         b1, b2 = self.betas
+        self._fresh = False                         # (the four-launch step: scores of theta's classifier, every step)
         _lib.check(self.lib.pcg_step_scores_train(
             g.desc_ref(), _p(self.theta), _p(self.m), _p(self.v), self.E, _p(self.s0), _p(self.keys) if g.n_pos else None,
             _p(self.slabs), _p(self.step_counter), _p(self.sync), self.lr, b1, b2, self.eps, self.wd,
             None if touched is None else C.c_void_p(touched), self._stream()), "pcg_step_scores_train")
         return self.keys if g.n_pos else None
+
+    def params_changed(self):
+        """Tell the engine that the parameters were written from outside (a state dict loaded into the flat buffer's views):
+        the stepped copy of the label classifier and the score table are taken from theta again."""
+        self.flush()
+        self.clf_next.copy_(self.theta[self.n_rest:])
+        self._fresh = False
+
+    def _enqueue_refresh(self, touched: Optional[int] = None):
+        """scores + unsorted train-pos keys of the classifier the next select launch uses (clf_next), one launch (no update of
+        anything): the first training step after anything else has run, and every first step of an epoch of a touched-rows
+        engine (whose previous step could not know this batch's map)."""
+        g = self.g
+        F = self.F
+        _lib.check(self.lib.pcg_step_scores(
+            g.desc_ref(), _p(self.clf_next), C.c_void_p(self.clf_next.data_ptr() + 8 * F), 0, g.n_nodes, _p(self.s0), None,
+            _p(self.keys) if g.n_pos else None, -1, _p(self.sync), None if touched is None else C.c_void_p(touched),
+            self._stream()), "pcg_step_scores")
+        self._fresh = True
+
+    def _enqueue_choose_train(self, ids, labels, B, plan: int, score_next: bool, next_touched: Optional[int] = None):
+        """select (+ the label classifier's step for this batch) and gather (+ the deferred update of the other parameters,
+        + the next step's scores if score_next) of a training step: pcg_choose_gather_train."""
+        g = self.g
+        agg = self.agg.view(-1)[:g.R * B * g.feat_dim].view(g.R, B, g.feat_dim)
+        cnt = self.cnt.view(-1)[:g.R * B].view(g.R, B)
+        b1, b2 = self.betas
+        timed = self._prof is not None and not torch.cuda.is_current_stream_capturing()
+        if timed:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        _lib.check(self.lib.pcg_choose_gather_train(
+            g.desc_ref(), _p(ids), _p(labels), B, _p(self.s0), _p(self.keys) if g.n_pos else None, self._thr, self._rhos, 0,
+            _p(agg), agg.stride(-2), _p(cnt), _p(self.data), C.c_void_p(plan), self.list_capacity, _p(self.status), _p(self.sync),
+            _p(self.theta), _p(self.m), _p(self.v), self.E, _p(self.clf_next), _p(self.slabs), _p(self.step_counter),
+            self.lambda_1, 1.0 / (B * self.scale), self.lr, b1, b2, self.eps, self.wd, 1 if score_next else 0,
+            None if next_touched is None else C.c_void_p(next_touched), self._stream()), "pcg_choose_gather_train")
+        if timed:
+            ev[1].record()
+            self._prof.append(ev)
+        self.last_counts = cnt
+        self._fresh = bool(score_next)
+        return agg, cnt
 
     def _enqueue_choose(self, ids, labels, B, keys, train_flag, plan: int, sort_in_kernel: bool):
         """select + gather over the batch's plan (rows of several chunks are left as partial sums for the dense kernel).
@@ -219,31 +271,39 @@ class FusedPCGNN:
         return agg, cnt
 
     def _enqueue_tail(self, ids, labels, B, agg, plan: int, train: bool, combined=None, adam_clf: Optional[bool] = None):
-        """dense tail reading the gather's partial sums (no combine launch); training: + the label classifier's Adam
-        in the same launch, the update of the other parameters left pending (flush() or the next front applies it).
-        adam_clf=False (training): gradient slabs only - the caller reduces / all-reduces them itself."""
+        """dense tail reading the gather's partial sums (no combine launch); training: the gradient slabs are left pending
+        (adam_clf 2: the next step's gather launch or flush() applies them; the label classifier has been stepped by this step's
+        select launch).  adam_clf=0 (training): gradient slabs only - the caller reduces / all-reduces them itself; 1: the
+        label classifier's Adam by the kernel's last workgroup (the four-launch step of pcg_step_scores_train)."""
         g = self.g
         cnt = self.cnt.view(-1)[:g.R * B]
         b1, b2 = self.betas
-        adam_clf = train if adam_clf is None else adam_clf
+        adam_clf = (2 if train else 0) if adam_clf is None else int(adam_clf)
         _lib.check(self.lib.pcg_train_dense(
             g.desc_ref(), _p(self.theta), _p(self.m), _p(self.v), self.E, _p(ids), _p(labels), B, _p(agg), agg.stride(1),
             _p(cnt), _p(self.data), C.c_void_p(plan), self.list_capacity, self.lambda_1, 1.0 / (B * self.scale), _p(self.logits),
             _p(self.center), _p(combined), _p(self.row_loss) if labels is not None else None, _p(self.slabs) if train else None,
-            _p(self.step_counter) if train else None, _p(self.sync), self.lr, b1, b2, self.eps, self.wd, 1 if adam_clf else 0,
+            _p(self.step_counter) if train else None, _p(self.sync), self.lr, b1, b2, self.eps, self.wd, adam_clf,
             self._stream()), "pcg_train_dense")
+        if adam_clf == 1:                           # (the four-launch step updates theta's classifier in place)
+            self.clf_next.copy_(self.theta[self.n_rest:])
 
     def flush(self):
         """Apply a deferred Adam update now (no-op on the device if none is pending).  Enqueued, not synchronised."""
         b1, b2 = self.betas
         _lib.check(self.lib.pcg_adam_flush(
             _p(self.theta), _p(self.m), _p(self.v), _p(self.slabs), 0, self.n_params, self.n_rest, _p(self.step_counter),
-            _p(self.sync), self.lr, b1, b2, self.eps, self.wd, self._stream()), "pcg_adam_flush")
+            _p(self.sync), self.lr, b1, b2, self.eps, self.wd, _p(self.clf_next), self._stream()), "pcg_adam_flush")
 
-    def _enqueue_step(self, ids, labels, B, plan: int, defer: bool, touched: Optional[int] = None):
-        """the four launches of one training step over an existing plan (+ the flush unless deferred)."""
-        keys = self._enqueue_scores_train(touched)
-        agg, _ = self._enqueue_choose(ids, labels, B, keys, True, plan, sort_in_kernel=True)
+    def _enqueue_step(self, ids, labels, B, plan: int, defer: bool, touched: Optional[int] = None,
+                      next_touched: Optional[int] = None):
+        """the three launches of one training step over an existing plan (+ the flush unless deferred; + a score launch first
+        if the scores at hand are not those of the current classifier).  touched / next_touched: the byte maps of this batch
+        and of the one that follows (a touched-rows engine scores the next step's rows only if it is told which they are)."""
+        if not self._fresh:
+            self._enqueue_refresh(touched)
+        score_next = (not self.touched_on) or next_touched is not None
+        agg, _ = self._enqueue_choose_train(ids, labels, B, plan, score_next, next_touched)
         self._enqueue_tail(ids, labels, B, agg, plan, True)
         if not defer:
             self.flush()
@@ -266,7 +326,7 @@ class FusedPCGNN:
 
     # ------------------------------------------------------------------
     def train_step(self, ids: torch.Tensor, labels: torch.Tensor, allreduce=None, defer: bool = False, plan: Optional[int] = None,
-                   touched: Optional[int] = None):
+                   touched: Optional[int] = None, next_touched: Optional[int] = None):
         """zero_grad + loss + backward + Adam step for one batch (model_handler.py:149-153).
         ids / labels: int32 device tensors.  Nothing is returned and nothing syncs;
         ``last_loss()`` reads the batch loss afterwards.  ``allreduce(flat_grad)`` (data-parallel
@@ -284,7 +344,7 @@ class FusedPCGNN:
             if plan is None:
                 plan = self._enqueue_plan_one(ids, labels, B, True)
                 touched = self._touch_one.data_ptr() if self.touched_on else None
-            self._enqueue_step(ids, labels, B, plan, defer, touched)
+            self._enqueue_step(ids, labels, B, plan, defer, touched, next_touched)
             return
         # data-parallel ranks: gradient of the local batch -> all-reduce -> the same Adam on every rank
         self.flush()
@@ -292,6 +352,7 @@ class FusedPCGNN:
         self._enqueue_adam(B, apply=False, want_grad=True)
         allreduce(self.grad)
         self._enqueue_adam(B, apply=True, from_grad=True)
+        self.clf_next.copy_(self.theta[self.n_rest:])      # (the label classifier is stepped with everything else here)
 
     def train_step_graph(self, ids: torch.Tensor, labels: torch.Tensor, timed: bool = False):
         """Same as train_step through captured hipGraphs (one set per batch size): one graph launch
@@ -326,7 +387,7 @@ class FusedPCGNN:
         stream, capture every fn into a hipGraph of its own, and put the optimizer state back.  A deferred Adam update
         of real steps is applied first (the saved state then includes it); the warm-up's own is flushed and undone."""
         self.flush()
-        state = (self.theta.clone(), self.m.clone(), self.v.clone(), self.step_counter.clone())
+        state = (self.theta.clone(), self.m.clone(), self.v.clone(), self.step_counter.clone(), self.clf_next.clone())
         prof, self._prof = self._prof, None
         s = torch.cuda.Stream(self.dev)
         s.wait_stream(torch.cuda.current_stream(self.dev))
@@ -341,8 +402,9 @@ class FusedPCGNN:
             with torch.cuda.graph(gr):
                 fn()
             graphs.append(gr)
-        for dst, src in zip((self.theta, self.m, self.v, self.step_counter), state):
+        for dst, src in zip((self.theta, self.m, self.v, self.step_counter, self.clf_next), state):
             dst.copy_(src)
+        self._fresh = False                          # (s0 holds the warm-up's scores)
         self._prof = prof
         return graphs
 
@@ -353,16 +415,16 @@ class FusedPCGNN:
         agg = self.agg.view(-1)[:g.R * B * g.feat_dim].view(g.R, B, g.feat_dim)
         plan = self._plan_slot(B).data_ptr()
 
-        def pre():
+        def pre():                     # (a step on its own: nothing is known about the batch before or after it)
             self._enqueue_plan_one(ids, lab, B, True)
-            self._enqueue_scores_train(self._touch_one.data_ptr() if self.touched_on else None)
+            self._enqueue_refresh(self._touch_one.data_ptr() if self.touched_on else None)
 
         def post():
             self._enqueue_tail(ids, lab, B, agg, plan, True)
             self.flush()
 
         def choose():
-            self._enqueue_choose(ids, lab, B, keys, True, plan, sort_in_kernel=True)
+            self._enqueue_choose_train(ids, lab, B, plan, False)
 
         def full():
             pre()
@@ -426,6 +488,7 @@ class FusedPCGNN:
         self._enqueue_plan(st["ids"], st["lab"], self._ep_n, self._ep_bs, st["plans"], self._ep_stride, True, bump_counter)
         if self.touched_on:
             self._enqueue_mark(st["ids"], self._ep_n, self._ep_bs, st["touched"])
+            self._fresh = False                      # (new maps: the rows scored so far need not cover the new first batch)
 
     def _ep_plan(self, b: int, which: Optional[int] = None) -> int:
         return self._ep_sets[self._cur if which is None else which]["plans"].data_ptr() + b * self._ep_stride
@@ -434,6 +497,12 @@ class FusedPCGNN:
         if not self.touched_on:
             return None
         return self._ep_sets[self._cur if which is None else which]["touched"].data_ptr() + b * self._touch_stride
+
+    def _ep_next_touch(self, b: int, which: Optional[int] = None) -> Optional[int]:
+        """the map of the batch after b, if the staged epoch has one"""
+        if not self.touched_on or (b + 1) * self._ep_bs >= self._ep_n:
+            return None
+        return self._ep_touch(b + 1, which)
 
     def begin_epoch(self, ids: torch.Tensor, labels: torch.Tensor, batch_size: int):
         """Stage an epoch's (already shuffled) ids and labels and plan its batches; afterwards ``epoch_step(b)`` is exactly
@@ -459,9 +528,13 @@ class FusedPCGNN:
         gr = self._ep_graphs.get(key)
         if gr is None:
             ids, lab = self._ep_ids[lo:lo + B], self._ep_lab[lo:lo + B]
-            gr = self._capture_graphs([lambda: self.train_step(ids, lab, defer=defer, plan=self._ep_plan(b), touched=self._ep_touch(b))])[0]
+            gr = self._capture_graphs([lambda: self.train_step(ids, lab, defer=defer, plan=self._ep_plan(b), touched=self._ep_touch(b),
+                                                               next_touched=self._ep_next_touch(b))])[0]
             self._ep_graphs[key] = gr
+        if not self._fresh:                          # (the graph was captured with the scores at hand, or scores them itself)
+            self._enqueue_refresh(self._ep_touch(b))
         gr.replay()
+        self._fresh = (not self.touched_on) or self._ep_next_touch(b) is not None
 
     def epoch_step_timed(self, b: int, eager: bool = True):
         """Batch b of the staged epoch with HIP events around the select + gather call (appended to ``_prof``): the same
@@ -482,30 +555,32 @@ class FusedPCGNN:
         agg = self.agg.view(-1)[:g.R * B * g.feat_dim].view(g.R, B, g.feat_dim)
         keys = self.keys if g.n_pos else None
         last = lo + B >= self._ep_n               # the epoch's last batch: nothing follows that would apply the deferred update
-        touched = self._ep_touch(b)
+        touched, nxt = self._ep_touch(b), self._ep_next_touch(b)
+        score_next = (not self.touched_on) or nxt is not None
+        if not self._fresh:
+            self._enqueue_refresh(touched)
         if eager:
-            self._enqueue_scores_train(touched)
-            self._enqueue_choose(ids, lab, B, keys, True, plan, sort_in_kernel=True)     # (records the two events itself)
+            self._enqueue_choose_train(ids, lab, B, plan, score_next, nxt)           # (records the two events itself)
             self._enqueue_tail(ids, lab, B, agg, plan, True)
             if last:
                 self.flush()
             self.last_counts = self.cnt.view(-1)[:g.R * B].view(g.R, B)
             return
         if grs is None:
-            parts = (lambda: self._enqueue_scores_train(touched),
-                     lambda: self._enqueue_choose(ids, lab, B, keys, True, plan, sort_in_kernel=True),
+            parts = (lambda: self._enqueue_choose_train(ids, lab, B, plan, score_next, nxt),
                      lambda: (self._enqueue_tail(ids, lab, B, agg, plan, True), self.flush() if last else None))
-            grs = self._capture_graphs(list(parts))
+            grs = self._capture_graphs(list(parts), warm=[lambda: (self._enqueue_refresh(touched), parts[0](), parts[1]())])
             self._ep_graphs[key] = grs
-        grs[0].replay()
+            self._enqueue_refresh(touched)
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-        grs[1].replay()
+        grs[0].replay()
         ev[1].record()
         if self._prof is not None:
             self._prof.append(ev)
         self.last_counts = self.cnt.view(-1)[:g.R * B].view(g.R, B)
-        grs[2].replay()
+        grs[1].replay()
+        self._fresh = score_next
 
     def epoch_run(self, n_steps: Optional[int] = None, sample=None, bump_counter: Optional[torch.Tensor] = None,
                   flush: bool = True, prefetch: bool = False):
@@ -535,7 +610,7 @@ class FusedPCGNN:
                     lo = b * self._ep_bs
                     B = min(self._ep_bs, n - lo)
                     self.train_step(st["ids"][lo:lo + B], st["lab"][lo:lo + B], defer=True, plan=self._ep_plan(b, cur),
-                                    touched=self._ep_touch(b, cur))
+                                    touched=self._ep_touch(b, cur), next_touched=self._ep_next_touch(b, cur))
                 if flush:
                     self.flush()
             def warm_run():                      # (the warm-up leaves the staged ids - and the epoch counter - as they are)
@@ -562,7 +637,12 @@ class FusedPCGNN:
             gr = self._capture_graphs([sampled_run], warm=[warm_run])[0]
             self._ep_graphs[key] = gr
         self._lastB = min(self._ep_bs, n - (n_steps - 1) * self._ep_bs)
+        # (whole-table engine: the graph was captured with the scores at hand - it holds no score launch of its own; a
+        #  touched-rows engine's graph scores its first batch's rows itself, behind its sampler and maps)
+        if not self.touched_on and not self._fresh:
+            self._enqueue_refresh()
         gr.replay()
+        self._fresh = not self.touched_on
         if prefetch:
             self._cur, self._cur_ready = cur ^ 1, True
         else:

@@ -13,8 +13,13 @@ import os
 import sys
 from collections import defaultdict
 
-CALL_KERNELS = ("select_rows", "gather_chunks", "combine_rows")      # the launches of the select + aggregate call (the training engine's pcg_choose_gather_planned has no combine_rows: its sums are finished in the dense kernel)
-WIDE_READERS = ("gather_chunks",)                                     # 16 B per lane: FETCH_SIZE x 2
+# the launches of the select + aggregate call.  The training engine's pcg_choose_gather_train = select_rows (+ the label classifier's
+# step) and gather_train_kernel (gather + the deferred Adam update + the next step's score pass); no combine_rows (the dense kernel
+# finishes multi-chunk sums).  gather_chunks / combine_rows: the calls without the training riders.
+CALL_KERNELS = ("select_rows", "gather_train_kernel", "gather_chunks", "combine_rows")
+# 16 B per lane: FETCH_SIZE x 2.  (gather_train_kernel's Adam workgroups read the gradient slabs 4 B per lane - at most
+# n_tiles x n_params x 4 B per launch, 6.9 MB on the YelpChi-like batch: doubled with the rest, so that entry is an upper bound)
+WIDE_READERS = ("gather_train_kernel", "gather_chunks")
 
 
 def per_kernel(path, counter):
@@ -54,7 +59,7 @@ def main():
         data = {}
     data[workload] = {"choose_agg_bytes_per_launch": total, "commit": os.environ.get("PCG_COMMIT", "unknown"), "detail": detail,
                       "correction": "gfx950: FETCH_SIZE reads 1/2 of 16-B/lane coalesced reads (MI355X_MICROARCH.md, HBM) -> "
-                                    "gather_chunks (float4 per lane) doubled; 4-B/lane kernels uncorrected",
+                                    "gather_train_kernel / gather_chunks (float4 per lane) doubled - an upper bound for the former, whose Adam riders read 4 B per lane; 4-B/lane kernels uncorrected",
                       "note": "mean over the run's dispatches of every kernel of the call; counters in KB"}
     json.dump(data, open(out, "w"), indent=1)
     print(json.dumps(data[workload], indent=1))

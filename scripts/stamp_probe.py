@@ -17,7 +17,7 @@ ids_all = tr.start_epoch(0)
 ids = ids_all[:B].contiguous(); lab = tr.labels_i32[ids.long()]
 rows = g.R * B
 in_select = os.environ.get("PROBE_SORT", "select") == "select"
-stamps = torch.zeros(rows + 1, 8, dtype=torch.int64, device="cuda")
+stamps = torch.zeros(rows + 2, 8, dtype=torch.int64, device="cuda")
 plan = fz._enqueue_plan_one(ids, lab, B, True)
 torch.cuda.synchronize()
 lib.pcg_debug_set_stamps(C.c_void_p(stamps.data_ptr()))
@@ -28,10 +28,12 @@ pl = stamps[rows].cpu().numpy().astype(np.float64) * 0.01
 print("plan (last workgroup of the batch, us): own rows + totals published %.2f, predecessors' totals %.2f, writes %.2f" % (pl[1] - pl[0], pl[2] - pl[1], pl[3] - pl[2]))
 stamps.zero_()
 for it in range(3):
-    keys = fz._enqueue_scores_train() if in_select else fz._enqueue_scores(True)
+    if in_select: fz._enqueue_refresh()
+    else: keys = fz._enqueue_scores(True)
     torch.cuda.synchronize()
     if it == 2: lib.pcg_debug_set_stamps(C.c_void_p(stamps.data_ptr()))
-    agg, _ = fz._enqueue_choose(ids, lab, B, keys, True, plan, sort_in_kernel=in_select)
+    if in_select: agg, _ = fz._enqueue_choose_train(ids, lab, B, plan, True)        # (select + the classifier's step | gather + the rest)
+    else: agg, _ = fz._enqueue_choose(ids, lab, B, keys, True, plan, sort_in_kernel=False)
     torch.cuda.synchronize()
 lib.pcg_debug_set_stamps(None)
 extra = stamps[rows].cpu().numpy().astype(np.float64) * 0.01
@@ -47,6 +49,10 @@ t0 = st[ran, 0].min()
 print("sort:", "inside select_rows" if in_select else "separate launch", "| rows with stamps", int(ran.sum()), "of", rows)
 if in_select:
     print("   sort workgroup 0 started at %.2f, the LAST key group was published at %.2f us (after the first row start)" % tuple(extra[4:6] - t0))
+if in_select and extra[3] > 0:
+    print("   the label classifier's step (one workgroup): from %.2f to %.2f us" % tuple(extra[2:4] - t0))
+    ph = stamps[rows + 1].cpu().numpy().astype(np.float64) * 0.01
+    print("      classifier, state, ids staged at %.2f | rows done %.2f | partials in LDS %.2f" % tuple(ph[0:3] - t0))
 wt = st[:, 7][ran & pos & (st[:, 7] > 0)] - t0
 if wt.size:
     w3 = (st[:, 7] - st[:, 3])[ran & pos & (st[:, 7] > 0)]
