@@ -142,6 +142,12 @@ struct ClfStep {
     const int32_t *step_counter;
     float scale;               // lambda_1 / global batch size: what a row's d loss / d logit is multiplied by
     AdamHyper h;
+    // a batch of more than 1024 rows is shared by n_wg workgroups (a slice of rows each): every one leaves its gradient in
+    // part[w * part_stride ..] (write-through), the one whose ticket is the last adds them up in workgroup order and applies Adam
+    int32_t n_wg;
+    float *part;
+    int64_t part_stride;
+    uint32_t *ticket;          // device word, zero between launches
 };
 
 struct ChooseArgs {

@@ -1016,6 +1016,12 @@ int pcg_choose_gather_train(const pcg_graph_desc *g, const int32_t *nodes, const
     a.clf.step_counter = step_counter;
     a.clf.scale = inv_count * lambda_1;
     a.clf.h = h;
+    // (a slice of <= 1024 rows per workgroup, at most 8 of them; their gradients meet in the first slabs' classifier entries -
+    //  free until this step's dense launch writes them -, the arrival ticket is the dense kernel's unused one)
+    a.clf.n_wg = (B + 1023) / 1024 > 8 ? 8 : (B + 1023) / 1024;
+    a.clf.part = const_cast<float *>(slabs) + o_clf;
+    a.clf.part_stride = n_params;
+    a.clf.ticket = sync_words;
     hipStream_t st = static_cast<hipStream_t>(stream);
     rc = pcg::launch_select(a, st, true);
     if (rc != PCG_OK) return rc;

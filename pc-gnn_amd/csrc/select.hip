@@ -1063,16 +1063,18 @@ __device__ __forceinline__ void sort_share(const ChooseArgs &a, int w, uint64_t 
 // Geometry as in the score pass: lanes_per_row lanes share a feature row, each its float4 chunk(s); row slots x waves x
 // iterations add up in registers, then slots (butterfly), then waves (LDS, wave order).  lds: (SEL_NW + 1) * (2F + 2) floats.
 // ---------------------------------------------------------------------------------------------------------------------
-// (not inlined, and handed its few arguments by value: a reference to the kernel's argument block would be a stack copy of it)
+// (handed its few arguments by value: a reference to the kernel's argument block would be a stack copy of it.  Inlined: as a
+// function of its own - callee-saved registers, arguments on the stack - it ran twice as long)
 // K: float4 chunks of a row per lane (2 only for rows of more than 256 floats), U: rows in flight per lane.  Everything the
 // step reads that depends on nothing else (the classifier, its Adam state, the step count, the batch's ids and labels) is
 // requested up front; the ids and labels are staged in LDS a block of rows at a time, so that the feature rows of half a batch
 // of 1024 are one memory round trip; every (wave, row slot) leaves its partial gradient in LDS and 2F + 2 threads add them up in
 // (wave, slot) order - no cross-lane traffic.  lds: NC4 + SEL_NW * rpw * NC4 + 2 * RB words (NC4 = 2F + 2 rounded up to 4).
 template <int K, int U>
-__device__ __noinline__ void clf_step_body(const ClfStep c, const float *__restrict__ X, int F, int stride,
+__device__ __forceinline__ void clf_step_body(const ClfStep c, const float *__restrict__ X, int F, int stride,
                                            const int32_t *__restrict__ nodes, const int32_t *__restrict__ labels, int B,
-                                           uint32_t *lds_u, int tid, unsigned long long *st) {
+                                           uint32_t *lds_u, int tid, unsigned long long *st, int cw) {
+    // nodes / labels / B: THIS workgroup's slice of the batch (workgroup cw of c.n_wg)
     typedef float f4 __attribute__((ext_vector_type(4)));
     constexpr int NT = SEL_NW * PCG_WAVE;
     const int NC = 2 * F + 2, NC4 = (NC + 3) & ~3;
@@ -1083,14 +1085,14 @@ __device__ __noinline__ void clf_step_body(const ClfStep c, const float *__restr
     float *red = wl + NC4;                                      // [n_part][NC4]
     int *idl = reinterpret_cast<int *>(red + n_part * NC4);     // [RB] a block of the batch's ids, [RB] its labels
     int RB = ((WG_KEYCAP - (n_part + 1) * NC4) / 2) & ~(PCG_WAVE - 1);          // (>= 2048: feat_stride <= 512, host-checked)
-    RB = RB < 6 * NT ? RB : 6 * NT;
+    RB = RB < 2 * NT ? RB : 2 * NT;                             // (a workgroup's slice is <= 1024 rows up to batches of 8192)
     int *yl = idl + RB;
     // this thread's parameter (threads < NC; a loop covers NC > NT), its Adam state, the step count: requested now
     const bool mine = tid < NC;
     const int ic = mine ? tid : 0;
     const float p_old = c.clf_next[ic], m_old = c.m[ic], v_old = c.v[ic];
     const float t = (float)(c.step_counter[0] + 1);             // this step's dense launch counts it; it has not run yet
-    constexpr int NPRE = 6;                                     // ids / labels per thread of a block: RB <= NPRE * NT
+    constexpr int NPRE = 2;                                     // ids / labels per thread of a block: RB <= NPRE * NT
     int nb = B < RB ? B : RB;
     int id_pre[NPRE], y_pre[NPRE];
 #pragma unroll
@@ -1102,7 +1104,7 @@ __device__ __noinline__ void clf_step_body(const ClfStep c, const float *__restr
     for (int i = tid; i < NC; i += NT) {
         const float w = i == tid ? p_old : c.clf_next[i];
         wl[i] = w;
-        c.theta_clf[i] = w;                                     // what this step's dense kernel computes the loss term with
+        if (cw == 0) c.theta_clf[i] = w;                        // what this step's dense kernel computes the loss term with
     }
 #pragma unroll
     for (int q = 0; q < NPRE; ++q) {
@@ -1112,7 +1114,6 @@ __device__ __noinline__ void clf_step_body(const ClfStep c, const float *__restr
             yl[i] = y_pre[q];
         }
     }
-    const float bc1 = 1.f - powf(c.h.beta1, t), bc2 = 1.f - powf(c.h.beta2, t);   // (behind the loads, ahead of the rows)
     __syncthreads();
     if (st && tid == 0) st[0] = wall_clock64();
     bool has[K];
@@ -1208,9 +1209,40 @@ __device__ __noinline__ void clf_step_body(const ClfStep c, const float *__restr
     }
     __syncthreads();
     if (st && tid == 0) st[2] = wall_clock64();
+    if (c.n_wg > 1) {
+        // this workgroup's gradient -> its slot (write-through: another workgroup of this launch reads it), then the ticket
+        float *slot_out = c.part + (size_t)cw * c.part_stride;
+        for (int i = tid; i < NC; i += NT) {
+            float g = red[i];
+            for (int w = 1; w < n_part; ++w) g += red[w * NC4 + i];
+            __hip_atomic_store(slot_out + i, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                         // every thread's stores are complete
+        int *flag = reinterpret_cast<int *>(red);                // (the partial sums have been read)
+        if (tid == 0) flag[0] = __hip_atomic_fetch_add(c.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)c.n_wg - 1u;
+        __syncthreads();
+        const bool last = flag[0] != 0;
+        __syncthreads();                                         // (red is written again below)
+        if (!last) return;
+        // the last one in: all gradients, in workgroup order (loads past the L1: agent scope; all of a parameter's in flight)
+        for (int i = tid; i < NC; i += NT) {
+            float x[8];
+#pragma unroll
+            for (int w = 0; w < 8; ++w)
+                x[w] = __hip_atomic_load(c.part + (size_t)(w < c.n_wg ? w : c.n_wg - 1) * c.part_stride + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            float g = x[0];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) g = w < c.n_wg ? g + x[w] : g;
+            red[i] = g;
+        }
+        if (tid == 0) __hip_atomic_store(c.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const float bc1 = 1.f - powf(c.h.beta1, t), bc2 = 1.f - powf(c.h.beta2, t);
     for (int i = tid; i < NC; i += NT) {
         float g = red[i];
-        for (int w = 1; w < n_part; ++w) g += red[w * NC4 + i];
+        if (c.n_wg == 1)
+            for (int w = 1; w < n_part; ++w) g += red[w * NC4 + i];
         const bool first = i == tid;                             // (its state came with the first loads)
         const float p = first ? p_old : wl[i];
         const float mo = first ? m_old : c.m[i], vo = first ? v_old : c.v[i];
@@ -1245,7 +1277,7 @@ __global__ void __launch_bounds__(SEL_NW *PCG_WAVE) __attribute__((amdgpu_waves_
     // single-wave items per unit: eight (one per wave) when there is plenty of them, fewer when the batch is so small that
     // the items can be spread over more workgroups (more CUs' load paths) than eight per workgroup would use
     // (training: workgroup 0 does the label classifier's step and nothing else; the row workgroups are the others)
-    const int clf_wg = a.clf.clf_next ? 1 : 0;
+    const int clf_wg = a.clf.clf_next ? a.clf.n_wg : 0;
     const int grid = (int)gridDim.x - clf_wg, bid = (int)blockIdx.x - clf_wg;
     const int avail = grid - n_wg > grid / 4 ? grid - n_wg : grid / 4;
     int bs = (n_items + avail - 1) / avail;
@@ -1261,8 +1293,13 @@ __global__ void __launch_bounds__(SEL_NW *PCG_WAVE) __attribute__((amdgpu_waves_
         // (one workgroup, as long as the launch's longest rows, sharing its CU with two workgroups of rows: it goes first)
         __builtin_amdgcn_s_setprio(3);
         if (a.stamps && leader) a.stamps[(size_t)a.g.n_rel * a.B * 8 + 2] = wall_clock64();
-        if (a.g.feat_stride > 256) clf_step_body<2, 2>(a.clf, a.g.X, a.g.feat_dim, a.g.feat_stride, a.nodes, a.labels, a.B, lds, (int)threadIdx.x, a.stamps ? a.stamps + (size_t)a.g.n_rel * a.B * 8 + 8 : nullptr);
-        else clf_step_body<1, 4>(a.clf, a.g.X, a.g.feat_dim, a.g.feat_stride, a.nodes, a.labels, a.B, lds, (int)threadIdx.x, a.stamps ? a.stamps + (size_t)a.g.n_rel * a.B * 8 + 8 : nullptr);
+        // this workgroup's slice of the batch: whole multiples of 64 rows (every workgroup has some: n_wg <= ceil(B / 1024))
+        const int cw = (int)blockIdx.x;
+        const int per = ((a.B + a.clf.n_wg - 1) / a.clf.n_wg + PCG_WAVE - 1) & ~(PCG_WAVE - 1);
+        const int r0 = cw * per < a.B ? cw * per : a.B, r1 = r0 + per < a.B ? r0 + per : a.B;
+        unsigned long long *cst = (a.stamps && cw == 0) ? a.stamps + (size_t)a.g.n_rel * a.B * 8 + 8 : nullptr;
+        if (a.g.feat_stride > 256) clf_step_body<2, 2>(a.clf, a.g.X, a.g.feat_dim, a.g.feat_stride, a.nodes + r0, a.labels + r0, r1 - r0, lds, (int)threadIdx.x, cst, cw);
+        else clf_step_body<1, 4>(a.clf, a.g.X, a.g.feat_dim, a.g.feat_stride, a.nodes + r0, a.labels + r0, r1 - r0, lds, (int)threadIdx.x, cst, cw);
         if (a.stamps && leader) a.stamps[(size_t)a.g.n_rel * a.B * 8 + 3] = wall_clock64();
         return;
     }
@@ -1394,7 +1431,7 @@ int launch_select_rows(const ChooseArgs &a, hipStream_t st) {
         blocks = (v >= SEL_SHARDS && v <= SEL_BLOCKS && v % SEL_SHARDS == 0) ? v : SEL_BLOCKS;
     }
     ChooseArgs as = a;
-    const int row_blocks = blocks - (a.clf.clf_next ? 1 : 0);      // (training: one of the workgroups steps the label classifier)
+    const int row_blocks = blocks - (a.clf.clf_next ? a.clf.n_wg : 0);      // (training: one of the workgroups steps the label classifier)
     if (a.n_sort > 0) {                      // how the sort is shared: slices per key group, keys per slice (>= 128)
         if (a.n_sort > row_blocks) return PCG_E_ARG;
         // (PCG_SORT_SLICES: tuning knob.  More slices = fewer compares per workgroup, but accumulator atomics and a ticket hop,

@@ -479,6 +479,39 @@ def fused_of(P, c, rho, **kw):
     return m, FusedPCGNN(m, c.lr, c.wd, max_batch=len(c.nodes), **kw)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [1024, 1500, 4096, 9000])
+def test_label_classifier_step_of_its_own(P, case, B):
+    """The label classifier is stepped by the select launch (one workgroup per <= 1024 rows of the batch, the gradients of
+    several summed by the last one in): after two steps - batches with repeated centres - its parameters and Adam state
+    track torch autograd + torch.optim.Adam; the other parameters too (their update is the deferred one)."""
+    c = case
+    rho = c.rhos[0]
+    rs = np.random.RandomState(B)
+    nodes = rs.randint(0, len(c.labels), size=B)
+    ids = torch.from_numpy(nodes.astype(np.int32)).cuda()
+    lab = torch.from_numpy(c.labels[nodes].astype(np.int32)).cuda()
+    m1, f1 = fused_of(P, c, rho)
+    m3 = build_model(P, c, rho, graph=graph_of(P, c))
+    opt = torch.optim.Adam([p for p in m3.parameters() if p.requires_grad], lr=c.lr, weight_decay=c.wd)
+    for step in range(2):
+        sl = slice(0, None) if step == 0 else slice(B // 3, None)
+        f1.train_step(ids[sl], lab[sl], defer=True)
+        opt.zero_grad()
+        m3.loss(ids[sl], lab[sl].long()).backward()
+        opt.step()
+    f1.flush()
+    torch.cuda.synchronize()
+    f1.check()
+    sd1, sd3 = m1.state_dict(), m3.state_dict()
+    for k in PARAM_KEYS(c.R):
+        a, b = sd1[k].cpu().numpy(), sd3[k].cpu().numpy()
+        # (Adam's first steps move every parameter by ~lr whatever the gradient's size: a wrong gradient sum - a slice of the
+        #  batch missing, say - shows as differences of the order of lr everywhere; rounding differences of the sums do not)
+        np.testing.assert_allclose(a, b, rtol=0, atol=c.lr * 0.25, err_msg=k)
+        assert np.mean(np.abs(a - b)) < c.lr * 5e-3, k
+
+
 def test_fused_forward_grads_adam_golden(P, case):
     c = case
     rho = c.rhos[0]
