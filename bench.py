@@ -73,9 +73,10 @@ def parse():
                     "medians (SURVEY 8d); 0 = skip")
     ap.add_argument("--verify-batches", type=int, default=1, help="batches whose chosen sets are checked after the clock stops "
                     "(count law on every row, the oracle's sets on a strided sample); 0 = skip")
-    ap.add_argument("--prefetch", action="store_true", help="graph engine: sampler + plans of the NEXT epoch on a parallel branch of an "
-                    "epoch's graph (two buffer sets) instead of at the head of its own graph.  A/B switch, off: a forked hipGraph "
-                    "costs more per replay (~45 us) than the three launches it hides (~23 us per epoch): 62.2 vs 58.1 us/step")
+    ap.add_argument("--prefetch", nargs="?", const="graph", default="off", choices=["off", "graph", "stream"],
+                    help="graph engine: sampler + plans of the NEXT epoch beside an epoch's steps: `graph` = on a parallel branch of "
+                         "the epoch's graph, `stream` = enqueued by the host on a second stream (two events per epoch); off = in "
+                         "front of the epoch's steps, inside its graph")
     ap.add_argument("--engine", default=None, choices=["graph", "fused", "torch", "dp"],
                     help="graph: fused HIP step replayed from a hipGraph (default at 1 GPU); fused: same kernels "
                          "launched eagerly (default at N>1, gradient all-reduce in between); torch: torch dense tail")
@@ -462,6 +463,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    PREFETCH = {"off": False, "graph": True, "stream": "stream"}[args.prefetch]
     warmup = args.warmup
     if epoch_graphs:                       # capture every graph (per-slot and whole-epoch) untimed
         warmup = max(warmup, 2 * nb + 2)
@@ -488,7 +490,7 @@ def main():
             first_timed = 2 if n_steps >= 2 * nb else 1
             timed_epoch = engine != "graph" or (phase["epochs"] - first_timed) % args.event_every == 0
             if epoch_graphs and at_epoch_start and not timed_epoch and k + nb <= n_steps:
-                tr.run_epoch_one_graph(flush=False, prefetch=args.prefetch)  # pick + shuffle + labels + plans + every batch's step: one graph launch (the
+                tr.run_epoch_one_graph(flush=False, prefetch=PREFETCH)  # pick + shuffle + labels + plans + every batch's step: one graph launch (the
                                                      # last batch's deferred Adam update is applied by the next front launch, or
                                                      # by the flush that ends the timed region)
                 state["ids"], state["b"] = tr.fused._ep_ids[:tr.pick_size], nb
@@ -515,7 +517,7 @@ def main():
         # 0 / 1; with the next epoch's sampler on a parallel branch: sampling its own epoch first or finding it prepared) and the
         # per-batch graphs of both buffer sets
         def whole():
-            tr.run_epoch_one_graph(flush=False, prefetch=args.prefetch)
+            tr.run_epoch_one_graph(flush=False, prefetch=PREFETCH)
             state["epoch"] += 1
             return nb
 
@@ -525,7 +527,7 @@ def main():
                 tr.fused.epoch_step(b, defer=True)
             state["epoch"] += 1
             return nb
-        seq = (whole, whole, batchwise, whole, batchwise, whole, whole) if args.prefetch else (whole, batchwise)
+        seq = (whole, whole, batchwise, whole, batchwise, whole, whole) if PREFETCH else (whole, batchwise)
         warmup = sum(f() for f in seq)
         state["ids"], state["b"] = None, 0
         run_steps(2 * nb + 2, False)           # ... and one pass through the timed region's own sequence (bracketed epoch included)

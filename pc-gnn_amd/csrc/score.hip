@@ -58,7 +58,8 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const float *__restric
 
 // ---- which rows a batch's selection can read: a byte map per batch, built once per epoch (it depends on the picked ids and the
 // CSR rows only, like the plan): the centres and every neighbour they have in any relation
-__global__ void __launch_bounds__(256) zero_bytes_kernel(uint4 *__restrict__ p, int64_t n16) {
+__global__ void __launch_bounds__(256) zero_bytes_kernel(uint4 *__restrict__ p, int64_t n16, uint32_t *__restrict__ queue) {
+    if (queue && blockIdx.x == 0 && threadIdx.x == 0) queue[0] = 0u;        // (mark_touched_kernel's queue of long rows)
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) p[i] = make_uint4(0u, 0u, 0u, 0u);
 }
@@ -71,7 +72,12 @@ struct MarkArgs {
     int64_t map_stride, n_nodes;
     const int32_t *train_pos;          // their scores are read too: by the train-pos sort when there are too many of them for the
     int32_t n_pos;                     // front launch to form the keys from the feature rows (pcg_pos_sort reads s0[train_pos])
+    uint32_t *queue;                   // [4 + n_rel * n_total]: [0] = how many rows of more than MARK_LONG neighbours, [4 ..] = their items
 };
+// A row of a hub - a power-law graph has centres with 10^5 .. 10^6 neighbours - is not one wave's work (256 ids per round trip:
+// the longest row set the kernel's duration, 1.6 ms per epoch at 10 M nodes / 200 M edges): such rows are queued by the item pass
+// and marked by the whole grid in a pass of their own (mark_long_kernel).
+constexpr int MARK_LONG = 4096;
 __global__ void __launch_bounds__(256) mark_touched_kernel(const MarkArgs a) {
     const int lane = lane_id();
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
@@ -99,6 +105,10 @@ __global__ void __launch_bounds__(256) mark_touched_kernel(const MarkArgs a) {
         if (r == 0 && lane == 0) map[node] = 1;                              // the centre's own score is read too
         const int64_t beg = a.indptr[r][node], end = a.indptr[r][node + 1];
         const int32_t *__restrict__ nbr = a.indices[r];
+        if (a.queue && end - beg > MARK_LONG) {                             // (wave-uniform) the whole grid's work: mark_long_kernel
+            if (lane == 0) a.queue[4 + atomicAdd(a.queue, 1u)] = (uint32_t)it;
+            continue;
+        }
         constexpr int CU = 4;                                               // four loads of 64 ids in flight (unconditional: clamped)
         for (int64_t j0 = beg; j0 < end; j0 += CU * PCG_WAVE) {
             int32_t idv[CU];
@@ -113,6 +123,73 @@ __global__ void __launch_bounds__(256) mark_touched_kernel(const MarkArgs a) {
                 if (j < end && (uint32_t)idv[u] < (uint64_t)a.n_nodes) map[idv[u]] = 1;
             }
         }
+    }
+}
+
+// the queued rows: every workgroup learns where they are (a batch of 256 at a time, one per thread, in LDS), then the grid's
+// waves share every row's neighbours, 256 per wave and turn
+__global__ void __launch_bounds__(256) mark_long_kernel(const MarkArgs a) {
+    __shared__ long long s_beg[256], s_end[256], s_map[256];
+    __shared__ int s_rel[256];
+    __shared__ long long s_pre[256];                                        // pieces of the rows up to and including this one
+    const int lane = lane_id();
+    const unsigned n = a.queue[0];
+    const int64_t per_slot = (int64_t)a.n_rel * a.B;
+    const int64_t wave_g = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    constexpr int CU = 4, PIECE = CU * PCG_WAVE;                            // a piece: 256 neighbour ids, four loads of 64 in flight
+    for (unsigned e0 = 0; e0 < n; e0 += 256) {
+        const unsigned e = e0 + threadIdx.x;
+        long long beg = 0, end = 0;
+        if (e < n) {
+            const int64_t it = (int64_t)a.queue[4 + e];
+            const int slot = (int)(it / per_slot);
+            const int rem = (int)(it - (int64_t)slot * per_slot);
+            const int r = rem / a.B;
+            const int i = slot * a.B + (rem - r * a.B);
+            const int32_t node = a.nodes[i];
+            beg = a.indptr[r][node];
+            end = a.indptr[r][node + 1];
+            s_map[threadIdx.x] = (long long)slot * a.map_stride;
+            s_rel[threadIdx.x] = r;
+        }
+        s_beg[threadIdx.x] = beg;
+        s_end[threadIdx.x] = end;
+        s_pre[threadIdx.x] = (end - beg + PIECE - 1) / PIECE;
+        __syncthreads();
+        if (threadIdx.x == 0)                                               // (256 adds: nothing beside the marking itself)
+            for (int q = 1; q < 256; ++q) s_pre[q] += s_pre[q - 1];
+        __syncthreads();
+        // the batch's pieces, all rows together, dealt out over the grid's waves: a wave finds its piece's row by bisection
+        const long long total = s_pre[255];
+        for (long long p = wave_g; p < total; p += n_waves) {
+            int lo = 0, hi = 255;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (s_pre[mid] > p) hi = mid;
+                else lo = mid + 1;
+            }
+            const int q = lo;
+            const long long c = p - (q > 0 ? s_pre[q - 1] : 0);
+            const int64_t endq = s_end[q], j0 = s_beg[q] + c * PIECE;
+            const int r = s_rel[q];
+            unsigned char *__restrict__ map = a.maps + s_map[q];
+            int32_t idv[CU];
+#pragma unroll
+            for (int u = 0; u < CU; ++u) {
+                const int64_t j = j0 + u * PCG_WAVE + lane;
+                const int64_t jc = j < endq ? j : endq - 1;
+                int32_t v = 0;
+                for (int rr = 0; rr < PCG_MAX_REL; ++rr)                    // (a kernel-argument array: indexed by a constant)
+                    if (rr == r) v = a.indices[rr][jc];
+                idv[u] = v;
+            }
+#pragma unroll
+            for (int u = 0; u < CU; ++u) {
+                const int64_t j = j0 + u * PCG_WAVE + lane;
+                if (j < endq && (uint32_t)idv[u] < (uint64_t)a.n_nodes) map[idv[u]] = 1;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -144,8 +221,9 @@ int64_t pcg_touched_bytes(int64_t n_nodes) { return n_nodes < 0 ? PCG_E_ARG : pc
  * (map_stride >= pcg_touched_bytes(n_nodes), a multiple of 16) is zeroed, then map[v] = 1 for every centre v of batch s, every
  * neighbour of v in any relation, and every train positive.  Two launches for all batches (per epoch, like pcg_plan_batches). */
 int pcg_mark_touched(const pcg_graph_desc *g, const int32_t *nodes, int32_t n_total, int32_t B, uint8_t *maps, int64_t map_stride,
-                     void *stream) {
+                     uint32_t *queue, void *stream) {
     if (!g || !nodes || n_total < 0 || B < 1 || !maps || g->n_rel < 1 || g->n_rel > PCG_MAX_REL) return PCG_E_ARG;
+    if (!queue && g->max_degree > pcg::MARK_LONG) return PCG_E_ARG;
     if (map_stride < pcg::touched_bytes(g->n_nodes) || (map_stride & 15) != 0 || (reinterpret_cast<uintptr_t>(maps) & 15u) != 0)
         return PCG_E_ARG;
     if (n_total == 0) return PCG_OK;
@@ -165,16 +243,21 @@ int pcg_mark_touched(const pcg_graph_desc *g, const int32_t *nodes, int32_t n_to
     a.n_nodes = g->n_nodes;
     a.train_pos = g->train_pos;
     a.n_pos = g->train_pos ? g->n_pos : 0;
+    a.queue = g->max_degree > pcg::MARK_LONG ? queue : nullptr;        // (no such rows in this graph: no queue, no third launch)
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t n16 = (int64_t)n_slots * map_stride / 16;
     int zb = (int)((n16 + 255) / 256);
     zb = zb > 4096 ? 4096 : zb;
-    hipLaunchKernelGGL(pcg::zero_bytes_kernel, dim3(zb), dim3(256), 0, st, reinterpret_cast<uint4 *>(maps), n16);
+    hipLaunchKernelGGL(pcg::zero_bytes_kernel, dim3(zb), dim3(256), 0, st, reinterpret_cast<uint4 *>(maps), n16, a.queue);
     PCG_LAUNCH_CHECK();
     int64_t mb = ((int64_t)g->n_rel * n_total + 3) / 4;
     mb = mb > 2048 ? 2048 : mb;
     hipLaunchKernelGGL(pcg::mark_touched_kernel, dim3((int)mb), dim3(256), 0, st, a);
     PCG_LAUNCH_CHECK();
+    if (a.queue) {
+        hipLaunchKernelGGL(pcg::mark_long_kernel, dim3(2048), dim3(256), 0, st, a);
+        PCG_LAUNCH_CHECK();
+    }
     return PCG_OK;
 }
 

@@ -182,9 +182,15 @@ class FusedPCGNN:
         return slot.data_ptr()
 
     def _enqueue_mark(self, ids, n_total, B, maps: torch.Tensor):
-        """byte maps of the rows each batch's selection can read (two launches for all batches)"""
-        _lib.check(self.lib.pcg_mark_touched(self.g.desc_ref(), _p(ids), n_total, B, _p(maps), self._touch_stride, self._stream()),
-                   "pcg_mark_touched")
+        """byte maps of the rows each batch's selection can read (two launches for all batches, three on graphs with hub rows)"""
+        need = 4 + self.g.R * n_total
+        q = getattr(self, "_mark_queue", None)
+        if q is None or q.numel() < need:
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.PcgnnLibraryError("a larger epoch's touched-row maps inside a graph capture: warm up before capturing")
+            q = self._mark_queue = torch.zeros(need, dtype=torch.int32, device=self.dev)
+        _lib.check(self.lib.pcg_mark_touched(self.g.desc_ref(), _p(ids), n_total, B, _p(maps), self._touch_stride, _p(q),
+                                             self._stream()), "pcg_mark_touched")
 
     def _enqueue_scores(self, train_flag):
         """label-aware score table + per-step sort of the train positives (the calls of their own: evaluation, parity)."""
@@ -479,6 +485,9 @@ class FusedPCGNN:
         """True if the current set already holds a sampled and planned epoch that no step has used yet (left by
         ``epoch_run(prefetch=True)``) - the caller then starts on it instead of sampling; the set counts as used from here on."""
         ready, self._cur_ready = self._cur_ready, False
+        if ready and getattr(self, "_ev_ready", None) is not None:       # (prepared on the side stream: epoch_run(prefetch="stream"))
+            torch.cuda.current_stream(self.dev).wait_event(self._ev_ready)
+            self._ev_ready = None
         return ready
 
     def plan_staged(self, bump_counter: Optional[torch.Tensor] = None, which: Optional[int] = None):
@@ -592,15 +601,19 @@ class FusedPCGNN:
         next - the next epoch's first front launch applies it, any other public call flushes it first.
         prefetch=True (needs ``sample``): the sampler and the plans of the NEXT epoch run on a parallel branch of this epoch's
         graph, into the other buffer set; afterwards that set is the current one and ready (``take_prefetched``).  The first
-        such call - or one after the ready set was used up by other calls - samples its own epoch first."""
+        such call - or one after the ready set was used up by other calls - samples its own epoch first.
+        prefetch="stream": the same division of labour without a fork inside the graph: the sampler and plan launches of the next
+        epoch are enqueued - by the host, behind this epoch's graph launch - on a second stream, where they run beside this
+        epoch's kernels; the only cross-stream waits are two events per epoch (the other buffer set is free / is ready)."""
         nb = -(-self._ep_n // self._ep_bs)
         n_steps = nb if n_steps is None else min(n_steps, nb)
         n = self._ep_n
-        prefetch = prefetch and sample is not None
+        on_stream = prefetch == "stream" and sample is not None
+        prefetch = prefetch is True and sample is not None
         cur = self._cur
-        primed = prefetch and self._cur_ready
+        primed = (prefetch or on_stream) and self._cur_ready
         key = ("epoch", cur, n, self._ep_bs, n_steps, sample is not None, None if bump_counter is None else bump_counter.data_ptr(),
-               flush, prefetch, primed)
+               flush, prefetch, primed, on_stream)
         gr = self._ep_graphs.get(key)
         if gr is None:
             st = self._ep_sets[cur]
@@ -616,7 +629,7 @@ class FusedPCGNN:
             def warm_run():                      # (the warm-up leaves the staged ids - and the epoch counter - as they are)
                 self.plan_staged(which=cur)
                 run()
-                if prefetch:                     # (the other set's plan slots and kernels get their first use outside a capture)
+                if prefetch or on_stream:        # (the other set's plan slots and kernels get their first use outside a capture)
                     self.plan_staged(which=cur ^ 1)
             def sampled_run():
                 if not primed:
@@ -641,9 +654,29 @@ class FusedPCGNN:
         #  touched-rows engine's graph scores its first batch's rows itself, behind its sampler and maps)
         if not self.touched_on and not self._fresh:
             self._enqueue_refresh()
+        main = torch.cuda.current_stream(self.dev)
+        if primed and getattr(self, "_ev_ready", None) is not None:
+            main.wait_event(self._ev_ready)          # the side stream has sampled and planned this set
+            self._ev_ready = None
         gr.replay()
         self._fresh = not self.touched_on
-        if prefetch:
+        if on_stream:
+            # the next epoch's sampler + plans, on the side stream: behind the graph launched BEFORE this one (the last reader of
+            # the other set), beside this one
+            if getattr(self, "_side", None) is None:
+                self._side, self._ev_free = torch.cuda.Stream(self.dev), None
+            nxt = self._ep_sets[cur ^ 1]
+            if self._ev_free is not None:
+                self._side.wait_event(self._ev_free)
+            with torch.cuda.stream(self._side):
+                sample(nxt["ids"][:n], nxt["lab"][:n])
+                self.plan_staged(bump_counter, which=cur ^ 1)
+                self._ev_ready = torch.cuda.Event()
+                self._ev_ready.record(self._side)
+            self._ev_free = torch.cuda.Event()
+            self._ev_free.record(main)               # (this epoch's graph: the last reader of the set it ran on)
+            self._cur, self._cur_ready = cur ^ 1, True
+        elif prefetch:
             self._cur, self._cur_ready = cur ^ 1, True
         else:
             self._cur_ready = False

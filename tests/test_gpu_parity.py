@@ -830,9 +830,10 @@ def test_epoch_as_one_graph_equals_step_by_step(P):
     from pcgnn_amd.handler import PCGNNTrainer
     w = synth.make_workload("mini", 6000, 32, (4000, 30000, 90000), 0.12, seed=3)
     cfg = dict(engine="graph", batch_size=256, seed=5)
-    a, b, c, d, e = (PCGNNTrainer(w, cfg, dev()) for _ in range(5))
-    for t in (b, c, d, e):
+    a, b, c, d, e, f = (PCGNNTrainer(w, cfg, dev()) for _ in range(6))
+    for t in (b, c, d, e, f):
         t.fused.theta.copy_(a.fused.theta)
+        t.fused.params_changed()
     nb = a.batches_per_epoch()
     assert a.pick_size % a.batch_size != 0 and nb >= 3
     for ep in range(3):
@@ -848,6 +849,8 @@ def test_epoch_as_one_graph_equals_step_by_step(P):
                 e.fused.epoch_step(k, defer=True)
         else:
             e.run_epoch_one_graph(flush=False, prefetch=True)
+        # ... or enqueued by the host on a second stream beside this epoch's graph
+        f.run_epoch_one_graph(flush=False, prefetch="stream")
         ids = b.start_epoch_staged()
         for k in range(nb):
             sl = slice(k * b.batch_size, min((k + 1) * b.batch_size, b.pick_size))
@@ -862,9 +865,11 @@ def test_epoch_as_one_graph_equals_step_by_step(P):
                 c.fused.epoch_step(k, defer=True)
     d.fused.flush()
     e.fused.flush()
+    f.fused.flush()
     torch.cuda.synchronize()
     assert int(a._epoch_dev[0]) == int(b._epoch_dev[0]) == int(c._epoch_dev[0]) == int(d._epoch_dev[0]) == 3
     assert int(e._epoch_dev[0]) == 4 and e.fused._cur_ready        # (the fourth epoch is sampled and planned already)
+    assert int(f._epoch_dev[0]) == 4 and f.fused._cur_ready
     assert torch.equal(a.fused._ep_ids[:a.pick_size], b.fused._ep_ids[:b.pick_size])
     assert torch.equal(a.fused._ep_ids[:a.pick_size], c.fused._ep_ids[:c.pick_size])
     for name in ("theta", "m", "v", "step_counter"):
@@ -872,6 +877,7 @@ def test_epoch_as_one_graph_equals_step_by_step(P):
         assert torch.equal(getattr(a.fused, name), getattr(c.fused, name)), name + " (per-batch graphs, deferred Adam)"
         assert torch.equal(getattr(a.fused, name), getattr(d.fused, name)), name + " (epoch graphs without the end-of-epoch flush)"
         assert torch.equal(getattr(a.fused, name), getattr(e.fused, name)), name + " (next epoch's sampler + plans on a parallel branch)"
+        assert torch.equal(getattr(a.fused, name), getattr(f.fused, name)), name + " (next epoch's sampler + plans on a second stream)"
     assert torch.isfinite(a.fused.theta).all() and not torch.equal(a.fused.theta, torch.zeros_like(a.fused.theta))
 
 
@@ -1087,7 +1093,28 @@ def test_touched_rows_only_scoring(P, monkeypatch):
     assert stride >= w.n + 8 and stride % 512 == 0
     maps = torch.full((3 * stride,), 7, dtype=torch.uint8, device=dev())          # (garbage: the call zeroes the maps itself)
     st = ops._stream(dev())
-    _lib.check(lib.pcg_mark_touched(g.desc_ref(), _p(ids), n_total, B, _p(maps), stride, st), "pcg_mark_touched")
+    queue = torch.zeros(4 + 3 * n_total, dtype=torch.int32, device=dev())
+    _lib.check(lib.pcg_mark_touched(g.desc_ref(), _p(ids), n_total, B, _p(maps), stride, _p(queue), st), "pcg_mark_touched")
+    # rows of hubs (> 4096 neighbours) are queued and marked by the whole grid in a launch of their own: the same marks
+    Xh, lab_h, csr_h = hub_graph(11, 30000, (5000, 9000, 20000))
+    gh = P.DeviceGraph(Xh, [csr_h], np.flatnonzero(lab_h == 1)[:50].tolist(), dev())
+    assert gh.max_degree > 4096
+    hub_nodes = np.concatenate([np.argsort(-np.diff(csr_h[0]))[:3], rs.randint(0, 30000, size=61)]).astype(np.int32)
+    stride_h = int(lib.pcg_touched_bytes(30000))
+    maps_h = torch.full((2 * stride_h,), 9, dtype=torch.uint8, device=dev())
+    queue_h = torch.zeros(4 + 64, dtype=torch.int32, device=dev())
+    _lib.check(lib.pcg_mark_touched(gh.desc_ref(), _p(torch.from_numpy(hub_nodes).cuda()), 64, 40, _p(maps_h), stride_h, _p(queue_h), st),
+               "pcg_mark_touched")
+    torch.cuda.synchronize()
+    assert int(queue_h[0]) == 3
+    for s_ in range(2):
+        sl = hub_nodes[s_ * 40:(s_ + 1) * 40]
+        want = np.zeros(stride_h, dtype=np.uint8)
+        want[sl] = 1
+        want[np.flatnonzero(lab_h == 1)[:50]] = 1
+        for v_ in sl:
+            want[csr_h[1][csr_h[0][v_]:csr_h[0][v_ + 1]]] = 1
+        assert np.array_equal(maps_h[s_ * stride_h:(s_ + 1) * stride_h].cpu().numpy(), want), f"hub batch {s_}"
     s0_full = ops.score_table(g, W, b)
     keys = torch.zeros(int(lib.pcg_pos_sort_capacity(g.n_pos)), dtype=torch.int64, device=dev())
     for s_ in range(3):
