@@ -16,6 +16,7 @@ stamp() { for f in "$@"; do [ -f "$f" ] && sed -i "1i # commit $PCG_COMMIT" "$f"
 PL="--workload powerlaw --nodes 2000000 --edges 40000000 --batch-size 4096"
 PL10="--workload powerlaw --nodes 10000000 --edges 200000000 --batch-size 4096"
 if [ "$2" != "big" ]; then
+echo "[collect] smoke"; (cd $R && python3 -c "import __graft_entry__ as g; g.smoke()") > $O/smoke.log 2>&1 || exit 1
 echo "[collect] bench yelp"; python3 $R/bench.py > $O/bench_yelp.log 2>&1 || exit 1
 echo "[collect] bench yelp, as the driver runs it"; python3 $R/bench.py --steps 20 --warmup 5 > $O/bench_yelp_driver_style.log 2>&1 || exit 1
 echo "[collect] kernel trace yelp"; rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_yelp -o y -- python3 $R/bench.py --cpu-batches 0 > $O/trace_yelp.log 2>&1 || exit 1
