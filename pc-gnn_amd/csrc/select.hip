@@ -1257,6 +1257,10 @@ __device__ __forceinline__ void clf_step_body(const ClfStep c, const float *__re
     __syncthreads();                                             // (the LDS is the row paths' again)
 }
 
+// CLF: the launch carries the label classifier's step (training: pcg_choose_gather_train): 1 = feature rows of up to 256 floats
+// (one float4 chunk per lane: the datasets' 128-B rows), 2 = wider rows.  Instantiation 0 holds none of that code - nor the
+// few bytes of scratch it spills under the row paths' register budget -, so every other caller's launch is the row paths' alone.
+template <int CLF>
 __global__ void __launch_bounds__(SEL_NW *PCG_WAVE) __attribute__((amdgpu_waves_per_eu(6, 8))) select_rows(const ChooseArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t *lds = reinterpret_cast<uint32_t *>(smem);
@@ -1277,7 +1281,7 @@ __global__ void __launch_bounds__(SEL_NW *PCG_WAVE) __attribute__((amdgpu_waves_
     // single-wave items per unit: eight (one per wave) when there is plenty of them, fewer when the batch is so small that
     // the items can be spread over more workgroups (more CUs' load paths) than eight per workgroup would use
     // (training: workgroup 0 does the label classifier's step and nothing else; the row workgroups are the others)
-    const int clf_wg = a.clf.clf_next ? a.clf.n_wg : 0;
+    const int clf_wg = (CLF && a.clf.clf_next) ? a.clf.n_wg : 0;
     const int grid = (int)gridDim.x - clf_wg, bid = (int)blockIdx.x - clf_wg;
     const int avail = grid - n_wg > grid / 4 ? grid - n_wg : grid / 4;
     int bs = (n_items + avail - 1) / avail;
@@ -1289,7 +1293,7 @@ __global__ void __launch_bounds__(SEL_NW *PCG_WAVE) __attribute__((amdgpu_waves_
     if (a.pending_clear && bid == 0 && leader) a.pending_clear[0] = 0u;   // the launch before has applied the deferred update
     __syncthreads();
     // the label classifier's step for this batch (training): one workgroup, before its share of the rows
-    if (bid < 0) {
+    if (CLF && bid < 0) {
         // (one workgroup, as long as the launch's longest rows, sharing its CU with two workgroups of rows: it goes first)
         __builtin_amdgcn_s_setprio(3);
         if (a.stamps && leader) a.stamps[(size_t)a.g.n_rel * a.B * 8 + 2] = wall_clock64();
@@ -1298,8 +1302,8 @@ __global__ void __launch_bounds__(SEL_NW *PCG_WAVE) __attribute__((amdgpu_waves_
         const int per = ((a.B + a.clf.n_wg - 1) / a.clf.n_wg + PCG_WAVE - 1) & ~(PCG_WAVE - 1);
         const int r0 = cw * per < a.B ? cw * per : a.B, r1 = r0 + per < a.B ? r0 + per : a.B;
         unsigned long long *cst = (a.stamps && cw == 0) ? a.stamps + (size_t)a.g.n_rel * a.B * 8 + 8 : nullptr;
-        if (a.g.feat_stride > 256) clf_step_body<2, 2>(a.clf, a.g.X, a.g.feat_dim, a.g.feat_stride, a.nodes + r0, a.labels + r0, r1 - r0, lds, (int)threadIdx.x, cst, cw);
-        else clf_step_body<1, 4>(a.clf, a.g.X, a.g.feat_dim, a.g.feat_stride, a.nodes + r0, a.labels + r0, r1 - r0, lds, (int)threadIdx.x, cst, cw);
+        if constexpr (CLF == 2) clf_step_body<2, 2>(a.clf, a.g.X, a.g.feat_dim, a.g.feat_stride, a.nodes + r0, a.labels + r0, r1 - r0, lds, (int)threadIdx.x, cst, cw);
+        else if constexpr (CLF == 1) clf_step_body<1, 3>(a.clf, a.g.X, a.g.feat_dim, a.g.feat_stride, a.nodes + r0, a.labels + r0, r1 - r0, lds, (int)threadIdx.x, cst, cw);
         if (a.stamps && leader) a.stamps[(size_t)a.g.n_rel * a.B * 8 + 3] = wall_clock64();
         return;
     }
@@ -1448,7 +1452,9 @@ int launch_select_rows(const ChooseArgs &a, hipStream_t st) {
         as.sort_slices = slices < 1 ? 1 : slices;
         as.sort_slice_len = (a.g.n_pos + as.sort_slices - 1) / as.sort_slices;
     }
-    hipLaunchKernelGGL(select_rows, dim3(blocks), dim3(SEL_NW * PCG_WAVE), select_smem_bytes(), st, as);
+    if (a.clf.clf_next && a.g.feat_stride > 256) hipLaunchKernelGGL(select_rows<2>, dim3(blocks), dim3(SEL_NW * PCG_WAVE), select_smem_bytes(), st, as);
+    else if (a.clf.clf_next) hipLaunchKernelGGL(select_rows<1>, dim3(blocks), dim3(SEL_NW * PCG_WAVE), select_smem_bytes(), st, as);
+    else hipLaunchKernelGGL(select_rows<0>, dim3(blocks), dim3(SEL_NW * PCG_WAVE), select_smem_bytes(), st, as);
     PCG_LAUNCH_CHECK();
     if (a.g.max_degree > WG_KEYCAP) {        // rows too long for the LDS keys: their own launch (hub-heavy graphs only)
         const int64_t per_wg = a.g.max_degree;

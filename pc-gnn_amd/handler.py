@@ -298,6 +298,8 @@ class ModelHandler(object):
             if engine is not None:
                 engine.flush()
             model.load_state_dict(torch.load(self.result.model_path, weights_only=True))
+            if engine is not None:
+                engine.params_changed()          # (the engine's own copy of the label classifier follows the restored one)
         auc_test, recall_test, f1_mac_test, precision_test = U.test(ds["idx_test"], ds["y_test"], engine or model, args.batch_size,
                                                                     self.result, epoch_best=epoch_best, flag="test")
         self.model, self.engine, self.epoch_best, self.last_epoch = model, engine, epoch_best, epoch

@@ -1143,6 +1143,7 @@ def test_touched_rows_only_scoring(P, monkeypatch):
     t = PCGNNTrainer(w, cfg, dev())
     assert t.fused.touched_on and not a.fused.touched_on
     t.fused.theta.copy_(a.fused.theta)
+    t.fused.params_changed()
     for ep in range(2):
         a.run_epoch_one_graph()
         if ep == 0:
@@ -1176,6 +1177,7 @@ def test_touched_rows_only_scoring(P, monkeypatch):
     monkeypatch.setenv("PCG_TOUCHED", "1")
     t2 = PCGNNTrainer(w2, cfg2, dev())
     t2.fused.theta.copy_(a2.fused.theta)
+    t2.fused.params_changed()
     a2.fused.stage_epoch(a2.pick_size, 1024); t2.fused.stage_epoch(t2.pick_size, 1024)
     for tr_ in (a2, t2):
         tr_.start_epoch_staged()
@@ -1247,6 +1249,7 @@ def test_realloc_between_epoch_graphs(P):
     cfg = dict(engine="graph", batch_size=256, seed=5)
     a, b = PCGNNTrainer(w, cfg, dev()), PCGNNTrainer(w, cfg, dev())
     b.fused.theta.copy_(a.fused.theta)
+    b.fused.params_changed()
     big = torch.arange(700, dtype=torch.int32, device=dev())
     for ep in range(3):
         a.run_epoch_one_graph()
