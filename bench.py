@@ -15,13 +15,15 @@ N=1 workload: BASELINE.json configs[1] - YelpChi-shaped synthetic graph
 (N=45,954, F=32, 3 relations with 49,315 / 573,616 / 3,402,743 undirected edges,
 14.53 % positives, 40 % train), emb 64, batch 1024, rho 0.5.
 
-Graph engine (default at N=1): an epoch - sampler + every batch's five launches - is
-ONE hipGraph launch; in the first epoch of the timed region and every `--event-every`-th
-after it the first `--timed-per-epoch` batches are launched kernel by kernel with HIP
-events around the select + gather call (same kernels, same order; the rest of such an
-epoch is one graph replay per batch): those events give the `roofline` object (dominant
-launch = select_rows + gather_chunks).  N>1: the destination-node partitioned path
-(pc-gnn_amd/dist.py), weak scaling.
+Graph engine (default at N=1): an epoch - sampler + plans + every batch's three launches
+(select_rows | gather_train_kernel | dense_step) - is ONE hipGraph launch; in the second
+epoch of the timed region and every `--event-every`-th after it the first
+`--timed-per-epoch` batches are launched kernel by kernel with HIP events around the
+pcg_choose_gather_train call (same kernels, same order; the rest of such an epoch is one
+graph replay per batch): those events give the `roofline` object (dominant call =
+select_rows + gather_train_kernel: selection, gather, the next step's score pass, the
+deferred Adam update; bytes: algorithmic_bytes()).  N>1: the destination-node
+partitioned path (pc-gnn_amd/dist.py), weak scaling.
 
 Prints ONE JSON line (rank 0) with `roofline` and `cpu_baseline` (the oracle port timed
 on the host cores on the event-bracketed batches of the same run; rank 0, N=1 only).
