@@ -493,13 +493,33 @@ def main():
             timed_epoch = engine != "graph" or (phase["epochs"] - first_timed) % args.event_every == 0
             if epoch_graphs and at_epoch_start and not timed_epoch and k + nb <= n_steps:
                 tr.run_epoch_one_graph(flush=False, prefetch=PREFETCH)  # pick + shuffle + labels + plans + every batch's step: one graph launch (the
-                                                     # last batch's deferred Adam update is applied by the next front launch, or
+                                                     # last batch's deferred Adam update is applied by the next gather launch, or
                                                      # by the flush that ends the timed region)
                 state["ids"], state["b"] = tr.fused._ep_ids[:tr.pick_size], nb
                 state["epoch"] += 1
                 if measure:
                     counted["nodes"] += tr.pick_size
                 k += nb
+                continue
+            if epoch_graphs and at_epoch_start and not timed_epoch and not PREFETCH:
+                # the run's last, partial epoch: its n_steps - k batches (sampler and plans in front) are one graph launch too
+                r = n_steps - k
+                done = tr.run_epoch_one_graph(flush=False, n_steps=r)
+                state["ids"], state["b"] = tr.fused._ep_ids[:tr.pick_size], r
+                state["epoch"] += 1
+                if measure:
+                    counted["nodes"] += done
+                k += r
+                continue
+            if (epoch_graphs and not at_epoch_start and timed_epoch and not PREFETCH and state["b"] >= args.timed_per_epoch
+                    and k + (nb - state["b"]) <= n_steps):
+                # an event-bracketed epoch behind its bracketed batches: the rest of its batches are one graph launch
+                b0 = state["b"]
+                tr.fused.epoch_run(first_step=b0, flush=False)
+                state["b"] = nb
+                if measure:
+                    counted["nodes"] += tr.pick_size - b0 * B
+                k += nb - b0
                 continue
             ids = next_batch()
             # (also during the warm-up, so that every graph is captured before the clock starts.)  With epoch graphs the first
@@ -534,6 +554,15 @@ def main():
         state["ids"], state["b"] = None, 0
         run_steps(2 * nb + 2, False)           # ... and one pass through the timed region's own sequence (bracketed epoch included)
         warmup += 2 * nb + 2
+        while state["b"] != nb:                # (finish the partial epoch the pass ended in)
+            one_step(next_batch())
+            warmup += 1
+        if args.steps % nb not in (0, 2) and not PREFETCH:      # the partial-epoch graph of THIS run's last epoch (2: captured above)
+            r = args.steps % nb
+            tr.run_epoch_one_graph(flush=False, n_steps=r)
+            state["ids"], state["b"] = tr.fused._ep_ids[:tr.pick_size], r
+            state["epoch"] += 1
+            warmup += r
         while state["b"] != nb:                # the warm-up ends at an epoch boundary
             one_step(next_batch())
             warmup += 1

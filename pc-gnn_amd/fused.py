@@ -592,7 +592,7 @@ class FusedPCGNN:
         self._fresh = score_next
 
     def epoch_run(self, n_steps: Optional[int] = None, sample=None, bump_counter: Optional[torch.Tensor] = None,
-                  flush: bool = True, prefetch: bool = False):
+                  flush: bool = True, prefetch: bool = False, first_step: int = 0):
         """All batches of the staged epoch as ONE graph launch: the host latency between two graph launches (~8 us)
         is paid once per epoch instead of once per batch.  ``sample(ids, labels)``, if given, is enqueued (and captured): it
         fills the given id / label buffers on the device (pick + shuffle + labels), so a replay is a whole new epoch;
@@ -604,22 +604,26 @@ class FusedPCGNN:
         such call - or one after the ready set was used up by other calls - samples its own epoch first.
         prefetch="stream": the same division of labour without a fork inside the graph: the sampler and plan launches of the next
         epoch are enqueued - by the host, behind this epoch's graph launch - on a second stream, where they run beside this
-        epoch's kernels; the only cross-stream waits are two events per epoch (the other buffer set is free / is ready)."""
+        epoch's kernels; the only cross-stream waits are two events per epoch (the other buffer set is free / is ready).
+        first_step > 0: the REST of an epoch that is staged and planned already and whose first batches have been run some other
+        way (batches first_step .. n_steps - 1): no sampler, no plans."""
         nb = -(-self._ep_n // self._ep_bs)
         n_steps = nb if n_steps is None else min(n_steps, nb)
         n = self._ep_n
+        if first_step > 0:
+            sample, prefetch = None, False
         on_stream = prefetch == "stream" and sample is not None
         prefetch = prefetch is True and sample is not None
         cur = self._cur
         primed = (prefetch or on_stream) and self._cur_ready
         key = ("epoch", cur, n, self._ep_bs, n_steps, sample is not None, None if bump_counter is None else bump_counter.data_ptr(),
-               flush, prefetch, primed, on_stream)
+               flush, prefetch, primed, on_stream, first_step)
         gr = self._ep_graphs.get(key)
         if gr is None:
             st = self._ep_sets[cur]
             nxt = self._ep_sets[cur ^ 1]
             def run():
-                for b in range(n_steps):
+                for b in range(first_step, n_steps):
                     lo = b * self._ep_bs
                     B = min(self._ep_bs, n - lo)
                     self.train_step(st["ids"][lo:lo + B], st["lab"][lo:lo + B], defer=True, plan=self._ep_plan(b, cur),
@@ -627,12 +631,15 @@ class FusedPCGNN:
                 if flush:
                     self.flush()
             def warm_run():                      # (the warm-up leaves the staged ids - and the epoch counter - as they are)
-                self.plan_staged(which=cur)
+                if first_step == 0:
+                    self.plan_staged(which=cur)
+                elif not self._fresh:
+                    self._enqueue_refresh(self._ep_touch(first_step, cur))
                 run()
                 if prefetch or on_stream:        # (the other set's plan slots and kernels get their first use outside a capture)
                     self.plan_staged(which=cur ^ 1)
             def sampled_run():
-                if not primed:
+                if not primed and first_step == 0:
                     if sample is not None:
                         sample(st["ids"][:n], st["lab"][:n])
                     self.plan_staged(bump_counter, which=cur)
@@ -652,14 +659,17 @@ class FusedPCGNN:
         self._lastB = min(self._ep_bs, n - (n_steps - 1) * self._ep_bs)
         # (whole-table engine: the graph was captured with the scores at hand - it holds no score launch of its own; a
         #  touched-rows engine's graph scores its first batch's rows itself, behind its sampler and maps)
-        if not self.touched_on and not self._fresh:
+        if first_step > 0:
+            if not self._fresh:                      # (the graph was captured with the scores at hand)
+                self._enqueue_refresh(self._ep_touch(first_step, cur))
+        elif not self.touched_on and not self._fresh:
             self._enqueue_refresh()
         main = torch.cuda.current_stream(self.dev)
         if primed and getattr(self, "_ev_ready", None) is not None:
             main.wait_event(self._ev_ready)          # the side stream has sampled and planned this set
             self._ev_ready = None
         gr.replay()
-        self._fresh = not self.touched_on
+        self._fresh = (not self.touched_on) or self._ep_next_touch(n_steps - 1, cur) is not None
         if on_stream:
             # the next epoch's sampler + plans, on the side stream: behind the graph launched BEFORE this one (the last reader of
             # the other set), beside this one

@@ -84,13 +84,13 @@ class PCGNNTrainer:
     def _sample_into(self, ids: torch.Tensor, lab: torch.Tensor):
         self.sampler.pick_shuffled(self.pick_size, ids, self.labels_i32, lab, epoch_counter=self._epoch_dev, bump=False)
 
-    def run_epoch_one_graph(self, flush: bool = True, prefetch: bool = False) -> int:
+    def run_epoch_one_graph(self, flush: bool = True, prefetch: bool = False, n_steps: Optional[int] = None) -> int:
         """A whole epoch - pick, shuffle, labels, every batch's plan and every batch's training step - as one graph launch.
         flush=False / prefetch=True: see FusedPCGNN.epoch_run (back-to-back epochs: the next epoch's first launch applies the
         last update; the next epoch's sampler and plans run beside this epoch's steps)."""
         self.fused.stage_epoch(self.pick_size, self.batch_size)
-        self.fused.epoch_run(sample=self._sample_into, bump_counter=self._epoch_dev, flush=flush, prefetch=prefetch)
-        return self.pick_size
+        self.fused.epoch_run(n_steps=n_steps, sample=self._sample_into, bump_counter=self._epoch_dev, flush=flush, prefetch=prefetch)
+        return self.pick_size if n_steps is None else min(self.pick_size, n_steps * self.batch_size)
 
     def step(self, batch_ids: torch.Tensor, timed: bool = False) -> torch.Tensor:
         """One iteration of the batch loop (model_handler.py:147-153)."""
