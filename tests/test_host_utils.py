@@ -187,3 +187,29 @@ def test_bench_launches_its_own_ranks():
     # per relation: 4 * (2B + D) CSR + 4 * D scores + 4 * F * S rows + 4 * B * F output
     want = (4 * (4 + 3) + 4 * 3 + 4 * 8 * 2 + 4 * 2 * 8) + (4 * (4 + 5) + 4 * 5 + 4 * 8 * 3 + 4 * 2 * 8)
     assert bench.algorithmic_bytes(G, ids, counts) == want
+
+
+def test_bench_algorithmic_bytes_counts_the_riders_once():
+    """bench.py's byte count of the select + gather call: the SURVEY 8(d) terms of the call itself, plus - for the training
+    call, whose two launches also carry the next step's score pass, the label classifier's step and the deferred Adam update -
+    the table stream, the train positives' rows, the centres' rows and the optimizer state; never the per-tile slabs."""
+    import importlib.util
+    import os
+    import types
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    deg = [np.array([3, 0, 5, 2]), np.array([1, 1, 1, 1])]
+    g = types.SimpleNamespace(R=2, feat_dim=8, deg_host=deg)
+    ids = np.array([0, 2, 2])
+    counts = [np.array([2, 3, 3]), np.array([1, 1, 1])]
+    base = bench.algorithmic_bytes(g, ids, counts)
+    B, F = 3, 8
+    want = 0
+    for r in range(2):
+        D, S = int(deg[r][ids].sum()), int(counts[r].sum())
+        want += 4 * (2 * B + D) + 4 * D + 4 * F * S + 4 * B * F
+    assert base == want
+    riders = dict(table_rows=100, n_pos=7, n_params=50)
+    assert bench.algorithmic_bytes(g, ids, counts, riders) == want + 100 * (4 * F + 4) + 7 * (4 * F + 8) + B * (4 * F + 8) + 28 * 50
+    assert bench.algorithmic_bytes(g, ids, counts, dict(table_rows=0, n_pos=7, n_params=50)) < bench.algorithmic_bytes(g, ids, counts, riders)
