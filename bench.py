@@ -94,13 +94,25 @@ def make_workload(args):
     return synth.power_law(args.nodes, args.edges, args.seed), 4096, 0.01, 0.001
 
 
+def unique_rows(csr, n_nodes, ids_host):
+    """U of SURVEY 8(d): |batch + every neighbour it has in any relation| (src/layers.py:226-227's unique_nodes)."""
+    mark = np.zeros(n_nodes, dtype=bool)
+    mark[ids_host] = True
+    for indptr, idx in csr:
+        for v in np.unique(ids_host):
+            mark[idx[indptr[v]:indptr[v + 1]]] = True
+    return int(mark.sum())
+
+
 def algorithmic_bytes(graph, ids_host, counts_host, riders=None):
     """HBM bytes the choose+aggregate call must move for one batch:
     CSR row bounds + neighbour ids + neighbour class-0 scores + chosen feature rows + output.
     riders (the training call pcg_choose_gather_train, whose two launches also carry the next step's score pass, the label
-    classifier's step and the deferred Adam update): dict(table_rows, n_pos, n_params) - + the table stream and the scores it
-    writes, + the train positives' rows and keys, + the centres' rows, + one read of the gradient and a read and a write of
-    theta, m, v (the per-tile slabs the gradient is summed from are an implementation's traffic, not counted)."""
+    classifier's step and the deferred Adam update): dict(table_rows | csr + n_nodes, n_pos, n_params) - + SURVEY 8(d)'s U x F
+    term: the feature rows of the batch's unique_nodes read once for scoring, and their scores (U is counted from the CSR when
+    `table_rows` is not given; an engine that scores the whole table streams N >= U rows - the surplus is its own traffic, not
+    algorithmic bytes), + the train positives' rows and keys, + the centres' rows, + one read of the gradient and a read and a
+    write of theta, m, v (the per-tile slabs the gradient is summed from are an implementation's traffic, not counted)."""
     B = len(ids_host)
     total = 0
     for r in range(graph.R):
@@ -109,7 +121,8 @@ def algorithmic_bytes(graph, ids_host, counts_host, riders=None):
         total += 4 * (2 * B + D) + 4 * D + 4 * graph.feat_dim * S + 4 * B * graph.feat_dim
     if riders:
         F = graph.feat_dim
-        total += riders["table_rows"] * (4 * F + 4) + riders["n_pos"] * (4 * F + 8) + B * (4 * F + 8) + 28 * riders["n_params"]
+        U = riders["table_rows"] if "table_rows" in riders else unique_rows(riders["csr"], riders["n_nodes"], ids_host)
+        total += U * (4 * F + 4) + riders["n_pos"] * (4 * F + 8) + B * (4 * F + 8) + 28 * riders["n_params"]
     return total
 
 
@@ -596,11 +609,11 @@ def main():
     if rank == 0:
         kern_ms = [a.elapsed_time(b) for a, b in events]
         batches_host = [i.cpu().numpy().astype(np.int64) for i, _ in used_ev]   # the event-bracketed batches: the CPU sample
-        # (a touched-rows engine scores only the rows its next batch marks: how many is not known here - its table term is left
-        #  out, the figure is then a lower bound of the call's bytes)
+        # (the score rider's term is SURVEY 8(d)'s U x F - the unique_nodes of the bracketed batch, counted from the host CSR -
+        #  whether the engine scores the whole table or only the rows the next batch marks)
         riders = None
         if tr.fused is not None:
-            riders = dict(table_rows=0 if tr.fused.touched_on else tr.graph.n_nodes, n_pos=tr.graph.n_pos, n_params=tr.fused.n_params)
+            riders = dict(csr=w.csr, n_nodes=w.n, n_pos=tr.graph.n_pos, n_params=tr.fused.n_params)
         abytes = [algorithmic_bytes(tr.graph, i.cpu().numpy().astype(np.int64), c.cpu().numpy(), riders) for i, c in used_ev]
         avg_ms = float(np.mean(kern_ms))
         achieved = float(np.mean(abytes)) / (avg_ms * 1e-3) / 1e9
@@ -631,7 +644,7 @@ def main():
                        "global_batch": B * world, "parallelism": "single" if world == 1 else f"dp{world}-replicated-graph",
                        "engine": engine,
                        "nodes_processed": int(nodes_total)},
-            "roofline": {"bound": "hbm", "kernel": "pcg_choose_gather_train: select_rows (sorts the train positives, steps the label classifier for this batch) + gather_train_kernel (gather || the other parameters' deferred Adam update || the NEXT step's score pass and train-pos keys); the plan is made per epoch beside the sampler, multi-chunk sums are finished in the dense kernel's prologue; bytes = select + gather + table stream + optimizer state (algorithmic_bytes)", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "pcg_choose_gather_train: select_rows (sorts the train positives, steps the label classifier for this batch) + gather_train_kernel (gather || the other parameters' deferred Adam update || the NEXT step's score pass and train-pos keys); the plan is made per epoch beside the sampler, multi-chunk sums are finished in the dense kernel's prologue; bytes = select + gather + U x F feature rows scored + optimizer state (algorithmic_bytes)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_from": ("profiles/pmc_traffic.json: two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of this command at commit "
                                           f"{traffic_commit}") if traffic is not None else None,

@@ -213,3 +213,9 @@ def test_bench_algorithmic_bytes_counts_the_riders_once():
     riders = dict(table_rows=100, n_pos=7, n_params=50)
     assert bench.algorithmic_bytes(g, ids, counts, riders) == want + 100 * (4 * F + 4) + 7 * (4 * F + 8) + B * (4 * F + 8) + 28 * 50
     assert bench.algorithmic_bytes(g, ids, counts, dict(table_rows=0, n_pos=7, n_params=50)) < bench.algorithmic_bytes(g, ids, counts, riders)
+    # U counted from the CSR: the batch's unique nodes and all their neighbours (layers.py:226-227)
+    csr = [(np.array([0, 2, 2, 4, 5]), np.array([1, 3, 0, 3, 2])), (np.array([0, 1, 2, 3, 4]), np.array([0, 1, 2, 3]))]
+    assert bench.unique_rows(csr, 4, ids) == 4                                     # {0, 2} + {1, 3} + {0, 3} = every node
+    assert bench.unique_rows(csr, 4, np.array([1])) == 1
+    by_csr = bench.algorithmic_bytes(g, ids, counts, dict(csr=csr, n_nodes=4, n_pos=7, n_params=50))
+    assert by_csr == bench.algorithmic_bytes(g, ids, counts, dict(table_rows=4, n_pos=7, n_params=50))
