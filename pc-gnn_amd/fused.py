@@ -1,11 +1,20 @@
 """Whole-step driver: every launch of one PC-GNN train step, back to back on one
-stream, no torch ops and no host synchronisation in between - four launches:
+stream, no torch ops and no host synchronisation in between - three launches:
 
-    scores  [score pass || train-pos keys || Adam of the previous step's gradient (all but the label classifier)]
-    select_rows [the train positives' sort by its first workgroups || every row's selection] -> gather_chunks
-    dense_step [sums of multi-chunk rows, forward, loss, backward partials, Adam of the label classifier]
+    select_rows          [the train positives' sort by its first workgroups || the label classifier's own step for this batch
+                          (one workgroup: forward, loss gradient, Adam) || every row's selection]
+    gather_train_kernel  [gather || Adam of the previous step's gradient (all but the label classifier) || the NEXT step's score
+                          pass and train-pos keys, with the classifier the select launch has just stepped]
+    dense_step           [sums of multi-chunk rows, forward, loss, backward partials (per-tile slabs)]
 
-(``pcg_step_scores_train`` / ``pcg_choose_gather_planned`` / ``pcg_train_dense``).  The PLAN of a batch (row records, list
+(``pcg_choose_gather_train`` / ``pcg_train_dense(adam_clf = 2)``; the first step after anything else has run is preceded by one
+score launch, ``pcg_step_scores``).  Why this order is legal: the label classifier's parameters get gradient from nothing but
+the centres' feature rows and labels, so its step does not have to wait for the dense kernel - and the scores the next batch is
+selected by can be formed beside this batch's gather instead of at the head of the next step.  ``clf_next`` is that classifier,
+one step ahead of theta's copy (which the current step's loss term is computed with); ``flush()`` makes them equal;
+``params_changed()`` after parameters were written from outside.
+
+The PLAN of a batch (row records, list
 offsets, tier queues, the gather's chunk table) depends only on the batch's ids, labels and the CSR degrees - not on any
 parameter - so it is not part of a step: ``pcg_plan_batches`` plans every batch of an epoch in ONE launch right after the
 sampler (one plan slot per batch; the selection list and the partial sums - the data part - are shared).  A deferred Adam
