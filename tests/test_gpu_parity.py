@@ -830,8 +830,8 @@ def test_epoch_as_one_graph_equals_step_by_step(P):
     from pcgnn_amd.handler import PCGNNTrainer
     w = synth.make_workload("mini", 6000, 32, (4000, 30000, 90000), 0.12, seed=3)
     cfg = dict(engine="graph", batch_size=256, seed=5)
-    a, b, c, d, e, f = (PCGNNTrainer(w, cfg, dev()) for _ in range(6))
-    for t in (b, c, d, e, f):
+    a, b, c, d, e, f, h, i = (PCGNNTrainer(w, cfg, dev()) for _ in range(8))
+    for t in (b, c, d, e, f, h, i):
         t.fused.theta.copy_(a.fused.theta)
         t.fused.params_changed()
     nb = a.batches_per_epoch()
@@ -851,6 +851,14 @@ def test_epoch_as_one_graph_equals_step_by_step(P):
             e.run_epoch_one_graph(flush=False, prefetch=True)
         # ... or enqueued by the host on a second stream beside this epoch's graph
         f.run_epoch_one_graph(flush=False, prefetch="stream")
+        # an event-bracketed epoch as bench.py runs it: the first batch kernel by kernel, the REST of the epoch one graph launch
+        h.start_epoch_staged()
+        h.fused.epoch_step_timed(0)
+        h.fused.epoch_run(first_step=1, flush=False)
+        # a run's last, partial epoch as one graph launch (sampler + plans + its first two batches), the rest batch by batch
+        i.run_epoch_one_graph(flush=False, n_steps=2)
+        for k in range(2, nb):
+            i.fused.epoch_step(k, defer=True)
         ids = b.start_epoch_staged()
         for k in range(nb):
             sl = slice(k * b.batch_size, min((k + 1) * b.batch_size, b.pick_size))
@@ -863,9 +871,8 @@ def test_epoch_as_one_graph_equals_step_by_step(P):
                 c.fused.epoch_step_timed(k)
             else:
                 c.fused.epoch_step(k, defer=True)
-    d.fused.flush()
-    e.fused.flush()
-    f.fused.flush()
+    for t in (d, e, f, h, i):
+        t.fused.flush()
     torch.cuda.synchronize()
     assert int(a._epoch_dev[0]) == int(b._epoch_dev[0]) == int(c._epoch_dev[0]) == int(d._epoch_dev[0]) == 3
     assert int(e._epoch_dev[0]) == 4 and e.fused._cur_ready        # (the fourth epoch is sampled and planned already)
@@ -878,6 +885,8 @@ def test_epoch_as_one_graph_equals_step_by_step(P):
         assert torch.equal(getattr(a.fused, name), getattr(d.fused, name)), name + " (epoch graphs without the end-of-epoch flush)"
         assert torch.equal(getattr(a.fused, name), getattr(e.fused, name)), name + " (next epoch's sampler + plans on a parallel branch)"
         assert torch.equal(getattr(a.fused, name), getattr(f.fused, name)), name + " (next epoch's sampler + plans on a second stream)"
+        assert torch.equal(getattr(a.fused, name), getattr(h.fused, name)), name + " (first batch eager, the rest of the epoch one graph)"
+        assert torch.equal(getattr(a.fused, name), getattr(i.fused, name)), name + " (a partial epoch as one graph, the rest batch by batch)"
     assert torch.isfinite(a.fused.theta).all() and not torch.equal(a.fused.theta, torch.zeros_like(a.fused.theta))
 
 
