@@ -73,6 +73,9 @@ def parse():
     ap.add_argument("--report-epochs", type=int, default=7, help="graph engine: epochs timed one by one AFTER the timed region "
                     "(sampler and batches as two graph launches with events in between) for the reference-window / pick-inclusive "
                     "medians (SURVEY 8d); 0 = skip")
+    ap.add_argument("--post-brackets", type=int, default=8, help="graph engine: epochs run AFTER the timed region whose first batch is "
+                    "launched kernel by kernel with HIP events around pcg_choose_gather_train: further samples for `roofline` "
+                    "(the timed region itself brackets one batch every --event-every epochs); 0 = none")
     ap.add_argument("--verify-batches", type=int, default=1, help="batches whose chosen sets are checked after the clock stops "
                     "(count law on every row, the oracle's sets on a strided sample); 0 = skip")
     ap.add_argument("--prefetch", nargs="?", const="graph", default="off", choices=["off", "graph", "stream"],
@@ -190,48 +193,77 @@ def epoch_report(tr, n_epochs):
             "how": "after the timed region; per epoch: event | sampler launch | event | one graph launch of all batches | event"}
 
 
-def verify_rows(w, tr, cfg, batches, stride=61):
-    """After the clock has stopped: the chosen sets of event-bracketed batches of the run, recomputed by the product path with
-    the final parameters and read back - the count law on every row (kept = deg > k + 1 ? k : deg neighbours, plus at most
-    m = int(k * rho) train positives for a positive centre, src/layers.py:662-694) and, on a strided sample of rows, the
-    oracle's sets for the same device scores (bit-exact).  The oracle is the checker here, nothing it computes is timed
-    or fed back."""
-    from oracle import pcgnn_oracle as O
-    from pcgnn_amd import ops
-    g, fz = tr.graph, tr.fused
+def post_region_brackets(w, tr, cfg, n_pairs, verify, stride=61):
+    """After the clock has stopped: `n_pairs` further epochs whose FIRST batch is launched kernel by kernel with HIP events around
+    pcg_choose_gather_train (select_rows + gather_train_kernel), the rest of each epoch one graph launch - more samples for the
+    roofline object than the timed region's few brackets.  verify: the first of these launches is also CHECKED - the scores it
+    selects by are copied beforehand, the selection lists it wrote are read back from the workspace (plan slot + data part) right
+    after it: the count law on every row (kept = deg > k + 1 ? k : deg neighbours, plus at most m = int(k * rho) train positives for
+    a positive centre, src/layers.py:662-694; |set| == the kernel's count) and, on a strided sample of rows, the oracle's sets for
+    the same scores (bit-exact).  The oracle is the checker: nothing it computes is timed or fed back.
+    Returns (events, [(ids, counts)], verified | None)."""
+    fz = tr.fused
+    fz.stage_epoch(tr.pick_size, tr.batch_size)
+    fz.take_prefetched()
+    fz._prof = []
+    used, verified = [], None
+    B = tr.batch_size
+    for i in range(n_pairs + (1 if verify else 0)):
+        ids_all = tr.start_epoch_staged()
+        ids = ids_all[:B]
+        checked = verify and i == 0                   # the checked launch starts from a drained device: its timing is not a sample
+        s0_before = None
+        if checked:
+            if not fz._fresh:
+                fz._enqueue_refresh(fz._ep_touch(0))
+            s0_before = fz.s0.clone()
+        fz.epoch_step_timed(0, eager=True)
+        if checked:
+            fz._prof.pop()
+            sets = fz.read_batch_lists(0)             # (synchronises; the lists of THIS launch: nothing has selected since)
+            verified = verify_lists(w, tr, cfg, ids, sets, fz.last_counts.cpu().numpy(), s0_before, stride)
+        else:
+            used.append((ids.clone(), fz.last_counts.clone()))
+        fz.epoch_run(first_step=1, flush=False)
     fz.flush()
-    s0 = ops.score_table(g, fz.w_clf, fz.b_clf)
-    keys = ops.pos_sort(g, s0)
-    s0_h = torch.from_numpy(s0.cpu().numpy())
+    torch.cuda.synchronize(tr.device)
+    fz.check()
+    events, fz._prof = fz._prof, None
+    return events, used, verified
+
+
+def verify_lists(w, tr, cfg, ids, sets, cnt_h, s0_dev, stride):
+    from oracle import pcgnn_oracle as O
+    g = tr.graph
+    s0_h = torch.from_numpy(s0_dev.cpu().numpy())
     pos = list(w.train_pos)
     pos_s = s0_h[torch.as_tensor(pos, dtype=torch.long)]
     rho, thr = float(cfg["rho"]), 0.5
+    B = int(ids.numel())
+    lab_h = tr.labels_i32[ids.long()].cpu().numpy()
+    ids_h = ids.cpu().numpy().astype(np.int64)
     rows_law = rows_oracle = 0
-    for ids in batches:
-        B = int(ids.numel())
-        lab = tr.labels_i32[ids.long()]
-        sets, _, cnt = ops.chosen_sets(g, ids, lab, s0, keys, [thr] * g.R, rho, True)
-        ids_h, lab_h, cnt_h = ids.cpu().numpy().astype(np.int64), lab.cpu().numpy(), cnt.cpu().numpy()
-        for r in range(g.R):
-            deg = g.deg_host[r][ids_h].astype(np.int64)
-            k = np.ceil(deg * thr).astype(np.int64)
-            kept = np.where(deg > k + 1, k, deg)
-            m = np.where(lab_h == 1, np.minimum((k * rho).astype(np.int64), len(pos)), 0)
-            sizes = np.array([len(x) for x in sets[r]])
-            if not (np.array_equal(sizes, cnt_h[r]) and (sizes >= kept).all() and (sizes <= kept + m).all()):
-                raise SystemExit(f"verify_rows: the count law fails in relation {r}")
-            rows_law += B
-            probe = list(range(0, B, stride))
-            indptr, idx = w.csr[r]
-            lists = [idx[indptr[v]:indptr[v + 1]].tolist() for v in ids_h[probe]]
-            want = O.choose_sets(s0_h[torch.as_tensor(ids_h[probe], dtype=torch.long)], [int(lab_h[b]) for b in probe], lists,
-                                 [s0_h[torch.as_tensor(l, dtype=torch.long)] for l in lists], pos, pos_s, thr, rho, True)
-            for b, ws_ in zip(probe, want):
-                if sets[r][b] != ws_:
-                    raise SystemExit(f"verify_rows: relation {r} row {b} (node {ids_h[b]}, degree {deg[b]}) differs from the oracle's set")
-            rows_oracle += len(probe)
-    return {"batches": len(batches), "rows_count_law": rows_law, "rows_vs_oracle": rows_oracle,
-            "how": "after the timed region, final parameters, product path re-run on the run's event-bracketed batches"}
+    for r in range(g.R):
+        deg = g.deg_host[r][ids_h].astype(np.int64)
+        k = np.ceil(deg * thr).astype(np.int64)
+        kept = np.where(deg > k + 1, k, deg)
+        m = np.where(lab_h == 1, np.minimum((k * rho).astype(np.int64), len(pos)), 0)
+        sizes = np.array([len(x) for x in sets[r]])
+        if not (np.array_equal(sizes, cnt_h[r]) and (sizes >= kept).all() and (sizes <= kept + m).all()):
+            raise SystemExit(f"verify: the count law fails in relation {r}")
+        rows_law += B
+        probe = list(range(0, B, stride))
+        indptr, idx = w.csr[r]
+        lists = [idx[indptr[v]:indptr[v + 1]].tolist() for v in ids_h[probe]]
+        want = O.choose_sets(s0_h[torch.as_tensor(ids_h[probe], dtype=torch.long)], [int(lab_h[b]) for b in probe], lists,
+                             [s0_h[torch.as_tensor(l, dtype=torch.long)] for l in lists], pos, pos_s, thr, rho, True)
+        for b, ws_ in zip(probe, want):
+            if sets[r][b] != ws_:
+                raise SystemExit(f"verify: relation {r} row {b} (node {ids_h[b]}, degree {deg[b]}) differs from the oracle's set")
+        rows_oracle += len(probe)
+    return {"batches": 1, "rows_count_law": rows_law, "rows_vs_oracle": rows_oracle,
+            "how": "after the timed region: the selection lists an event-bracketed pcg_choose_gather_train launch wrote (plan slot + "
+                   "data part read back), against the scores that launch selected by (copied before it)"}
 
 
 def run_partitioned(args, w, B, lr, wd, dev, dist, world, rank):
@@ -306,12 +338,18 @@ def run_partitioned(args, w, B, lr, wd, dev, dist, world, rank):
         for e0, e1, ids_l, cnt in prof:
             ms.append(e0.elapsed_time(e1))
             ids_h = ids_l.cpu().numpy().astype(np.int64)
-            ab.append(algorithmic_bytes(g, ids_h, cnt.view(g.R, -1).cpu().numpy()) + 4 * g.X.shape[0] * g.feat_dim)
+            # (SURVEY 8(d)'s U x F: the feature rows of the batch's unique nodes - centres and every neighbour, counted from this
+            #  rank's CSR rows by global id - read once for scoring; not the whole extended table the rank's score pass streams)
+            glob = [ids_h + d.part.lo] + [idx[ip[v]:ip[v + 1]] for ip, idx in d.csr_host for v in np.unique(ids_h)]
+            U = int(np.unique(np.concatenate(glob)).size)
+            ab.append(algorithmic_bytes(g, ids_h, cnt.view(g.R, -1).cpu().numpy()) + U * (4 * g.feat_dim + 4))
         avg_ms = float(np.mean(ms)) if ms else float("nan")
         achieved = float(np.mean(ab)) / (avg_ms * 1e-3) / 1e9 if ms else float("nan")
         roofline = {"bound": "hbm", "kernel": "the step graph of rank 0 (score pass over owned + train-pos + halo rows, plan, train-pos "
-                                              "sort, select_rows, halo look-up, gather_chunks, dense_step, slab sum): one launch per step",
+                                              "sort, select_rows, halo look-up, gather_chunks, dense_step, slab sum): one launch per step; "
+                                              "bytes = select + gather + U x F scored rows (U = the batch's unique nodes)",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "traffic_note": "no PMC pass of the partitioned step has been collected (profiles/): null",
                     "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": float(np.mean(ab)) if ab else None,
                     "launches_timed": len(ms)}
         out = {
@@ -597,6 +635,9 @@ def main():
         tr.fused.check()
         status_clean = True
     report = epoch_report(tr, args.report_epochs) if (epoch_graphs and args.report_epochs > 0 and rank == 0) else None
+    post_ev, post_used, verified = [], [], None
+    if epoch_graphs and rank == 0 and (args.post_brackets > 0 or args.verify_batches > 0):
+        post_ev, post_used, verified = post_region_brackets(w, tr, cfg, args.post_brackets, args.verify_batches > 0)
 
     nodes_local = counted["nodes"]
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -607,6 +648,9 @@ def main():
     elapsed, nodes_total = float(t.item()), float(n.item())
 
     if rank == 0:
+        n_in_region = len(events)
+        events = list(events) + list(post_ev)
+        used_ev = list(used_ev) + list(post_used)
         kern_ms = [a.elapsed_time(b) for a, b in events]
         batches_host = [i.cpu().numpy().astype(np.int64) for i, _ in used_ev]   # the event-bracketed batches: the CPU sample
         # (the score rider's term is SURVEY 8(d)'s U x F - the unique_nodes of the bracketed batch, counted from the host CSR -
@@ -648,13 +692,17 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_from": ("profiles/pmc_traffic.json: two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of this command at commit "
                                           f"{traffic_commit}") if traffic is not None else None,
-                         "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": float(np.mean(abytes)),
-                         "launches_timed": len(kern_ms)},
+                         "avg_launch_ms": avg_ms, "min_launch_ms": float(np.min(kern_ms)), "max_launch_ms": float(np.max(kern_ms)),
+                         "algorithmic_bytes_per_launch": float(np.mean(abytes)),
+                         "launches_timed": len(kern_ms), "launches_timed_inside_the_timed_region": n_in_region,
+                         "launches_how": "HIP events around the call's two kernels; the timed region brackets the first batch of its "
+                                         "second epoch and of every --event-every-th after it, --post-brackets further epochs "
+                                         "after the clock has stopped add one bracket each (same launches, same graphs around them)"},
         }
         if report is not None:
             out["epoch_report"] = report
-        if world == 1 and args.verify_batches > 0 and tr.fused is not None and used_ev:
-            out["verified"] = verify_rows(w, tr, cfg, [i for i, _ in used_ev][:args.verify_batches])
+        if verified is not None:
+            out["verified"] = verified
         if world == 1 and args.cpu_batches > 0:
             # the CPU sample: the event-bracketed batches of the run, topped up with further epochs of the same sampler (same
             # weights, same batch size) when a short run has bracketed fewer than --cpu-batches

@@ -162,16 +162,33 @@ __device__ __forceinline__ void wait_sorted_keys(const ChooseArgs &a, int &keys_
     keys_ok = 1;
 }
 
-// every load of a sorted train-pos key.  PCG_PK_NT = 1: past the L1 (non-temporal: served by L2 like an agent-scope load, yet an
-// ordinary load to the compiler - agent-scope ATOMIC loads are never speculated: "x = cond ? load : c" became a branch with a load
-// and a full wait of its own, +5 us per positive row).  Default: plain loads - see wait_sorted_keys for why no L1 line of the
-// sorted keys can predate their publication; with L1 bypassed the first probes of the window search (the same 64 positions for
-// every row) hit the same few L2 lines from a thousand rows released at once: +4 us per positive row.
+// every load of a sorted train-pos key.  The keys may have been sorted INSIDE this launch by other workgroups (sort_share:
+// write-through sc1 stores, each storing wave drained, one agent-scope add per key group), so the consumer side must be one of
+// the hand-off forms that are valid across CUs and XCDs (per-XCD L2s are not coherent, a CU's L1 is never refreshed):
+//   PCG_PK_NT = 2 (default): EVERY load of a key is an sc1 load to registers (raw buffer load, aux 16): served by L2 past the L1,
+//     and an sc1-stored line is dropped from the storing XCD's L2 - with the polling wave's relaxed agent poll and the LDS word
+//     the other waves wait on this is the guides' "sc1 stores, drained; counter; sc1 loads in place of the acquire" form
+//     (MI355X_MICROARCH.md, inter-workgroup visibility, Valid forms).  An ordinary load to the compiler (speculated, batched),
+//     unlike an agent-scope ATOMIC load ("x = cond ? load : c" became a branch with a load and a full wait of its own: +5 us per
+//     positive row).
+//   PCG_PK_NT = 0: plain loads - correct only as long as no line of the sorted keys can sit in this CU's L1 / this XCD's L2
+//     before the count is complete (the launch starts with clean caches and nothing reads the buffer before its own wait returns;
+//     an sc1 store leaves no line behind in the storing XCD's L2).  Not an architectural guarantee: kept as the A/B reference.
+//   PCG_PK_NT = 1: non-temporal loads (L1 bypassed, no sc1).
+// An agent-scope acquire fence instead (buffer_inv sc1 per workgroup, three workgroups per CU) cost ~5 us per positive row: it
+// empties the L1 under the other workgroups' score gathers.
 #ifndef PCG_PK_NT
-#define PCG_PK_NT 0
+#define PCG_PK_NT 2
 #endif
 __device__ __forceinline__ uint64_t pk_ld(const uint64_t *pk, int i) {
-#if PCG_PK_NT
+#if PCG_PK_NT == 2
+    // (the descriptor is wave-uniform - four scalar registers formed from the kernel argument; 0x00020000: raw 32-bit format;
+    //  the range is not bounded here: every index is clamped by its caller)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t *>(pk), 0, 0x7FFFFFFF, 0x00020000);
+    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+    const u2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, i * 8, 0, 16);        // aux 16 = sc1
+    return ((uint64_t)v.y << 32) | v.x;
+#elif PCG_PK_NT == 1
     return __builtin_nontemporal_load(pk + i);
 #else
     return pk[i];

@@ -371,6 +371,7 @@ class DistributedPCGNN:
         for indptr, idx in sh["csr"]:
             ip = np.concatenate([indptr, np.full(n_ext - n_local, indptr[-1], dtype=np.int64)])
             csr_ext.append((ip, idx))
+        self.csr_host = sh["csr"]                 # this rank's rows, neighbour ids global (bench.py counts a batch's unique nodes from it)
         self.g = DeviceGraph(X_ext, csr_ext, sh["train_pos"], self.dev, id_space=w.n)
         g = self.g
         # node id of every table row: owned | train-pos | halo (= the exchange's request list, -1 = unused slot)

@@ -99,6 +99,10 @@ class FusedPCGNN:
         # score_next leaves them so); anything else that touches s0, the keys or the parameters clears it.
         self.clf_next = self.theta[self.n_rest:].clone()
         self._fresh = False
+        # model.load_state_dict writes the parameters behind the engine's back (they are views into theta): a deferred update
+        # is applied first, the stepped classifier and the score table are taken from theta again afterwards
+        model.register_load_state_dict_pre_hook(lambda *a, **k: self.flush())
+        model.register_load_state_dict_post_hook(lambda *a, **k: self.params_changed())
 
         # Score only the rows a batch's selection can read (its centres and their neighbours: a byte map per batch, built per epoch
         # beside the plans) instead of the whole table - worth it when the table is far larger than what a batch touches
@@ -198,6 +202,9 @@ class FusedPCGNN:
             if torch.cuda.is_current_stream_capturing():
                 raise _lib.PcgnnLibraryError("a larger epoch's touched-row maps inside a graph capture: warm up before capturing")
             q = self._mark_queue = torch.zeros(need, dtype=torch.int32, device=self.dev)
+            # every captured graph that marks rows holds the old queue's address
+            self._graphs.clear()
+            self._ep_graphs.clear()
         _lib.check(self.lib.pcg_mark_touched(self.g.desc_ref(), _p(ids), n_total, B, _p(maps), self._touch_stride, _p(q),
                                              self._stream()), "pcg_mark_touched")
 
@@ -487,6 +494,15 @@ class FusedPCGNN:
             self._ep_stride = stride
             self._cur, self._cur_ready = 0, False
             self._ep_graphs.clear()
+        if (getattr(self, "_ep_n", n), getattr(self, "_ep_bs", batch_size)) != (n, batch_size):
+            # another epoch shape inside the same buffers: the last batch's (shorter) plan layout moves to another slot, and the
+            # plan launch's look-back tags (a small integer per workgroup) would sit on top of whatever the old layout left
+            # there - zero the slots so that no stale word can pass for a published total
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.PcgnnLibraryError("stage_epoch with a new epoch size inside a graph capture")
+            for st in self._ep_sets:
+                st["plans"].zero_()
+            self._ep_graphs.clear()
         self._ep_n, self._ep_bs = n, batch_size
         return self._ep_ids[:n], self._ep_lab[:n]
 
@@ -542,7 +558,7 @@ class FusedPCGNN:
             return
         self._lastB = B
         defer = defer and lo + B < self._ep_n
-        key = (self._cur, lo, B, "deferred") if defer else (self._cur, lo, B)
+        key = (self._cur, lo, B, self._ep_n, "deferred") if defer else (self._cur, lo, B, self._ep_n)
         gr = self._ep_graphs.get(key)
         if gr is None:
             ids, lab = self._ep_ids[lo:lo + B], self._ep_lab[lo:lo + B]
@@ -565,7 +581,7 @@ class FusedPCGNN:
         if B <= 0:
             return
         self._lastB = B
-        key = (self._cur, lo, B, "timed")
+        key = (self._cur, lo, B, self._ep_n, "timed")
         grs = self._ep_graphs.get(key)
         ids, lab = self._ep_ids[lo:lo + B], self._ep_lab[lo:lo + B]
         g = self.g
@@ -701,6 +717,32 @@ class FusedPCGNN:
             self._cur_ready = False
         return n_steps
 
+    def read_batch_lists(self, b: int):
+        """The selection lists batch b of the staged epoch has in the workspace RIGHT NOW - what the last select launch on that
+        batch's plan slot wrote (the data part is shared by all batches: call it before another batch is selected) - copied to
+        the host: sets[r][i] for relation r, centre i.  Synchronises.  (bench.py's `verified`, tests.)"""
+        import numpy as np
+        g, lib = self.g, self.lib
+        lo = b * self._ep_bs
+        B = min(self._ep_bs, self._ep_n - lo)
+        rows = g.R * B
+        torch.cuda.synchronize(self.dev)
+        off = lambda which: int(lib.pcg_choose_workspace_offset(g.desc_ref(), B, self.list_capacity, which))
+        slot = self._ep_plans[b * self._ep_stride:(b + 1) * self._ep_stride]
+        begin = slot[off(0):off(0) + 8 * (rows + 1)].view(torch.int64).cpu().numpy()
+        length = slot[off(1):off(1) + 4 * rows].view(torch.int32).cpu().numpy()
+        d0 = off(2) - self._plan_bytes(B)
+        lst = self.data[d0:d0 + 4 * max(int(begin[-1]), 1)].view(torch.int32).cpu().numpy()
+        sets = []
+        for r in range(g.R):
+            row_sets = []
+            for i in range(B):
+                row = r * B + i
+                seg = lst[begin[row]:begin[row] + length[row]]
+                row_sets.append(set(seg[seg >= 0].tolist()))
+            sets.append(row_sets)
+        return sets
+
     def check(self):
         """Raise if any batch since the last check did not fit its selection list (the kernels then select nothing and
         only set the device status word), or a list named a row outside its table, or an in-kernel wait ran out.  Reads one
@@ -717,7 +759,8 @@ class FusedPCGNN:
         if st & _lib.PCG_ST_LIST_ID_RANGE:
             what.append("a selection list named a row outside the feature table")
         if st & _lib.PCG_ST_SYNC_TIMEOUT:
-            what.append("the select kernel's wait for its own train-pos sort ran out")
+            what.append("a bounded in-kernel wait ran out: the select kernel's wait for its own train-pos sort, or a plan "
+                        "workgroup's wait for its predecessors' totals")
         raise _lib.PcgnnLibraryError("; ".join(what) or f"device status {st}")
 
     def last_loss(self) -> torch.Tensor:

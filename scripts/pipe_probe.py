@@ -1,0 +1,284 @@
+"""Diagnostic: what does running the step's stages on SEPARATE streams buy?  (timing only)
+
+A step's selection (scores -> select_rows) needs nothing of the dense tail - the label classifier is stepped on its own - and
+the gather / dense tail of batch t need nothing of batch t + 1's selection.  So the chain select -> gather -> dense of a step can
+be a software pipeline over batches: the selection of batch t + 1 beside the gather + dense of batch t.  This probe replays the
+same kernels (the four-launch step's: pcg_step_scores | pcg_choose_select_planned | pcg_gather_lists_planned | pcg_train_dense)
+ - V0: on one stream, one hipGraph of E epochs;
+ - V1: on two streams inside one hipGraph (select chain | gather + dense chain), double-buffered lists / counts / aggregates;
+ - V2: on three streams (select | gather | dense);
+ - V3 / V4: V1 / V2 launched by the host without a graph.
+and prints microseconds per step.  PROBE_WORKLOAD=yelp|powerlaw, PROBE_B, PROBE_E (emb), PROBE_EPOCHS (epochs per graph)."""
+import sys, os, time, ctypes as C, torch, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import pcgnn_amd
+from pcgnn_amd import synth, ops, _lib
+from pcgnn_amd.handler import PCGNNTrainer
+_p = ops._p
+B = int(os.environ.get("PROBE_B", "1024"))
+E = int(os.environ.get("PROBE_E", "64"))
+EPG = int(os.environ.get("PROBE_EPOCHS", "4"))
+if os.environ.get("PROBE_WORKLOAD", "yelp") == "powerlaw":
+    w = synth.power_law(int(os.environ.get("PROBE_NODES", "2000000")), int(os.environ.get("PROBE_EDGES", "40000000")), 0)
+else:
+    w = synth.yelp_like(0)
+dev = torch.device("cuda", 0)
+tr = PCGNNTrainer(w, dict(engine="fused", batch_size=B, emb_size=E), dev)
+fz = tr.fused; g = fz.g; lib = _lib.load()
+nb = tr.batches_per_epoch()
+tr.start_epoch_staged()                       # ids / labels / plans of one epoch (set 0)
+torch.cuda.synchronize()
+n = tr.pick_size
+ids_all, lab_all = fz._ep_ids[:n], fz._ep_lab[:n]
+# double buffers: data part (list | partial sums), counts, aggregates
+data = [fz.data, torch.zeros_like(fz.data)]
+cnt = [torch.empty_like(fz.cnt), torch.empty_like(fz.cnt)]
+agg = [torch.empty_like(fz.agg), torch.empty_like(fz.agg)]
+b1, b2 = fz.betas
+
+
+def st(s):
+    return C.c_void_p(s.cuda_stream)
+
+
+def front(s):
+    _lib.check(lib.pcg_step_scores(g.desc_ref(), _p(fz.clf_next), C.c_void_p(fz.clf_next.data_ptr() + 8 * fz.F), 0, g.n_nodes, _p(fz.s0),
+                                   None, _p(fz.keys), -1, _p(fz.sync), None, st(s)), "scores")
+
+
+def batch(t):
+    b = t % nb
+    lo = b * B
+    Bt = min(B, n - lo)
+    return ids_all[lo:lo + Bt], lab_all[lo:lo + Bt], Bt, fz._ep_plan(b)
+
+
+def select(t, s):
+    ids, lab, Bt, plan = batch(t)
+    _lib.check(lib.pcg_choose_select_planned(g.desc_ref(), _p(ids), _p(lab), Bt, _p(fz.s0), None, _p(fz.keys), fz._thr, fz._rhos, 1, 0,
+                                             _p(cnt[t & 1]), _p(data[t & 1]), C.c_void_p(plan), fz.list_capacity, _p(fz.status), _p(fz.sync), 0,
+                                             st(s)), "select")
+
+
+def gather(t, s):
+    ids, lab, Bt, plan = batch(t)
+    a = agg[t & 1].view(-1)[:g.R * Bt * g.feat_dim].view(g.R, Bt, g.feat_dim)
+    _lib.check(lib.pcg_gather_lists_planned(_p(g.X), g.feat_dim, g.X.stride(0), g.n_nodes, g.R * Bt, _p(cnt[t & 1]), g.desc_ref(), Bt,
+                                            _p(data[t & 1]), C.c_void_p(plan), fz.list_capacity, _p(a), a.stride(-2), _p(fz.status), st(s)), "gather")
+
+
+def dense(t, s):
+    ids, lab, Bt, plan = batch(t)
+    a = agg[t & 1].view(-1)[:g.R * Bt * g.feat_dim].view(g.R, Bt, g.feat_dim)
+    _lib.check(lib.pcg_train_dense(g.desc_ref(), _p(fz.theta), _p(fz.m), _p(fz.v), fz.E, _p(ids), _p(lab), Bt, _p(a), a.stride(1),
+                                   _p(cnt[t & 1]), _p(data[t & 1]), C.c_void_p(plan), fz.list_capacity, fz.lambda_1, 1.0 / Bt, _p(fz.logits),
+                                   _p(fz.center), None, _p(fz.row_loss), _p(fz.slabs), _p(fz.step_counter), _p(fz.sync), fz.lr, b1, b2,
+                                   fz.eps, fz.wd, 2, st(s)), "dense")
+
+
+def seq(T, main):
+    for t in range(T):
+        front(main); select(t, main); gather(t, main); dense(t, main)
+
+
+def pipe2(T, A, Bs):
+    """A: front + select of every batch; Bs: gather + dense.  gather(t) waits for select(t); select(t + 2) waits for dense(t)."""
+    ev_sel, ev_den = {}, {}
+    for t in range(T):
+        if t >= 2:
+            A.wait_event(ev_den[t - 2])
+        front(A); select(t, A)
+        ev_sel[t] = torch.cuda.Event(); ev_sel[t].record(A)
+        Bs.wait_event(ev_sel[t])
+        gather(t, Bs); dense(t, Bs)
+        ev_den[t] = torch.cuda.Event(); ev_den[t].record(Bs)
+
+
+def pipe3(T, A, G, D):
+    ev_sel, ev_gat, ev_den = {}, {}, {}
+    for t in range(T):
+        if t >= 2:
+            A.wait_event(ev_den[t - 2])          # counts / list buffer t & 1 are free
+        front(A); select(t, A)
+        ev_sel[t] = torch.cuda.Event(); ev_sel[t].record(A)
+        G.wait_event(ev_sel[t])
+        if t >= 2:
+            G.wait_event(ev_den[t - 2])          # aggregates / partial sums t & 1 are free
+        gather(t, G)
+        ev_gat[t] = torch.cuda.Event(); ev_gat[t].record(G)
+        D.wait_event(ev_gat[t])
+        dense(t, D)
+        ev_den[t] = torch.cuda.Event(); ev_den[t].record(D)
+
+
+def timeit(fn, reps, steps_per_call, label):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"{label:70s} {dt / (reps * steps_per_call) * 1e6:8.2f} us/step  ({reps} x {steps_per_call} steps)", flush=True)
+
+
+T = EPG * nb
+main = torch.cuda.current_stream(dev)
+side1, side2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+# warm every kernel outside a capture
+seq(nb, main)
+torch.cuda.synchronize()
+
+def host2():
+    side1.wait_stream(main)
+    pipe2(T, main, side1)
+    main.wait_stream(side1)
+
+
+def host3():
+    side1.wait_stream(main); side2.wait_stream(main)
+    pipe3(T, main, side1, side2)
+    main.wait_stream(side1); main.wait_stream(side2)
+
+
+# ---- P2: the pipelined step - ONE launch [select(t+1) || gather(t) || adam(t-1) || clf(t+2) || scores(t+2)] + dense(t) --------
+cap = int(lib.pcg_pos_sort_capacity(g.n_pos)) // 2
+s0b = [fz.s0, torch.empty_like(fz.s0)]
+raw = [torch.zeros(cap, dtype=torch.int64, device=dev) for _ in range(2)]
+ring = torch.stack([fz.clf_next.clone() for _ in range(4)])
+clf_counter = torch.zeros(1, dtype=torch.int32, device=dev)
+sort_done = torch.zeros(2, dtype=torch.int32, device=dev)
+keep = []
+
+
+def pipe_launch(t, s, rows=True, gat=True, clf=True, score=True):
+    d = _lib.PipeDesc()
+    d.thresholds, d.rho = fz._thr, fz._rhos
+    d.list_capacity = fz.list_capacity
+    d.status, d.sync_words = fz.status.data_ptr(), fz.sync.data_ptr()
+    d.theta, d.m, d.v = fz.theta.data_ptr(), fz.m.data_ptr(), fz.v.data_ptr()
+    d.slabs, d.step_counter = fz.slabs.data_ptr(), fz.step_counter.data_ptr()
+    d.emb, d.apply_adam = fz.E, 1
+    d.lambda_1 = fz.lambda_1
+    d.lr, d.beta1, d.beta2, d.eps, d.weight_decay = fz.lr, b1, b2, fz.eps, fz.wd
+    d.pos_sorted = fz.keys.data_ptr()
+    if rows:
+        ids, lab, Bt, plan = batch(t + 1)
+        q = (t + 1) & 1
+        d.sel_nodes, d.sel_labels, d.sel_B, d.sel_plan = ids.data_ptr(), lab.data_ptr(), Bt, plan
+        d.sel_data, d.sel_cnt, d.sel_s0 = data[q].data_ptr(), cnt[q].data_ptr(), s0b[q].data_ptr()
+        d.sel_raw_keys, d.sel_sort_done = raw[q].data_ptr(), sort_done[q:].data_ptr()
+    if gat:
+        ids, lab, Bt, plan = batch(t)
+        q = t & 1
+        a = agg[0].view(-1)[:g.R * Bt * g.feat_dim].view(g.R, Bt, g.feat_dim)
+        d.gat_B, d.agg_stride, d.gat_plan, d.gat_data, d.gat_cnt, d.agg = Bt, a.stride(-2), plan, data[q].data_ptr(), cnt[q].data_ptr(), a.data_ptr()
+    if clf:
+        ids, lab, Bt, plan = batch(t + 2)
+        d.clf_nodes, d.clf_labels, d.clf_B = ids.data_ptr(), lab.data_ptr(), Bt
+        d.clf_inv_count = 1.0 / Bt
+        d.clf_in, d.clf_out, d.clf_counter = ring[(t + 2) % 4].data_ptr(), ring[(t + 3) % 4].data_ptr(), clf_counter.data_ptr()
+    if score:
+        d.clf_in = ring[(t + 2) % 4].data_ptr()
+        d.score_s0, d.score_raw_keys = s0b[t & 1].data_ptr(), raw[t & 1].data_ptr()
+    d.zero_word = sort_done[(t & 1):].data_ptr()
+    _lib.check(lib.pcg_pipe_step(g.desc_ref(), C.byref(d), st(s)), "pipe")
+
+
+def dense_p(t, s):
+    ids, lab, Bt, plan = batch(t)
+    a = agg[0].view(-1)[:g.R * Bt * g.feat_dim].view(g.R, Bt, g.feat_dim)
+    _lib.check(lib.pcg_train_dense(g.desc_ref(), _p(fz.theta), _p(fz.m), _p(fz.v), fz.E, _p(ids), _p(lab), Bt, _p(a), a.stride(1),
+                                   _p(cnt[t & 1]), _p(data[t & 1]), C.c_void_p(plan), fz.list_capacity, fz.lambda_1, 1.0 / Bt, _p(fz.logits),
+                                   _p(fz.center), None, _p(fz.row_loss), _p(fz.slabs), _p(fz.step_counter), _p(fz.sync), fz.lr, b1, b2,
+                                   fz.eps, fz.wd, 2, st(s)), "dense")
+
+
+def pipe_seq(T, s, parts=None):
+    kw = parts or {}
+    pipe_launch(-2, s, rows=False, gat=False)          # fill: clf(0), scores(0)
+    pipe_launch(-1, s, gat=False)                      # rows(0), clf(1), scores(1)
+    for t in range(T):
+        pipe_launch(t, s, **kw)
+        dense_p(t, s)
+
+
+def seq3(T, s):
+    """the current three-launch step (pcg_choose_gather_train + dense), for reference"""
+    fz._enqueue_refresh()
+    for t in range(T):
+        ids, lab, Bt, plan = batch(t)
+        a, _ = fz._enqueue_choose_train(ids, lab, Bt, plan, True)
+        fz._enqueue_tail(ids, lab, Bt, a, plan, True)
+
+
+pipe_seq(nb, main)
+torch.cuda.synchronize()
+print("status after an eager pipelined epoch:", int(fz.status.item()), flush=True)
+fz.status.zero_()
+grp = torch.cuda.CUDAGraph()
+with torch.cuda.graph(grp):
+    pipe_seq(T, torch.cuda.current_stream(dev))
+timeit(grp.replay, 40, T, f"P2 pipelined step: select_pipe + dense, one graph of {T} steps (+2 fill launches)")
+for name, parts in (("no gather", dict(gat=False)), ("no scores", dict(score=False)), ("no clf", dict(clf=False)), ("rows only", dict(gat=False, score=False, clf=False)),
+                    ("riders only", dict(rows=False))):
+    gq = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gq):
+        pipe_seq(T, torch.cuda.current_stream(dev), parts)
+    timeit(gq.replay, 40, T, f"P2 {name}")
+g3 = torch.cuda.CUDAGraph()
+seq3(nb, main)
+torch.cuda.synchronize()
+with torch.cuda.graph(g3):
+    seq3(T, torch.cuda.current_stream(dev))
+timeit(g3.replay, 40, T, f"R3 the three-launch step, one graph of {T} steps")
+print("status:", int(fz.status.item()), flush=True)
+fz.status.zero_()
+if os.environ.get("PROBE_STREAMS") != "1":
+    print("done")
+    sys.exit(0)
+timeit(lambda: seq(T, main), 10, T, "V0h one stream, host launches (python + ctypes)")
+timeit(host2, 10, T, "V3 two streams, host launches")
+timeit(host3, 10, T, "V4 three streams, host launches")
+gr0 = torch.cuda.CUDAGraph()
+with torch.cuda.graph(gr0):
+    seq(T, torch.cuda.current_stream(dev))
+timeit(gr0.replay, 40, T, f"V0 one stream, one graph of {T} steps (scores|select|gather|dense)")
+
+gr1 = torch.cuda.CUDAGraph()
+with torch.cuda.graph(gr1):
+    cs = torch.cuda.current_stream(dev)
+    s1 = torch.cuda.Stream(dev)
+    s1.wait_stream(cs)
+    pipe2(T, cs, s1)
+    cs.wait_stream(s1)
+timeit(gr1.replay, 40, T, f"V1 two streams inside one graph of {T} steps")
+
+if os.environ.get('PROBE_V2') == '1':
+  gr2 = torch.cuda.CUDAGraph()
+  with torch.cuda.graph(gr2):
+    cs = torch.cuda.current_stream(dev)
+    s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    s1.wait_stream(cs); s2.wait_stream(cs)
+    pipe3(T, cs, s1, s2)
+    cs.wait_stream(s1); cs.wait_stream(s2)
+  timeit(gr2.replay, 40, T, f"V2 three streams inside one graph of {T} steps")
+
+
+# graphs of a single epoch (how much of a forked graph's cost is per replay?)
+if EPG > 1:
+    gr1b = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr1b):
+        cs = torch.cuda.current_stream(dev)
+        s1 = torch.cuda.Stream(dev)
+        s1.wait_stream(cs)
+        pipe2(nb, cs, s1)
+        cs.wait_stream(s1)
+    timeit(gr1b.replay, 160, nb, f"V1b two streams inside one graph of {nb} steps")
+    gr0b = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr0b):
+        seq(nb, torch.cuda.current_stream(dev))
+    timeit(gr0b.replay, 160, nb, f"V0b one stream, one graph of {nb} steps")
+fz.status.zero_()
+print("done")
