@@ -15,15 +15,16 @@ N=1 workload: BASELINE.json configs[1] - YelpChi-shaped synthetic graph
 (N=45,954, F=32, 3 relations with 49,315 / 573,616 / 3,402,743 undirected edges,
 14.53 % positives, 40 % train), emb 64, batch 1024, rho 0.5.
 
-Graph engine (default at N=1): an epoch - sampler + plans + every batch's three launches
-(select_rows | gather_train_kernel | dense_step) - is ONE hipGraph launch; in the second
-epoch of the timed region and every `--event-every`-th after it the first
-`--timed-per-epoch` batches are launched kernel by kernel with HIP events around the
-pcg_choose_gather_train call (same kernels, same order; the rest of such an epoch is one
-graph replay per batch): those events give the `roofline` object (dominant call =
-select_rows + gather_train_kernel: selection, gather, the next step's score pass, the
-deferred Adam update; bytes: algorithmic_bytes()).  N>1: the destination-node
-partitioned path (pc-gnn_amd/dist.py), weak scaling.
+Graph engine (default at N=1): a GROUP of `--epochs-per-launch` epochs - one sampler launch (pick +
+shuffle + labels of all of them), one plan launch (every batch's plan), every batch's three launches
+(select_rows | gather_train_kernel | dense_step) - is ONE hipGraph launch.  The second group of the
+timed region and every `--event-every`-th after it (the only group, if the region holds but one) is
+event-bracketed: sampler and plans as launches of their own, the group's first batch kernel by kernel
+with HIP events around the pcg_choose_gather_train call (same kernels, same order), the rest of the
+group one graph launch; `--post-brackets` further epochs after the clock has stopped add one such
+bracket each.  Those events give the `roofline` object (dominant call = select_rows +
+gather_train_kernel: selection, gather, the next step's score pass, the deferred Adam update; bytes:
+algorithmic_bytes()).  N>1: the destination-node partitioned path (pc-gnn_amd/dist.py), weak scaling.
 
 Prints ONE JSON line (rank 0) with `roofline` and `cpu_baseline` (the oracle port timed
 on the host cores on the event-bracketed batches of the same run; rank 0, N=1 only).
@@ -62,12 +63,10 @@ def parse():
                     help="run the node-partitioned RCCL path even at world size 1 (rehearsal of the N>1 code)")
     ap.add_argument("--window", type=int, default=8, help="partitioned path: steps per halo prefetch (feature rows never change, "
                     "so the remote rows of a window's centres are fetched once)")
-    ap.add_argument("--timed-graphs", action="store_true", help="event-bracketed steps as three graph launches instead of five "
-                    "kernel launches (the middle graph's launch latency then lands inside the bracket)")
-    ap.add_argument("--timed-per-epoch", type=int, default=1, help="batches of an event-bracketed epoch that are launched kernel by "
-                    "kernel with HIP events (the rest of that epoch: one graph replay per batch)")
+    ap.add_argument("--epochs-per-launch", type=int, default=4, help="graph engine: epochs sampled, planned and replayed together (one "
+                    "sampler launch, one plan launch, one graph launch per group; 1 = epoch by epoch)")
     ap.add_argument("--event-every", type=int, default=3,
-                    help="graph engine: bracket the select+aggregate launch with HIP events on every step of every Nth epoch")
+                    help="graph engine: bracket the select+aggregate launch of the first batch of every Nth group of epochs with HIP events")
     ap.add_argument("--list-capacity", type=int, default=None, help="entries of the selection list (default: the graph's worst case); "
                     "a value too small for a batch makes the run exit non-zero (the status word is checked after the timed region)")
     ap.add_argument("--report-epochs", type=int, default=7, help="graph engine: epochs timed one by one AFTER the timed region "
@@ -75,13 +74,9 @@ def parse():
                     "medians (SURVEY 8d); 0 = skip")
     ap.add_argument("--post-brackets", type=int, default=8, help="graph engine: epochs run AFTER the timed region whose first batch is "
                     "launched kernel by kernel with HIP events around pcg_choose_gather_train: further samples for `roofline` "
-                    "(the timed region itself brackets one batch every --event-every epochs); 0 = none")
+                    "(the timed region itself brackets one batch every --event-every groups of epochs); 0 = none")
     ap.add_argument("--verify-batches", type=int, default=1, help="batches whose chosen sets are checked after the clock stops "
                     "(count law on every row, the oracle's sets on a strided sample); 0 = skip")
-    ap.add_argument("--prefetch", nargs="?", const="graph", default="off", choices=["off", "graph", "stream"],
-                    help="graph engine: sampler + plans of the NEXT epoch beside an epoch's steps: `graph` = on a parallel branch of "
-                         "the epoch's graph, `stream` = enqueued by the host on a second stream (two events per epoch); off = in "
-                         "front of the epoch's steps, inside its graph")
     ap.add_argument("--engine", default=None, choices=["graph", "fused", "torch", "dp"],
                     help="graph: fused HIP step replayed from a hipGraph (default at 1 GPU); fused: same kernels "
                          "launched eagerly (default at N>1, gradient all-reduce in between); torch: torch dense tail")
@@ -486,25 +481,18 @@ def main():
                     p.grad.copy_(flat[o:o + p.numel()].view_as(p))
                     o += p.numel()
             tr.opt.step()
-        elif epoch_graphs and timed:   # the staged batch launched kernel by kernel with HIP events around select + gather
-            tr.fused.epoch_step_timed(state["b"] - 1, eager=not args.timed_graphs)
-        elif epoch_graphs:             # the staged batch as one graph replay (a batch that is not part of a whole-epoch replay)
-            tr.fused.epoch_step(state["b"] - 1, defer=True)
-        elif dist is None:        # (graph engine: the per-batch graphs; whole epochs go through run_epoch_one_graph below)
+        elif dist is None:        # (graph engine without epoch graphs: one per-batch graph replay)
             tr.step(ids, timed)
         else:
             tr.fused.train_step(ids, tr.labels_i32[ids.long()], allreduce=allreduce)
 
     state = {"epoch": 0, "ids": None, "b": 0}
     nb = tr.batches_per_epoch()
-    epoch_graphs = engine == "graph" and dist is None and not args.no_epoch_graphs   # ids/labels of an epoch in static buffers, 1 launch per step
+    epoch_graphs = engine == "graph" and dist is None and not args.no_epoch_graphs   # ids/labels of whole epochs in static buffers, 1 launch per group of epochs
 
     def next_batch():
         if state["ids"] is None or state["b"] == nb:
-            if epoch_graphs:     # pick + shuffle + labels in one launch, straight into the epoch's static buffers
-                state["ids"] = tr.start_epoch_staged()
-            else:
-                state["ids"] = tr.start_epoch(state["epoch"])      # pick + shuffle on the device
+            state["ids"] = tr.start_epoch(state["epoch"])      # pick + shuffle on the device
             state["epoch"] += 1
             state["b"] = 0
         b = state["b"]
@@ -516,113 +504,69 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    PREFETCH = {"off": False, "graph": True, "stream": "stream"}[args.prefetch]
     warmup = args.warmup
-    if epoch_graphs:                       # capture every graph (per-slot and whole-epoch) untimed
-        warmup = max(warmup, 2 * nb + 2)
-
     inter = tr.model.inter1
     prof = tr.fused if tr.fused is not None else inter
     used_ev, counted = [], {"nodes": 0}
+    # graph engine: K epochs are sampled, planned and replayed together - one sampler launch, one plan launch and one graph launch
+    # per K * nb steps (the plan slots of a group must fit a few GB: large graphs fall back to K = 1)
+    K = 1
+    if epoch_graphs:
+        slot = tr.fused._plan_bytes(B)
+        K = max(1, min(args.epochs_per_launch, (3 << 30) // max(2 * nb * slot, 1)))
+    G = K * nb
 
     def run_steps(n_steps, measure):
-        """n_steps training steps.  Graph engine: the first `timed_per_epoch` batches of every `event_every`-th epoch are
-        launched kernel by kernel with HIP events around select + gather (the same kernels in the same order), the other
-        batches of such an epoch are one graph replay each; every other epoch that fits into the remaining steps is ONE
-        graph launch."""
-        k = 0
-        phase = {"epochs": 0 if (state["ids"] is None or state["b"] == nb) else 1}
-        while k < n_steps:
-            at_epoch_start = state["ids"] is None or state["b"] == nb
-            if at_epoch_start:
-                phase["epochs"] += 1
-            # the SECOND epoch of a phase (warm-up, measurement) and every event_every-th after it are event-bracketed: the phase
-            # starts from an idle device (a barrier), and behind a whole-epoch graph launch the host is far enough ahead for the
-            # kernel-by-kernel launches of a bracketed epoch not to leave the device waiting
-            # (a phase shorter than two epochs brackets its first one)
-            first_timed = 2 if n_steps >= 2 * nb else 1
-            timed_epoch = engine != "graph" or (phase["epochs"] - first_timed) % args.event_every == 0
-            if epoch_graphs and at_epoch_start and not timed_epoch and k + nb <= n_steps:
-                tr.run_epoch_one_graph(flush=False, prefetch=PREFETCH)  # pick + shuffle + labels + plans + every batch's step: one graph launch (the
-                                                     # last batch's deferred Adam update is applied by the next gather launch, or
-                                                     # by the flush that ends the timed region)
-                state["ids"], state["b"] = tr.fused._ep_ids[:tr.pick_size], nb
-                state["epoch"] += 1
-                if measure:
-                    counted["nodes"] += tr.pick_size
-                k += nb
-                continue
-            if epoch_graphs and at_epoch_start and not timed_epoch and not PREFETCH:
-                # the run's last, partial epoch: its n_steps - k batches (sampler and plans in front) are one graph launch too
-                r = n_steps - k
-                done = tr.run_epoch_one_graph(flush=False, n_steps=r)
-                state["ids"], state["b"] = tr.fused._ep_ids[:tr.pick_size], r
-                state["epoch"] += 1
-                if measure:
-                    counted["nodes"] += done
-                k += r
-                continue
-            if (epoch_graphs and not at_epoch_start and timed_epoch and not PREFETCH and state["b"] >= args.timed_per_epoch
-                    and k + (nb - state["b"]) <= n_steps):
-                # an event-bracketed epoch behind its bracketed batches: the rest of its batches are one graph launch
-                b0 = state["b"]
-                tr.fused.epoch_run(first_step=b0, flush=False)
-                state["b"] = nb
-                if measure:
-                    counted["nodes"] += tr.pick_size - b0 * B
-                k += nb - b0
-                continue
+        """n_steps training steps, batch by batch (every engine but the whole-epoch graph engine)."""
+        for _ in range(n_steps):
             ids = next_batch()
-            # (also during the warm-up, so that every graph is captured before the clock starts.)  With epoch graphs the first
-            # `timed_per_epoch` batches of an event-bracketed epoch are launched kernel by kernel with events; every other batch
-            # that is not part of a whole-epoch replay is one per-batch graph replay
-            timed = timed_epoch and (not epoch_graphs or state["b"] <= args.timed_per_epoch)
-            one_step(ids, timed)
+            one_step(ids, True)
             if measure:
-                if timed:
-                    used_ev.append((ids.clone(), prof.last_counts.clone()))
+                used_ev.append((ids.clone(), prof.last_counts.clone()))
                 counted["nodes"] += int(ids.numel())
-            k += 1
+
+    def run_groups(n_steps, measure):
+        """n_steps training steps of the graph engine, in groups of K epochs (G = K * nb steps; the last group may be cut short).
+        A group is ONE graph launch: sampler (pick + shuffle + labels of K epochs), plans of all its batches, every batch's three
+        launches.  The second group of a phase and every `event_every`-th after it (the only group, if there is but one) is
+        event-bracketed instead: sampler and plans as launches of their own - the host gets ahead of the device behind them -,
+        the group's FIRST batch kernel by kernel with HIP events around pcg_choose_gather_train (the same kernels in the same
+        order), the rest of the group one graph launch."""
+        fz = tr.fused
+        k, gi = 0, 0
+        first_timed = 1 if n_steps > G else 0
+        while k < n_steps:
+            r = min(G, n_steps - k)
+            if (gi - first_timed) % args.event_every == 0:
+                ids_all = tr.start_epoch_staged(K)
+                fz.epoch_step_timed(0, eager=True)
+                if measure:
+                    used_ev.append((ids_all[:fz._ep_batches[0][1]].clone(), fz.last_counts.clone()))
+                if r > 1:
+                    fz.epoch_run(first_step=1, n_steps=r, flush=False)
+            else:
+                tr.run_epoch_one_graph(flush=False, n_steps=r, n_epochs=K)
+            if measure:
+                counted["nodes"] += tr.nodes_of_steps(r)
+            k += r
+            gi += 1
 
     prof._prof = []
     if epoch_graphs:
-        # every graph the timed region can replay is captured here: the whole-epoch graph in each of its variants (buffer set
-        # 0 / 1; with the next epoch's sampler on a parallel branch: sampling its own epoch first or finding it prepared) and the
-        # per-batch graphs of both buffer sets
-        def whole():
-            tr.run_epoch_one_graph(flush=False, prefetch=PREFETCH)
-            state["epoch"] += 1
-            return nb
-
-        def batchwise():
-            tr.start_epoch_staged()
-            for b in range(nb):
-                tr.fused.epoch_step(b, defer=True)
-            state["epoch"] += 1
-            return nb
-        seq = (whole, whole, batchwise, whole, batchwise, whole, whole) if PREFETCH else (whole, batchwise)
-        warmup = sum(f() for f in seq)
-        state["ids"], state["b"] = None, 0
-        run_steps(2 * nb + 2, False)           # ... and one pass through the timed region's own sequence (bracketed epoch included)
-        warmup += 2 * nb + 2
-        while state["b"] != nb:                # (finish the partial epoch the pass ended in)
-            one_step(next_batch())
-            warmup += 1
-        if args.steps % nb not in (0, 2) and not PREFETCH:      # the partial-epoch graph of THIS run's last epoch (2: captured above)
-            r = args.steps % nb
-            tr.run_epoch_one_graph(flush=False, n_steps=r)
-            state["ids"], state["b"] = tr.fused._ep_ids[:tr.pick_size], r
-            state["epoch"] += 1
-            warmup += r
-        while state["b"] != nb:                # the warm-up ends at an epoch boundary
-            one_step(next_batch())
-            warmup += 1
+        # one untimed pass through the timed region's own sequence: every graph the region replays (whole groups, the bracketed
+        # group's tail, the last, shorter group) is captured here
+        run_groups(args.steps, False)
+        tr.fused.flush()
+        warmup = args.steps
+        if args.warmup > warmup:
+            run_groups(args.warmup - warmup, False)
+            warmup = args.warmup
     else:
         run_steps(warmup, False)
     prof._prof = []                                    # (start, end) HIP events around the select + aggregate launch
     barrier()
     t0 = time.perf_counter()
-    run_steps(args.steps, True)
+    (run_groups if epoch_graphs else run_steps)(args.steps, True)
     if tr.fused is not None:
         tr.fused.flush()                               # every step's update is applied inside the timed region
     barrier()
@@ -680,13 +624,13 @@ def main():
             "timed_window": "every step = the reference's per-batch window (src/model_handler.py:143-155); the sampler - pick + "
                             "shuffle + label lookup (:130-133), one launch per epoch - runs INSIDE the timed region at every "
                             "epoch start, so `value` is the pick-inclusive figure (there is no separate pick-exclusive one); "
-                            "warm-up extended beyond --warmup so that every hipGraph is captured before the clock starts",
+                            "warm-up = one untimed pass through the timed region's own launch sequence (so that every hipGraph it replays is captured before the clock starts), extended to --warmup if that is longer",
             "config": {"workload": f"{w.name} N={w.n} F={w.X.shape[1]} R={len(w.csr)} "
                                    f"edges={'/'.join(str(e) for e in w.meta['rel_edges'])} "
                                    f"endpoints={w.meta['endpoints']}, PCGNN emb={args.emb} batch={B} rho={args.rho}, "
                                    f"pick 2*|train_pos|={tr.pick_size}/epoch",
                        "global_batch": B * world, "parallelism": "single" if world == 1 else f"dp{world}-replicated-graph",
-                       "engine": engine,
+                       "engine": engine, "epochs_per_launch": K if epoch_graphs else None,
                        "nodes_processed": int(nodes_total)},
             "roofline": {"bound": "hbm", "kernel": "pcg_choose_gather_train: select_rows (sorts the train positives, steps the label classifier for this batch) + gather_train_kernel (gather || the other parameters' deferred Adam update || the NEXT step's score pass and train-pos keys); the plan is made per epoch beside the sampler, multi-chunk sums are finished in the dense kernel's prologue; bytes = select + gather + U x F feature rows scored + optimizer state (algorithmic_bytes)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -696,7 +640,7 @@ def main():
                          "algorithmic_bytes_per_launch": float(np.mean(abytes)),
                          "launches_timed": len(kern_ms), "launches_timed_inside_the_timed_region": n_in_region,
                          "launches_how": "HIP events around the call's two kernels; the timed region brackets the first batch of its "
-                                         "second epoch and of every --event-every-th after it, --post-brackets further epochs "
+                                         "second group of epochs (its only one, if there is but one) and of every --event-every-th after it, --post-brackets further epochs "
                                          "after the clock has stopped add one bracket each (same launches, same graphs around them)"},
         }
         if report is not None:

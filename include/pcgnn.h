@@ -211,6 +211,12 @@ int pcg_choose_select_planned(const pcg_graph_desc *g, const int32_t *nodes, con
 int pcg_plan_batches(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t n_total, int32_t B,
                      const double *thresholds, const double *rho, int32_t train_flag, int32_t add_self, void *plans,
                      int64_t plan_stride, int64_t list_capacity, uint32_t *status, uint64_t *bump_counter, void *stream);
+/* pcg_plan_batches for n_epochs epochs at once - epoch e's n_total picks at nodes + e * n_total (labels likewise), its batches in
+ * slots e * ceil(n_total / B) ..., every epoch's last batch the shorter one: the launch's latency chain (two dependent load
+ * levels and a hand-off) is paid once per n_epochs epochs.  bump_counter += n_epochs. */
+int pcg_plan_epochs(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t n_total, int32_t n_epochs, int32_t B,
+                    const double *thresholds, const double *rho, int32_t train_flag, int32_t add_self, void *plans,
+                    int64_t plan_stride, int64_t list_capacity, uint32_t *status, uint64_t *bump_counter, void *stream);
 /* select + gather WITHOUT the combine launch (two launches): rows whose list fits one 128-entry gather chunk are finished
  * (their mean is in agg), longer rows are left as per-chunk partial sums in the workspace; pcg_train_dense, given the same
  * workspace and cnt, adds them up in chunk order (bit-identical to pcg_choose_aggregate_planned's agg) while it stages its
@@ -315,6 +321,12 @@ int pcg_pick(const double *cum, const int32_t *idx_train, int32_t n_train,
 int pcg_pick_shuffled(const double *cum, const int32_t *idx_train, int32_t n_train, uint64_t seed, uint64_t epoch_base,
                       uint64_t *epoch_counter, int32_t bump, int32_t k, const int32_t *labels_all, int32_t *out_ids,
                       int32_t *out_labels, void *stream);
+
+/* pcg_pick_shuffled for n_epochs consecutive epochs in one launch: epoch e (= epoch_base + epoch_counter[0] + e) is drawn and
+ * shuffled exactly as a call of its own would, into out_ids + e * k / out_labels + e * k; bump != 0: epoch_counter[0] += n_epochs. */
+int pcg_pick_shuffled_epochs(const double *cum, const int32_t *idx_train, int32_t n_train, uint64_t seed, uint64_t epoch_base,
+                             uint64_t *epoch_counter, int32_t bump, int32_t n_epochs, int32_t k, const int32_t *labels_all,
+                             int32_t *out_ids, int32_t *out_labels, void *stream);
 
 /* ---- dense tail: relation / inter GEMMs, classifier, loss, backward, Adam ---------------
  * Parameters live in ONE flat f32 buffer `theta` in this order (offsets from

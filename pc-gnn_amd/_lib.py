@@ -68,6 +68,9 @@ PROTOTYPES = {
     "pcg_choose_data_bytes": (_I64, [_G, _I32, _I64]),
     "pcg_plan_batches": (C.c_int, [_G, _P, _P, _I32, _I32, C.POINTER(_F64), C.POINTER(_F64), _I32, _I32, _P, _I64, _I64, _P, _P,
                                    _P]),
+    "pcg_plan_epochs": (C.c_int, [_G, _P, _P, _I32, _I32, _I32, C.POINTER(_F64), C.POINTER(_F64), _I32, _I32, _P, _I64, _I64, _P, _P,
+                                  _P]),
+    "pcg_pick_shuffled_epochs": (C.c_int, [_P, _P, _I32, _U64, _U64, _P, _I32, _I32, _I32, _P, _P, _P, _P]),
     "pcg_pos_sort_in_select": (_I32, [_I32]),
     "pcg_sync_words_count": (_I32, []),
     "pcg_aggregate_lists_planned": (C.c_int, [_P, _I32, _I32, _I64, _I32, _P, _G, _I32, _P, _P, _I64, _I32, _P, _I32, _P, _P]),

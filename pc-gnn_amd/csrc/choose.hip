@@ -400,7 +400,7 @@ __global__ void __launch_bounds__(PLAN_THREADS) plan_write(const ChooseArgs a, c
 //  a copy, or an argument whose address is taken, lives in scratch)
 constexpr int H_PLAN_SEQ = 12;           // word of Workspace::heads
 constexpr int PLAN_SPIN_MAX = 1 << 21;
-__device__ __forceinline__ void plan_slot(const ChooseArgs &a, int s, int block, int64_t stride, int64_t full_B) {
+__device__ __forceinline__ void plan_slot(const ChooseArgs &a, int s, int block, int64_t stride, int64_t node_off) {
     __shared__ int4 lds4[PLAN_THREADS / PCG_WAVE];
     __shared__ long long s_part[PCG_WAVE][8];
     __shared__ long long s_run[8];
@@ -416,7 +416,7 @@ __device__ __forceinline__ void plan_slot(const ChooseArgs &a, int s, int block,
     SLOT_STAMP(0);
     // ---- 1. this workgroup's rows: records, totals; the totals are published at once
     const int row = block * PLAN_THREADS + tid;
-    RowRec rec = row_plan(a, row < rows ? row : rows - 1, (int64_t)s * full_B);
+    RowRec rec = row_plan(a, row < rows ? row : rows - 1, node_off);
     const int cap = row < rows ? rec_cap(rec, a.add_self) : 0;
     const int nch = (cap + CHUNK - 1) / CHUNK;
     const int tier = row < rows ? row_tier(rec.d, rec.m > 0 || a.add_self) : -1;
@@ -505,14 +505,19 @@ __device__ __forceinline__ void plan_slot(const ChooseArgs &a, int s, int block,
     SLOT_STAMP(3);
 #undef SLOT_STAMP
 }
+// Several epochs' batches in one launch (pcg_plan_epochs): slot s = batch s % slots_per_epoch of epoch s / slots_per_epoch, whose
+// picks start at nodes[epoch * epoch_nodes]; an epoch's last batch (tail_b, or -1) may be the shorter one.  bump += bump_by.
 __global__ void __launch_bounds__(PLAN_THREADS) plan_batches_kernel(const ChooseArgs full, const ChooseArgs tail, int n_slots,
-                                                                    int tail_slot, int64_t stride, int nb_full,
-                                                                    unsigned long long *__restrict__ bump) {
-    if (blockIdx.x == 0 && threadIdx.x == 0 && bump) bump[0] += 1ull;
+                                                                    int tail_b, int64_t stride, int nb_full,
+                                                                    unsigned long long *__restrict__ bump, int slots_per_epoch,
+                                                                    int64_t epoch_nodes, int bump_by) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && bump) bump[0] += (unsigned long long)bump_by;
     const int s = (int)blockIdx.x / nb_full, block = (int)blockIdx.x - s * nb_full;
     if (s >= n_slots) return;
-    if (s == tail_slot) plan_slot(tail, s, block, stride, full.B);
-    else plan_slot(full, s, block, stride, full.B);
+    const int e = s / slots_per_epoch, b = s - e * slots_per_epoch;
+    const int64_t node_off = (int64_t)e * epoch_nodes + (int64_t)b * full.B;
+    if (b == tail_b) plan_slot(tail, s, block, stride, node_off);
+    else plan_slot(full, s, block, stride, node_off);
 }
 
 // The front of a training step in two launches instead of four: the plan's two passes ride along the score pass
@@ -742,10 +747,20 @@ int pcg_choose_select_planned(const pcg_graph_desc *g, const int32_t *nodes, con
 int pcg_plan_batches(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t n_total, int32_t B,
                      const double *thresholds, const double *rho, int32_t train_flag, int32_t add_self, void *plans,
                      int64_t plan_stride, int64_t list_capacity, uint32_t *status, uint64_t *bump_counter, void *stream) {
-    if (!g || n_total < 0 || B < 1 || !plans || plan_stride < 0 || (plan_stride & 255) != 0) return PCG_E_ARG;
+    return pcg_plan_epochs(g, nodes, labels, n_total, 1, B, thresholds, rho, train_flag, add_self, plans, plan_stride, list_capacity,
+                           status, bump_counter, stream);
+}
+
+/* The plans of every batch of n_epochs epochs of n_total picks each (epoch e's picks at nodes + e * n_total): ONE launch. */
+int pcg_plan_epochs(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t n_total, int32_t n_epochs, int32_t B,
+                    const double *thresholds, const double *rho, int32_t train_flag, int32_t add_self, void *plans,
+                    int64_t plan_stride, int64_t list_capacity, uint32_t *status, uint64_t *bump_counter, void *stream) {
+    if (!g || n_total < 0 || n_epochs < 1 || B < 1 || !plans || plan_stride < 0 || (plan_stride & 255) != 0) return PCG_E_ARG;
     if (n_total == 0) return PCG_OK;
-    const int n_slots = (n_total + B - 1) / B;
-    const int B_tail = n_total - (n_slots - 1) * B;
+    const int slots_per_epoch = (n_total + B - 1) / B;
+    if ((int64_t)slots_per_epoch * n_epochs > (1 << 20)) return PCG_E_ARG;
+    const int n_slots = slots_per_epoch * n_epochs;
+    const int B_tail = n_total - (slots_per_epoch - 1) * B;
     if (n_slots > 1 && plan_stride < pcg::carve(g, B, list_capacity, nullptr, nullptr, nullptr).plan_bytes) return PCG_E_ARG;
     // (the data part is not touched by the plan: any non-null base will do for the argument check)
     pcg::ChooseArgs full, tail;
@@ -756,10 +771,11 @@ int pcg_plan_batches(const pcg_graph_desc *g, const int32_t *nodes, const int32_
                      list_capacity, status, true, plans);
     if (rc != PCG_OK) return rc;
     const int nb_full = (g->n_rel * B + pcg::PLAN_THREADS - 1) / pcg::PLAN_THREADS;
-    const int tail_slot = B_tail == B ? -1 : n_slots - 1;
+    const int tail_b = B_tail == B ? -1 : slots_per_epoch - 1;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(pcg::plan_batches_kernel, dim3(n_slots * nb_full), dim3(pcg::PLAN_THREADS), 0, st, full, tail, n_slots, tail_slot,
-                       plan_stride, nb_full, reinterpret_cast<unsigned long long *>(bump_counter));
+    hipLaunchKernelGGL(pcg::plan_batches_kernel, dim3(n_slots * nb_full), dim3(pcg::PLAN_THREADS), 0, st, full, tail, n_slots, tail_b,
+                       plan_stride, nb_full, reinterpret_cast<unsigned long long *>(bump_counter), slots_per_epoch, (int64_t)n_total,
+                       (int)n_epochs);
     PCG_LAUNCH_CHECK();
     return PCG_OK;
 }

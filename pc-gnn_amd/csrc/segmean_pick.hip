@@ -192,7 +192,10 @@ __global__ void __launch_bounds__(256) pick_shuffled_kernel(const double *__rest
                                                             const unsigned long long *__restrict__ epoch_counter, int k, int bits,
                                                             const int32_t *__restrict__ labels_all, int32_t *__restrict__ out_ids,
                                                             int32_t *__restrict__ out_labels) {
-    const uint64_t epoch = epoch_base + (epoch_counter ? *epoch_counter : 0ull);
+    // (blockIdx.y: one of several epochs drawn in one launch - pcg_pick_shuffled_epochs; its k draws at out + blockIdx.y * k)
+    const uint64_t epoch = epoch_base + (epoch_counter ? *epoch_counter : 0ull) + blockIdx.y;
+    out_ids += (size_t)blockIdx.y * k;
+    if (out_labels) out_labels += (size_t)blockIdx.y * k;
     const int dl = threadIdx.x >> 4, sub = threadIdx.x & 15;          // draw slot 0..15, lane in the group
     const int di = blockIdx.x * 16 + dl;
     const double u = philox_uniform(seed, epoch, (uint32_t)(di < k ? di : 0));
@@ -205,7 +208,7 @@ __global__ void __launch_bounds__(256) pick_shuffled_kernel(const double *__rest
     }
 }
 
-__global__ void bump_counter_kernel(unsigned long long *counter) { *counter += 1ull; }
+__global__ void bump_counter_kernel(unsigned long long *counter, int by) { *counter += (unsigned long long)by; }
 
 }  // namespace pcg
 
@@ -236,19 +239,26 @@ int pcg_pick(const double *cum, const int32_t *idx_train, int32_t n_train, const
 int pcg_pick_shuffled(const double *cum, const int32_t *idx_train, int32_t n_train, uint64_t seed, uint64_t epoch_base,
                       uint64_t *epoch_counter, int32_t bump, int32_t k, const int32_t *labels_all, int32_t *out_ids,
                       int32_t *out_labels, void *stream) {
-    if (!cum || !idx_train || !out_ids || n_train < 1 || k < 0) return PCG_E_ARG;
+    return pcg_pick_shuffled_epochs(cum, idx_train, n_train, seed, epoch_base, epoch_counter, bump, 1, k, labels_all, out_ids, out_labels,
+                                    stream);
+}
+
+int pcg_pick_shuffled_epochs(const double *cum, const int32_t *idx_train, int32_t n_train, uint64_t seed, uint64_t epoch_base,
+                             uint64_t *epoch_counter, int32_t bump, int32_t n_epochs, int32_t k, const int32_t *labels_all,
+                             int32_t *out_ids, int32_t *out_labels, void *stream) {
+    if (!cum || !idx_train || !out_ids || n_train < 1 || k < 0 || n_epochs < 1 || n_epochs > 65535) return PCG_E_ARG;
     if (out_labels && !labels_all) return PCG_E_ARG;
     if (bump && !epoch_counter) return PCG_E_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (k > 0) {
         int bits = 0;
         while ((1ll << bits) < (long long)k) ++bits;
-        hipLaunchKernelGGL(pcg::pick_shuffled_kernel, dim3((k + 15) / 16), dim3(256), 0, st, cum, idx_train, n_train, seed, epoch_base,
+        hipLaunchKernelGGL(pcg::pick_shuffled_kernel, dim3((k + 15) / 16, n_epochs), dim3(256), 0, st, cum, idx_train, n_train, seed, epoch_base,
                            reinterpret_cast<const unsigned long long *>(epoch_counter), k, bits, labels_all, out_ids, out_labels);
         PCG_LAUNCH_CHECK();
     }
     if (bump) {       // a second, one-thread launch: a ticket per workgroup would be thousands of same-address atomics
-        hipLaunchKernelGGL(pcg::bump_counter_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<unsigned long long *>(epoch_counter));
+        hipLaunchKernelGGL(pcg::bump_counter_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<unsigned long long *>(epoch_counter), n_epochs);
         PCG_LAUNCH_CHECK();
     }
     return PCG_OK;

@@ -176,11 +176,13 @@ class FusedPCGNN:
         return buf
 
     # ------------------------------------------------------------------
-    def _enqueue_plan(self, ids, labels, n_total, B, plans: torch.Tensor, stride: int, train_flag, bump_counter=None):
-        """the plans of the batches ids[s * B : (s + 1) * B] (s < ceil(n_total / B)), one launch"""
-        _lib.check(self.lib.pcg_plan_batches(
-            self.g.desc_ref(), _p(ids), _p(labels if train_flag else None), n_total, B, self._thr, self._rhos, 1 if train_flag else 0, 0,
-            _p(plans), stride, self.list_capacity, _p(self.status), _p(bump_counter), self._stream()), "pcg_plan_batches")
+    def _enqueue_plan(self, ids, labels, n_total, B, plans: torch.Tensor, stride: int, train_flag, bump_counter=None, n_epochs: int = 1):
+        """the plans of the batches ids[s * B : (s + 1) * B] (s < ceil(n_total / B)) - of every one of n_epochs epochs of n_total
+        picks each -, one launch"""
+        _lib.check(self.lib.pcg_plan_epochs(
+            self.g.desc_ref(), _p(ids), _p(labels if train_flag else None), n_total, n_epochs, B, self._thr, self._rhos,
+            1 if train_flag else 0, 0, _p(plans), stride, self.list_capacity, _p(self.status), _p(bump_counter), self._stream()),
+            "pcg_plan_epochs")
 
     def _enqueue_plan_one(self, ids, labels, B, train_flag) -> int:
         """plan of ONE batch into this batch size's own slot (+ its touched-row map); returns the slot's address"""
@@ -474,27 +476,32 @@ class FusedPCGNN:
     def _ep_plans(self):
         return None if self._ep_sets is None else self._ep_sets[self._cur]["plans"]
 
-    def stage_epoch(self, n: int, batch_size: int):
-        """Static id / label buffers and plan slots of an epoch of n picks (the ids are filled by begin_epoch or by a
-        sampler; ``plan_staged()`` must follow before any of the epoch's steps runs).  Returns the CURRENT set's (ids, labels)."""
+    def stage_epoch(self, n: int, batch_size: int, n_epochs: int = 1):
+        """Static id / label buffers and plan slots of n_epochs epochs of n picks each (the ids are filled by begin_epoch or by a
+        sampler; ``plan_staged()`` must follow before any of the staged steps runs).  Several epochs staged together are sampled
+        and planned by ONE launch each - the sampler's and the plan's latency chains are paid once per n_epochs epochs - and are
+        walked as one sequence of batches 0 .. n_epochs * ceil(n / batch_size) - 1 (every epoch's last batch may be the shorter
+        one).  Returns the CURRENT set's (ids, labels), n_epochs * n long."""
         if batch_size > self.maxB:
             self.flush()
             self._alloc(batch_size)
-        nb = -(-n // batch_size)
+        nb_e = -(-n // batch_size)
+        nb, total = nb_e * n_epochs, n * n_epochs
         stride = self._plan_bytes(batch_size)
         sets = self._ep_sets
-        if sets is None or sets[0]["ids"].numel() < n or self._ep_stride != stride or sets[0]["plans"].numel() < nb * stride:
+        if sets is None or sets[0]["ids"].numel() < total or self._ep_stride != stride or sets[0]["plans"].numel() < nb * stride:
             if torch.cuda.is_current_stream_capturing():
                 raise _lib.PcgnnLibraryError("stage_epoch with a new shape inside a graph capture")
-            self._ep_sets = [dict(ids=torch.zeros(n, dtype=torch.int32, device=self.dev),
-                                  lab=torch.zeros(n, dtype=torch.int32, device=self.dev),
+            self._ep_sets = [dict(ids=torch.zeros(total, dtype=torch.int32, device=self.dev),
+                                  lab=torch.zeros(total, dtype=torch.int32, device=self.dev),
                                   plans=torch.zeros(nb * stride, dtype=torch.uint8, device=self.dev),
                                   touched=torch.zeros(nb * self._touch_stride, dtype=torch.uint8, device=self.dev)
                                   if self.touched_on else None) for _ in range(2)]
             self._ep_stride = stride
             self._cur, self._cur_ready = 0, False
             self._ep_graphs.clear()
-        if (getattr(self, "_ep_n", n), getattr(self, "_ep_bs", batch_size)) != (n, batch_size):
+        shape = (n, batch_size, n_epochs)
+        if getattr(self, "_ep_shape", shape) != shape:
             # another epoch shape inside the same buffers: the last batch's (shorter) plan layout moves to another slot, and the
             # plan launch's look-back tags (a small integer per workgroup) would sit on top of whatever the old layout left
             # there - zero the slots so that no stale word can pass for a published total
@@ -503,8 +510,11 @@ class FusedPCGNN:
             for st in self._ep_sets:
                 st["plans"].zero_()
             self._ep_graphs.clear()
-        self._ep_n, self._ep_bs = n, batch_size
-        return self._ep_ids[:n], self._ep_lab[:n]
+        self._ep_shape = shape
+        self._ep_n, self._ep_bs, self._ep_k = n, batch_size, n_epochs
+        # batch j of the staged sequence: (first pick, size)
+        self._ep_batches = [(e * n + b * batch_size, min(batch_size, n - b * batch_size)) for e in range(n_epochs) for b in range(nb_e)]
+        return self._ep_ids[:total], self._ep_lab[:total]
 
     def take_prefetched(self) -> bool:
         """True if the current set already holds a sampled and planned epoch that no step has used yet (left by
@@ -519,9 +529,11 @@ class FusedPCGNN:
         """Plan every batch of the staged epoch (set `which`, default the current one): one launch (after the sampler, before
         the epoch's first step).  bump_counter: the sampler's device epoch counter, incremented by it."""
         st = self._ep_sets[self._cur if which is None else which]
-        self._enqueue_plan(st["ids"], st["lab"], self._ep_n, self._ep_bs, st["plans"], self._ep_stride, True, bump_counter)
+        self._enqueue_plan(st["ids"], st["lab"], self._ep_n, self._ep_bs, st["plans"], self._ep_stride, True, bump_counter, self._ep_k)
         if self.touched_on:
-            self._enqueue_mark(st["ids"], self._ep_n, self._ep_bs, st["touched"])
+            nb_e = -(-self._ep_n // self._ep_bs)
+            for e in range(self._ep_k):              # (an epoch's last batch may be the shorter one: the maps are made epoch by epoch)
+                self._enqueue_mark(st["ids"][e * self._ep_n:], self._ep_n, self._ep_bs, st["touched"][e * nb_e * self._touch_stride:])
             self._fresh = False                      # (new maps: the rows scored so far need not cover the new first batch)
 
     def _ep_plan(self, b: int, which: Optional[int] = None) -> int:
@@ -533,8 +545,8 @@ class FusedPCGNN:
         return self._ep_sets[self._cur if which is None else which]["touched"].data_ptr() + b * self._touch_stride
 
     def _ep_next_touch(self, b: int, which: Optional[int] = None) -> Optional[int]:
-        """the map of the batch after b, if the staged epoch has one"""
-        if not self.touched_on or (b + 1) * self._ep_bs >= self._ep_n:
+        """the map of the batch after b, if the staged sequence has one"""
+        if not self.touched_on or b + 1 >= len(self._ep_batches):
             return None
         return self._ep_touch(b + 1, which)
 
@@ -552,13 +564,12 @@ class FusedPCGNN:
         """Batch b of the staged (and planned) epoch as one graph replay.  defer: as inside epoch_run - the Adam update of
         everything but the label classifier is left to the next batch's front launch (the epoch's last batch flushes it), so
         the parameters are complete only after the last batch or a flush()."""
-        lo = b * self._ep_bs
-        B = min(self._ep_bs, self._ep_n - lo)
-        if B <= 0:
+        if b >= len(self._ep_batches):
             return
+        lo, B = self._ep_batches[b]
         self._lastB = B
-        defer = defer and lo + B < self._ep_n
-        key = (self._cur, lo, B, self._ep_n, "deferred") if defer else (self._cur, lo, B, self._ep_n)
+        defer = defer and b + 1 < len(self._ep_batches)
+        key = (self._cur, lo, B, self._ep_shape, "deferred") if defer else (self._cur, lo, B, self._ep_shape)
         gr = self._ep_graphs.get(key)
         if gr is None:
             ids, lab = self._ep_ids[lo:lo + B], self._ep_lab[lo:lo + B]
@@ -576,19 +587,18 @@ class FusedPCGNN:
         gather).  eager: the four kernels launched one by one with the two event records between them (the host stays
         ahead of the GPU, so the events bracket the two kernels and nothing else); otherwise three graphs - scores | select +
         gather | dense - whose launch latency lands inside the bracket."""
-        lo = b * self._ep_bs
-        B = min(self._ep_bs, self._ep_n - lo)
-        if B <= 0:
+        if b >= len(self._ep_batches):
             return
+        lo, B = self._ep_batches[b]
         self._lastB = B
-        key = (self._cur, lo, B, self._ep_n, "timed")
+        key = (self._cur, lo, B, self._ep_shape, "timed")
         grs = self._ep_graphs.get(key)
         ids, lab = self._ep_ids[lo:lo + B], self._ep_lab[lo:lo + B]
         g = self.g
         plan = self._ep_plan(b)
         agg = self.agg.view(-1)[:g.R * B * g.feat_dim].view(g.R, B, g.feat_dim)
         keys = self.keys if g.n_pos else None
-        last = lo + B >= self._ep_n               # the epoch's last batch: nothing follows that would apply the deferred update
+        last = b + 1 >= len(self._ep_batches)     # the staged sequence's last batch: nothing follows that would apply the deferred update
         touched, nxt = self._ep_touch(b), self._ep_next_touch(b)
         score_next = (not self.touched_on) or nxt is not None
         if not self._fresh:
@@ -632,16 +642,17 @@ class FusedPCGNN:
         epoch's kernels; the only cross-stream waits are two events per epoch (the other buffer set is free / is ready).
         first_step > 0: the REST of an epoch that is staged and planned already and whose first batches have been run some other
         way (batches first_step .. n_steps - 1): no sampler, no plans."""
-        nb = -(-self._ep_n // self._ep_bs)
+        nb = len(self._ep_batches)
         n_steps = nb if n_steps is None else min(n_steps, nb)
-        n = self._ep_n
+        n = self._ep_n * self._ep_k
+        batches = list(self._ep_batches)
         if first_step > 0:
             sample, prefetch = None, False
         on_stream = prefetch == "stream" and sample is not None
         prefetch = prefetch is True and sample is not None
         cur = self._cur
         primed = (prefetch or on_stream) and self._cur_ready
-        key = ("epoch", cur, n, self._ep_bs, n_steps, sample is not None, None if bump_counter is None else bump_counter.data_ptr(),
+        key = ("epoch", cur, self._ep_shape, n_steps, sample is not None, None if bump_counter is None else bump_counter.data_ptr(),
                flush, prefetch, primed, on_stream, first_step)
         gr = self._ep_graphs.get(key)
         if gr is None:
@@ -649,8 +660,7 @@ class FusedPCGNN:
             nxt = self._ep_sets[cur ^ 1]
             def run():
                 for b in range(first_step, n_steps):
-                    lo = b * self._ep_bs
-                    B = min(self._ep_bs, n - lo)
+                    lo, B = batches[b]
                     self.train_step(st["ids"][lo:lo + B], st["lab"][lo:lo + B], defer=True, plan=self._ep_plan(b, cur),
                                     touched=self._ep_touch(b, cur), next_touched=self._ep_next_touch(b, cur))
                 if flush:
@@ -681,7 +691,7 @@ class FusedPCGNN:
                     run()
             gr = self._capture_graphs([sampled_run], warm=[warm_run])[0]
             self._ep_graphs[key] = gr
-        self._lastB = min(self._ep_bs, n - (n_steps - 1) * self._ep_bs)
+        self._lastB = batches[n_steps - 1][1]
         # (whole-table engine: the graph was captured with the scores at hand - it holds no score launch of its own; a
         #  touched-rows engine's graph scores its first batch's rows itself, behind its sampler and maps)
         if first_step > 0:
@@ -723,8 +733,7 @@ class FusedPCGNN:
         the host: sets[r][i] for relation r, centre i.  Synchronises.  (bench.py's `verified`, tests.)"""
         import numpy as np
         g, lib = self.g, self.lib
-        lo = b * self._ep_bs
-        B = min(self._ep_bs, self._ep_n - lo)
+        B = self._ep_batches[b][1]
         rows = g.R * B
         torch.cuda.synchronize(self.dev)
         off = lambda which: int(lib.pcg_choose_workspace_offset(g.desc_ref(), B, self.list_capacity, which))

@@ -70,27 +70,37 @@ class PCGNNTrainer:
         perm = torch.randperm(self.pick_size, device=self.device, generator=self._gen)
         return picked[perm]
 
-    def start_epoch_staged(self) -> torch.Tensor:
-        """pick + shuffle + label lookup in ONE launch (pcg_pick_shuffled), straight into the fused engine's epoch
+    def start_epoch_staged(self, n_epochs: int = 1) -> torch.Tensor:
+        """pick + shuffle + label lookup in ONE launch (pcg_pick_shuffled_epochs), straight into the fused engine's epoch
         buffers, then every batch's plan; the epoch number lives on the device and is moved on by the plan launch.  If a
         previous ``run_epoch_one_graph(prefetch=True)`` has prepared this epoch already, nothing is launched.
-        Returns the staged ids."""
-        ids, lab = self.fused.stage_epoch(self.pick_size, self.batch_size)
+        n_epochs > 1: that many epochs are sampled and planned together (one sampler launch, one plan launch) and walked as
+        one sequence of n_epochs * batches_per_epoch() batches.  Returns the staged ids (n_epochs * pick_size)."""
+        ids, lab = self.fused.stage_epoch(self.pick_size, self.batch_size, n_epochs)
         if not self.fused.take_prefetched():
             self._sample_into(ids, lab)
             self.fused.plan_staged(self._epoch_dev)      # every batch's plan; it also moves the epoch number on
         return ids
 
     def _sample_into(self, ids: torch.Tensor, lab: torch.Tensor):
-        self.sampler.pick_shuffled(self.pick_size, ids, self.labels_i32, lab, epoch_counter=self._epoch_dev, bump=False)
+        """fill ids / lab (a whole number of epochs of pick_size draws) with consecutive epochs' shuffled picks"""
+        self.sampler.pick_shuffled(self.pick_size, ids, self.labels_i32, lab, epoch_counter=self._epoch_dev, bump=False,
+                                   n_epochs=ids.numel() // self.pick_size)
 
-    def run_epoch_one_graph(self, flush: bool = True, prefetch: bool = False, n_steps: Optional[int] = None) -> int:
-        """A whole epoch - pick, shuffle, labels, every batch's plan and every batch's training step - as one graph launch.
+    def nodes_of_steps(self, n_steps: int) -> int:
+        """sampled nodes of the first n_steps batches of a staged sequence of epochs (every epoch's last batch is the short one)"""
+        nb = self.batches_per_epoch()
+        full, rest = divmod(n_steps, nb)
+        return full * self.pick_size + min(self.pick_size, rest * self.batch_size)
+
+    def run_epoch_one_graph(self, flush: bool = True, prefetch: bool = False, n_steps: Optional[int] = None, n_epochs: int = 1) -> int:
+        """A whole epoch - pick, shuffle, labels, every batch's plan and every batch's training step - as one graph launch
+        (n_epochs > 1: that many epochs, sampled and planned together, in one launch).
         flush=False / prefetch=True: see FusedPCGNN.epoch_run (back-to-back epochs: the next epoch's first launch applies the
         last update; the next epoch's sampler and plans run beside this epoch's steps)."""
-        self.fused.stage_epoch(self.pick_size, self.batch_size)
-        self.fused.epoch_run(n_steps=n_steps, sample=self._sample_into, bump_counter=self._epoch_dev, flush=flush, prefetch=prefetch)
-        return self.pick_size if n_steps is None else min(self.pick_size, n_steps * self.batch_size)
+        self.fused.stage_epoch(self.pick_size, self.batch_size, n_epochs)
+        done = self.fused.epoch_run(n_steps=n_steps, sample=self._sample_into, bump_counter=self._epoch_dev, flush=flush, prefetch=prefetch)
+        return self.nodes_of_steps(done)
 
     def step(self, batch_ids: torch.Tensor, timed: bool = False) -> torch.Tensor:
         """One iteration of the batch loop (model_handler.py:147-153)."""

@@ -260,15 +260,16 @@ def pick(cum: torch.Tensor, idx_train: torch.Tensor, k: int, uniforms: Optional[
 def pick_shuffled(cum: torch.Tensor, idx_train: torch.Tensor, k: int, seed: int, epoch_base: int,
                   out_ids: torch.Tensor, labels_all: Optional[torch.Tensor] = None,
                   out_labels: Optional[torch.Tensor] = None, epoch_counter: Optional[torch.Tensor] = None,
-                  bump: bool = False):
+                  bump: bool = False, n_epochs: int = 1):
     """An epoch's picks, shuffled, with their labels, in one launch (pcg_pick_shuffled): the same draws as
     ``pick(seed, epoch)``, in a uniformly random order.  epoch = epoch_base + epoch_counter[0] (a device int64 the
-    call increments afterwards when ``bump``: a captured graph then replays a new epoch every time)."""
+    call increments afterwards when ``bump``: a captured graph then replays a new epoch every time).  n_epochs > 1: that many
+    consecutive epochs in one launch, epoch e's k draws at out_ids[e * k:] (the counter moves on by n_epochs)."""
     lib = _lib.load()
-    _lib.check(lib.pcg_pick_shuffled(_p(cum), _p(idx_train), idx_train.numel(), seed & (2 ** 64 - 1),
-                                     epoch_base & (2 ** 64 - 1), _p(epoch_counter), 1 if bump else 0, k,
-                                     _p(labels_all), _p(out_ids), _p(out_labels), _stream(cum.device)),
-               "pcg_pick_shuffled")
+    _lib.check(lib.pcg_pick_shuffled_epochs(_p(cum), _p(idx_train), idx_train.numel(), seed & (2 ** 64 - 1),
+                                            epoch_base & (2 ** 64 - 1), _p(epoch_counter), 1 if bump else 0, n_epochs, k,
+                                            _p(labels_all), _p(out_ids), _p(out_labels), _stream(cum.device)),
+               "pcg_pick_shuffled_epochs")
     return out_ids
 
 

@@ -33,10 +33,11 @@ class PickSampler:
 
     def pick_shuffled(self, size: int, out_ids: torch.Tensor, labels_all: Optional[torch.Tensor] = None,
                       out_labels: Optional[torch.Tensor] = None, epoch: int = 0,
-                      epoch_counter: Optional[torch.Tensor] = None, bump: bool = False) -> torch.Tensor:
-        """pick + random.shuffle + label lookup of one epoch in one launch (utils.py:274-278, model_handler.py:131-133)."""
+                      epoch_counter: Optional[torch.Tensor] = None, bump: bool = False, n_epochs: int = 1) -> torch.Tensor:
+        """pick + random.shuffle + label lookup of one epoch (or of n_epochs consecutive ones, `size` draws each) in one launch
+        (utils.py:274-278, model_handler.py:131-133)."""
         return ops.pick_shuffled(self.cum, self.idx_train, size, self.seed, epoch, out_ids, labels_all, out_labels,
-                                 epoch_counter, bump)
+                                 epoch_counter, bump, n_epochs)
 
 
 def pick_step(idx_train, y_train, adj_list, size, device="cuda", uniforms=None, seed=0, epoch=0):

@@ -890,6 +890,55 @@ def test_epoch_as_one_graph_equals_step_by_step(P):
     assert torch.isfinite(a.fused.theta).all() and not torch.equal(a.fused.theta, torch.zeros_like(a.fused.theta))
 
 
+def test_epoch_groups_equal_epochs_one_by_one(P):
+    """Several epochs sampled, planned and replayed TOGETHER (one sampler launch, one plan launch, one graph launch for the
+    group: PCGNNTrainer.run_epoch_one_graph(n_epochs=K), what bench.py times) leave bit for bit what the same epochs leave one
+    by one: the same picks in the same order, parameters, Adam moments, step and epoch counters - as one group of four, as two
+    groups of two, as bench.py's event-bracketed group (first batch kernel by kernel, the rest one graph) and as a group cut
+    short inside its third epoch.  Every epoch's last batch is the shorter one."""
+    from pcgnn_amd import synth
+    from pcgnn_amd.handler import PCGNNTrainer
+    w = synth.make_workload("mini", 6000, 32, (4000, 30000, 90000), 0.12, seed=3)
+    cfg = dict(engine="graph", batch_size=256, seed=5)
+    a, b, c, d, e, f = (PCGNNTrainer(w, cfg, dev()) for _ in range(6))
+    for t in (b, c, d, e, f):
+        t.fused.theta.copy_(a.fused.theta)
+        t.fused.params_changed()
+    nb, n = a.batches_per_epoch(), a.pick_size
+    assert n % a.batch_size != 0 and nb >= 3
+    ids_a = []
+    for _ in range(4):
+        assert a.run_epoch_one_graph() == n
+        ids_a.append(a.fused._ep_ids[:n].clone())
+    assert b.run_epoch_one_graph(n_epochs=4) == 4 * n
+    assert torch.equal(b.fused._ep_ids[:4 * n], torch.cat(ids_a)), "a group's picks are its epochs' picks, epoch by epoch"
+    assert len(b.fused._ep_batches) == 4 * nb and b.fused._ep_batches[nb - 1][1] == n - (nb - 1) * a.batch_size
+    c.start_epoch_staged(4)
+    c.fused.epoch_step_timed(0)
+    c.fused.epoch_run(first_step=1)
+    d.run_epoch_one_graph(flush=False, n_epochs=2)
+    d.run_epoch_one_graph(n_epochs=2)
+    torch.cuda.synchronize()
+    for t in (a, b, c, d):
+        t.fused.check()
+        assert int(t._epoch_dev[0]) == 4
+    for name in ("theta", "m", "v", "step_counter"):
+        assert torch.equal(getattr(a.fused, name), getattr(b.fused, name)), name + " (one group of four epochs)"
+        assert torch.equal(getattr(a.fused, name), getattr(c.fused, name)), name + " (bracketed group)"
+        assert torch.equal(getattr(a.fused, name), getattr(d.fused, name)), name + " (two groups of two)"
+    # a group cut short inside its third epoch == two epochs and the first two batches of a third
+    r = 2 * nb + 2
+    assert e.run_epoch_one_graph(n_steps=r, n_epochs=4) == 2 * n + 2 * a.batch_size
+    f.run_epoch_one_graph(flush=False)
+    f.run_epoch_one_graph(flush=False)
+    f.run_epoch_one_graph(n_steps=2)
+    torch.cuda.synchronize()
+    assert int(e._epoch_dev[0]) == 4 and int(f._epoch_dev[0]) == 3      # (the group's four epochs were sampled; three were begun)
+    for name in ("theta", "m", "v", "step_counter"):
+        assert torch.equal(getattr(e.fused, name), getattr(f.fused, name)), name + " (a group cut short)"
+    assert int(e.fused.step_counter.item()) == r
+
+
 def test_large_batch_two_pass_plan(P):
     """rows > 4096 take the two-launch, multi-workgroup plan: same result as the oracle / the small-batch path."""
     ops = P.ops
