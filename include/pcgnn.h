@@ -403,6 +403,13 @@ int64_t pcg_touched_bytes(int64_t n_nodes);
  * the longest row: 1.6 ms per epoch at 10 M nodes / 200 M edges). */
 int pcg_mark_touched(const pcg_graph_desc *g, const int32_t *nodes, int32_t n_total, int32_t B, uint8_t *maps,
                      int64_t map_stride, uint32_t *queue, void *stream);
+/* pcg_mark_touched from the batches' PLANS (pcg_plan_batches has run on `plans` for the same nodes / n_total / B / list_capacity;
+ * an epoch of a pcg_plan_epochs group: pass that epoch's first slot and its n_total): the plan slots hold every row's record and the
+ * degree-tier queues, so the hub rows (> 4096 neighbours) are swept, one id range at a time, into LDS bitmaps that are expanded
+ * into the byte maps with coalesced stores - which also write every other byte zero (no zeroing pass) - and the other rows, the
+ * centres and the train positives are marked afterwards.  Two launches; the same maps as pcg_mark_touched, bit for bit. */
+int pcg_mark_touched_planned(const pcg_graph_desc *g, const int32_t *nodes, int32_t n_total, int32_t B, const void *plans,
+                             int64_t plan_stride, int64_t list_capacity, uint8_t *maps, int64_t map_stride, void *stream);
 int pcg_train_dense(const pcg_graph_desc *g, float *theta, float *m, float *v, int32_t emb, const int32_t *ids,
                     const int32_t *labels, int32_t B, const float *agg, int32_t agg_stride, const int32_t *cnt,
                     const void *workspace, const void *plan, int64_t list_capacity, float lambda_1, float inv_count, float *logits,

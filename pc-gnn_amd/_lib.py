@@ -78,6 +78,7 @@ PROTOTYPES = {
     "pcg_step_scores_train": (C.c_int, [_G, _P, _P, _P, _I32, _P, _P, _P, _P, _P, _F64, _F64, _F64, _F64, _F64, _P, _P]),
     "pcg_touched_bytes": (_I64, [_I64]),
     "pcg_mark_touched": (C.c_int, [_G, _P, _I32, _I32, _P, _I64, _P, _P]),
+    "pcg_mark_touched_planned": (C.c_int, [_G, _P, _I32, _I32, _P, _I64, _I64, _P, _I64, _P]),
     "pcg_choose_aggregate_planned": (C.c_int, [_G, _P, _P, _I32, _P, _P, _P, C.POINTER(_F64), C.POINTER(_F64), _I32, _I32,
                                                _I32, _P, _I32, _P, _P, _I64, _P, _P]),
     "pcg_choose_gather_planned": (C.c_int, [_G, _P, _P, _I32, _P, _P, _P, C.POINTER(_F64), C.POINTER(_F64), _I32, _I32,

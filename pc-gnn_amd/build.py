@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBNAME = "libpcgnn_hip.so"
-SOURCES = ["score.hip", "sort.hip", "segmean_pick.hip", "choose.hip", "select.hip", "gather.hip", "dense.hip", "halo.hip"]
+SOURCES = ["score.hip", "mark.hip", "sort.hip", "segmean_pick.hip", "choose.hip", "select.hip", "gather.hip", "dense.hip", "halo.hip"]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 

@@ -11,6 +11,8 @@ constexpr int TB_CAP = 64;       // rows of <= 64: one wave, one key per lane, r
 constexpr int T1_CAP = 512;      // rows of <= 512: one wave, up to 8 keys per lane in registers, 256-bin LDS histogram rounds
 constexpr int T4_CAP = 4096;     // workgroup rows are queued in two classes (> 4096 first) so that the longest start first
 constexpr int WG_KEYCAP = 10240; // workgroup rows up to this length keep their distance keys in LDS; longer ones recompute them
+constexpr int LONG_NW = 16;       // waves per workgroup of select_long_rows (rows beyond WG_KEYCAP: a launch of their own, one workgroup per CU)
+constexpr int LONG_KEYCAP = 32768; // ... which keep the keys of rows up to this length in LDS (128 KB of the CU's 160); longer still: global scratch
 constexpr int SEL_NW = 8;        // waves per select workgroup
 constexpr int SEL_BLOCKS = 768;  // persistent select workgroups: 3 per CU (<= 80 VGPRs: 6 waves per SIMD; 49.5 KB of LDS each)
 constexpr int HIST_WG = 2048;    // histogram bins of a workgroup row
@@ -66,10 +68,10 @@ static inline CarveSizes carve(const pcg_graph_desc *g, int32_t B, int64_t list_
                                unsigned char *data_base, Workspace *w) {
     const int64_t rows = (int64_t)g->n_rel * B;
     const int64_t chunk_cap = list_capacity / CHUNK + rows + 1;
-    // key scratch: only graphs with rows beyond the LDS key capacity need it; max_degree entries for each workgroup of
-    // select_long_rows (up to 256 of them; fewer if that would be more than 1 GiB)
+    // key scratch: only graphs with rows beyond select_long_rows' LDS key capacity need it; max_degree entries for each of its
+    // workgroups (up to 256 of them; fewer if that would be more than 1 GiB)
     int64_t scratch_cap = 0;
-    if (g->max_degree > WG_KEYCAP) {
+    if (g->max_degree > LONG_KEYCAP) {
         int64_t nb = (1ll << 28) / g->max_degree;
         nb = nb < 1 ? 1 : (nb > 256 ? 256 : nb);
         scratch_cap = nb * (int64_t)g->max_degree;

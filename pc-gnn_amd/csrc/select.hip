@@ -706,7 +706,8 @@ __device__ __forceinline__ void for_keys(const uint32_t *keys, const uint32_t *_
 // lds: WG_KEYCAP words (keys, later the kept ids) | hist HIST_WG | cand 64 | red
 template <bool LDSK, int NW = SEL_NW>
 __device__ __forceinline__ void select_wg_row(const ChooseArgs &a, int row, uint32_t *keys, uint32_t *hist, uint32_t *cand,
-                                              int *red, int tid, int &keys_ok, int *sortw, uint32_t *gk = nullptr) {
+                                              int *red, int tid, int &keys_ok, int *sortw, uint32_t *gk = nullptr,
+                                              int key_cap = WG_KEYCAP /* words of `keys` */) {
     constexpr int NT = NW * PCG_WAVE;
     constexpr int HBITS = NW == 8 ? 11 : 12;                 // 4 * NT histogram bins: one uint4 of them per thread
     static_assert(4 * NT == (1 << HBITS), "NW is 8 or 16");
@@ -854,7 +855,7 @@ __device__ __forceinline__ void select_wg_row(const ChooseArgs &a, int row, uint
     // list region and reports itself: no LDS staging, no copy.
     const bool plain = p.m == 0 && !a.add_self;                              // (the same for every thread)
     // (a keep-all row keeps d ids, not k: what must fit is the kept count)
-    const bool sel_in_lds = (LDSK || (keep_all ? d : k) <= WG_KEYCAP) && !plain;
+    const bool sel_in_lds = (LDSK || (keep_all ? d : k) <= key_cap) && !plain;
     uint32_t *selbuf = sel_in_lds ? keys : reinterpret_cast<uint32_t *>(out);
     if constexpr (LDSK) {
         // pass A: which positions stay (a bit per iteration in a register; seg <= 1280 -> <= 20 iterations), pass B: their
@@ -1394,16 +1395,19 @@ __global__ void __launch_bounds__(SEL_NW *PCG_WAVE) __attribute__((amdgpu_waves_
 // in global scratch needs more registers than select_rows' occupancy allows, and only hub-heavy graphs have such rows (the
 // launch is skipped when the graph's maximum degree rules them out).  Persistent workgroups walk the > 4096 queue and take
 // the rows that select_rows left alone; workgroup b keeps its keys in scratch[b * per_wg ..].
+// (LONG_NW = 16 waves per long row: half the gathers per lane; LONG_KEYCAP keys in LDS - one workgroup per CU - so that a row
+//  of up to 32768 neighbours never leaves the CU: at 10 M nodes / 200 M edges the rows of 10 - 18 K neighbours, ~170 per batch,
+//  took 60 us each with their keys in global scratch - written by pass 1, re-read by every histogram round and by both
+//  compaction passes)
 constexpr int LONG_BLOCKS = 256;
-constexpr int LONG_NW = 16;              // sixteen waves per long row: half the gathers / scratch reads per lane
 __global__ void __launch_bounds__(LONG_NW *PCG_WAVE) select_long_rows(const ChooseArgs a, int64_t per_wg) {
     extern __shared__ __align__(16) unsigned char smem[];
-    uint32_t *lds = reinterpret_cast<uint32_t *>(smem);                   // WG_KEYCAP words: the kept ids | 4096 bins | cand | red
-    uint32_t *hist = lds + WG_KEYCAP;
+    uint32_t *lds = reinterpret_cast<uint32_t *>(smem);                   // LONG_KEYCAP words: keys, then the kept ids | 4096 bins | cand | red
+    uint32_t *hist = lds + LONG_KEYCAP;
     uint32_t *cand = hist + 4 * LONG_NW * PCG_WAVE;
     int *red = reinterpret_cast<int *>(cand + PCG_WAVE);
     const int n16 = (int)a.w.counters[C_N16];
-    uint32_t *gk = a.w.key_scratch + (size_t)blockIdx.x * per_wg;
+    uint32_t *gk = a.w.key_scratch ? a.w.key_scratch + (size_t)blockIdx.x * per_wg : nullptr;     // (no scratch: no row beyond LONG_KEYCAP)
     // The queue is in row order, the long rows are anywhere in it: a static stride would hand some workgroups three or four of
     // them and most none.  Every workgroup therefore pulls queue positions from one cursor (heads[14]; a few hundred atomics
     // in all) - AFTER it is done with its unit, not a unit ahead: units cost nothing or 60 us here, and a workgroup busy with
@@ -1415,9 +1419,9 @@ __global__ void __launch_bounds__(LONG_NW *PCG_WAVE) select_long_rows(const Choo
     int keys_ok = 1;                                                        // (select_rows, the launch before, has sorted them)
     while (u < n16) {
         const int row = __builtin_amdgcn_readfirstlane(a.w.q16[u]);
-        if (a.w.recs[row].d > WG_KEYCAP) {                                  // (workgroup-uniform)
-            select_wg_row<false, LONG_NW>(a, row, lds, hist, cand, red, (int)threadIdx.x, keys_ok, nullptr, gk);
-        }
+        const int d = a.w.recs[row].d;                                      // (workgroup-uniform)
+        if (d > LONG_KEYCAP) select_wg_row<false, LONG_NW>(a, row, lds, hist, cand, red, (int)threadIdx.x, keys_ok, nullptr, gk, LONG_KEYCAP);
+        else if (d > WG_KEYCAP) select_wg_row<true, LONG_NW>(a, row, lds, hist, cand, red, (int)threadIdx.x, keys_ok, nullptr, nullptr, LONG_KEYCAP);
         __syncthreads();
         if (leader) claim[slot] = (int)gridDim.x + (int)atomicAdd(cursor, 1u);
         __syncthreads();
@@ -1475,10 +1479,21 @@ int launch_select_rows(const ChooseArgs &a, hipStream_t st) {
     PCG_LAUNCH_CHECK();
     if (a.g.max_degree > WG_KEYCAP) {        // rows too long for the LDS keys: their own launch (hub-heavy graphs only)
         const int64_t per_wg = a.g.max_degree;
-        int64_t nb = a.w.scratch_cap / per_wg;
-        nb = nb < LONG_BLOCKS ? nb : LONG_BLOCKS;
-        if (nb < 1) return PCG_E_ARG;
-        const size_t long_smem = sizeof(uint32_t) * (WG_KEYCAP + 4 * LONG_NW * PCG_WAVE + PCG_WAVE) + sizeof(int) * (2 * LONG_NW + 8);
+        int64_t nb = LONG_BLOCKS;                // (rows beyond LONG_KEYCAP keep their keys in scratch: as many workgroups as it holds)
+        if (a.g.max_degree > LONG_KEYCAP) {
+            nb = a.w.scratch_cap / per_wg;
+            nb = nb < LONG_BLOCKS ? nb : LONG_BLOCKS;
+            if (nb < 1) return PCG_E_ARG;
+        }
+        static_assert(LONG_KEYCAP == LONG_NW * PCG_WAVE * 32, "pass A of an LDS row keeps one bit per iteration in a uint32");
+        const size_t long_smem = sizeof(uint32_t) * (LONG_KEYCAP + 4 * LONG_NW * PCG_WAVE + PCG_WAVE) + sizeof(int) * (2 * LONG_NW + 8);
+        static bool attr_done = false;
+        if (!attr_done) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(select_long_rows), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)long_smem) != hipSuccess)
+                return PCG_E_LAUNCH;
+            attr_done = true;
+        }
         ChooseArgs al = a;                   // (the keys are sorted by now: nothing to sort, nothing to wait for)
         al.n_sort = 0;
         al.pending_clear = nullptr;

@@ -193,22 +193,14 @@ class FusedPCGNN:
                 if torch.cuda.is_current_stream_capturing():
                     raise _lib.PcgnnLibraryError("first use of the touched-row map inside a graph capture: warm up before capturing")
                 self._touch_one = torch.zeros(self._touch_stride, dtype=torch.uint8, device=self.dev)
-            self._enqueue_mark(ids, B, B, self._touch_one)
+            self._enqueue_mark(ids, B, B, self._touch_one, slot.data_ptr(), slot.numel())
         return slot.data_ptr()
 
-    def _enqueue_mark(self, ids, n_total, B, maps: torch.Tensor):
-        """byte maps of the rows each batch's selection can read (two launches for all batches, three on graphs with hub rows)"""
-        need = 4 + self.g.R * n_total
-        q = getattr(self, "_mark_queue", None)
-        if q is None or q.numel() < need:
-            if torch.cuda.is_current_stream_capturing():
-                raise _lib.PcgnnLibraryError("a larger epoch's touched-row maps inside a graph capture: warm up before capturing")
-            q = self._mark_queue = torch.zeros(need, dtype=torch.int32, device=self.dev)
-            # every captured graph that marks rows holds the old queue's address
-            self._graphs.clear()
-            self._ep_graphs.clear()
-        _lib.check(self.lib.pcg_mark_touched(self.g.desc_ref(), _p(ids), n_total, B, _p(maps), self._touch_stride, _p(q),
-                                             self._stream()), "pcg_mark_touched")
+    def _enqueue_mark(self, ids, n_total, B, maps: torch.Tensor, plans: int, stride: int):
+        """byte maps of the rows each batch's selection can read, from the batches' plans (`plans`: address of the first batch's
+        slot): two launches for all batches (pcg_mark_touched_planned)"""
+        _lib.check(self.lib.pcg_mark_touched_planned(self.g.desc_ref(), _p(ids), n_total, B, C.c_void_p(plans), stride, self.list_capacity,
+                                                     _p(maps), self._touch_stride, self._stream()), "pcg_mark_touched_planned")
 
     def _enqueue_scores(self, train_flag):
         """label-aware score table + per-step sort of the train positives (the calls of their own: evaluation, parity)."""
@@ -533,7 +525,8 @@ class FusedPCGNN:
         if self.touched_on:
             nb_e = -(-self._ep_n // self._ep_bs)
             for e in range(self._ep_k):              # (an epoch's last batch may be the shorter one: the maps are made epoch by epoch)
-                self._enqueue_mark(st["ids"][e * self._ep_n:], self._ep_n, self._ep_bs, st["touched"][e * nb_e * self._touch_stride:])
+                self._enqueue_mark(st["ids"][e * self._ep_n:], self._ep_n, self._ep_bs, st["touched"][e * nb_e * self._touch_stride:],
+                                   st["plans"].data_ptr() + e * nb_e * self._ep_stride, self._ep_stride)
             self._fresh = False                      # (new maps: the rows scored so far need not cover the new first batch)
 
     def _ep_plan(self, b: int, which: Optional[int] = None) -> int:

@@ -6,7 +6,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 name=$1; shift
 D=$R/pc-gnn_amd/lib/ab/$name; mkdir -p $D
 objs=""
-for s in score sort segmean_pick choose select gather dense halo; do
+for s in score mark sort segmean_pick choose select gather dense halo; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -fno-gpu-rdc -Wno-unused-function "$@" -c $R/pc-gnn_amd/csrc/$s.hip -o $D/$s.o &
 done
 wait

@@ -265,10 +265,12 @@ def hub_graph(seed, n, hub_degs, base_deg=6.0, feat=32):
 @pytest.mark.parametrize("quantize", [False, True])
 def test_hub_rows_block_and_scratch_paths(P, quantize):
     ops = P.ops
-    n = 60000
-    # (> 10240: the long-row launch - 30000 keeps its kept ids in the list region, 20480 / 10241 as positive centres in LDS)
+    n = 120000
+    # (> 10240: the long-row launch, keys in ITS LDS up to 32768 neighbours - 30000 / 20480 / 10241 / 32768 -, beyond that in global
+    #  scratch: 70000 as a positive centre keeps 35000 ids, more than that LDS holds - they go to the list region -, 40000 as a
+    #  negative one, 32769 on the boundary)
     hub_degs = [30000, 13000, 8193, 8192, 8191, 6000, 4097, 4096, 4095, 2500, 513, 512, 511, 257, 256, 255, 65, 64, 63, 20480, 10241,
-                10240]
+                10240, 40000, 70000, 32769, 32768]
     X, labels, csr = hub_graph(11, n, hub_degs)
     if quantize:   # many exact distance ties: the positional tie-break must match the oracle
         X = np.round(X * 2) / 2
@@ -281,7 +283,8 @@ def test_hub_rows_block_and_scratch_paths(P, quantize):
     s0 = ops.score_table(g, W, b)
     keys = ops.pos_sort(g, s0)
     nodes = list(range(len(hub_degs))) + [0, 1, 777, 778]
-    lab = ([1, 0, 1, 1, 0, 1, 1, 1, 0, 1, 1, 0, 1, 0] * 2)[:len(nodes)]
+    lab = ([1, 0, 1, 1, 0, 1, 1, 1, 0, 1, 1, 0, 1, 0] * 3)[:len(nodes)]
+    assert lab[22] == 0 and lab[23] == 1          # (40000: a negative centre, 70000: a positive one)
     for rho in (0.5, 2.0):
         sets, agg, cnt = ops.chosen_sets(g, torch.tensor(nodes, dtype=torch.int32, device=dev()),
                                          torch.tensor(lab, dtype=torch.int32, device=dev()), s0, keys, [0.5], rho, True)
@@ -1173,6 +1176,27 @@ def test_touched_rows_only_scoring(P, monkeypatch):
         for v_ in sl:
             want[csr_h[1][csr_h[0][v_]:csr_h[0][v_ + 1]]] = 1
         assert np.array_equal(maps_h[s_ * stride_h:(s_ + 1) * stride_h].cpu().numpy(), want), f"hub batch {s_}"
+    # the same maps from the batches' PLANS (pcg_mark_touched_planned: hub rows swept range by range into LDS bitmaps that are
+    # expanded into the byte maps - which also writes every other byte zero -, the other rows from the plans' records and tier
+    # queues): byte for byte pcg_mark_touched's, over garbage, for both graphs (a shorter last batch in each)
+    def planned_maps(gg, ids_t, labels_np, n_tot, Bq, stride_q):
+        lab_t = torch.from_numpy(labels_np[ids_t.cpu().numpy()].astype(np.int32)).cuda()
+        thr_c, rho_c = ops._host_arrays(gg, [0.5] * gg.R, [0.5] * gg.R)
+        cap = int(ops.sel_capacity(gg, ids_t.cpu().numpy(), labels_np[ids_t.cpu().numpy()], [0.5] * gg.R, [0.5] * gg.R, True).sum()) + 64
+        pst = int(lib.pcg_choose_plan_bytes(gg.desc_ref(), Bq, cap))
+        n_sl = -(-n_tot // Bq)
+        plans = torch.zeros(n_sl * pst, dtype=torch.uint8, device=dev())
+        status = torch.zeros(1, dtype=torch.int32, device=dev())
+        _lib.check(lib.pcg_plan_batches(gg.desc_ref(), _p(ids_t), _p(lab_t), n_tot, Bq, thr_c, rho_c, 1, 0, _p(plans), pst, cap, _p(status),
+                                        None, st), "pcg_plan_batches")
+        out = torch.full((n_sl * stride_q,), 5, dtype=torch.uint8, device=dev())
+        _lib.check(lib.pcg_mark_touched_planned(gg.desc_ref(), _p(ids_t), n_tot, Bq, _p(plans), pst, cap, _p(out), stride_q, st),
+                   "pcg_mark_touched_planned")
+        torch.cuda.synchronize()
+        assert int(status.item()) == 0
+        return out
+    assert torch.equal(planned_maps(g, ids, w.labels, n_total, B, stride), maps), "planned marks == pcg_mark_touched's"
+    assert torch.equal(planned_maps(gh, torch.from_numpy(hub_nodes).cuda(), lab_h, 64, 40, stride_h), maps_h), "... with hub rows"
     s0_full = ops.score_table(g, W, b)
     keys = torch.zeros(int(lib.pcg_pos_sort_capacity(g.n_pos)), dtype=torch.int64, device=dev())
     for s_ in range(3):
