@@ -145,6 +145,7 @@ class PCGNNTrainer:
 # ---------------------------------------------------------------------------------------------------------------------
 # ModelHandler: the reference's experiment driver (src/model_handler.py:24-178) over the HIP path
 # ---------------------------------------------------------------------------------------------------------------------
+EPOCHS_PER_LAUNCH = 4        # epochs ModelHandler.train samples, plans and replays per launch (FusedPCGNN.stage_epoch(n_epochs))
 FIRST_LABELED = {"amazon": 3305, "amazon_new": 2013}      # model_handler.py:38-40: the unlabeled Amazon users come first
 
 
@@ -267,15 +268,24 @@ class ModelHandler(object):
             epoch_dev = torch.zeros(2, dtype=torch.int64, device=dev)
         self.epoch_time = []
         epoch = -1
+        group_left = 0                                   # epochs of the current group (one launch) still to be accounted for
         for epoch in range(args.epochs):                                                                 # :128
             t0 = time.perf_counter()
-            if engine is not None:
-                # pick + shuffle + label lookup on the device, then every batch of the epoch (the last one partial; the
-                # empty batch the reference's int(len / B) + 1 can produce is not run): one graph launch
-                engine.stage_epoch(pick_size, args.batch_size)
-                engine.epoch_run(sample=lambda ids, lab: sampler.pick_shuffled(pick_size, ids, labels_dev, lab,
-                                                                                epoch_counter=epoch_dev, bump=False),
+            if engine is not None and group_left == 0:
+                # pick + shuffle + label lookup on the device, then every batch (an epoch's last one partial; the empty batch
+                # the reference's int(len / B) + 1 can produce is not run): one sampler launch, one plan launch and one graph
+                # launch for a GROUP of up to EPOCHS_PER_LAUNCH epochs - never across a validation point, the end of training
+                # or the first epoch at which the patience rule (:170-173) can stop the run, so the loop below behaves epoch by
+                # epoch exactly as the reference's
+                k = min(EPOCHS_PER_LAUNCH, args.valid_epochs - epoch % args.valid_epochs, args.epochs - epoch,
+                        max(1, epoch_best + args.patience + 2 - epoch))
+                engine.stage_epoch(pick_size, args.batch_size, k)
+                engine.epoch_run(sample=lambda ids, lab: sampler.pick_shuffled(pick_size, ids, labels_dev, lab, epoch_counter=epoch_dev,
+                                                                                bump=False, n_epochs=ids.numel() // pick_size),
                                  bump_counter=epoch_dev)
+                group_left = k
+            if engine is not None:
+                group_left -= 1
             else:
                 sampled = list(idx_train)                                                                # :132-133
                 random.shuffle(sampled)

@@ -6,7 +6,7 @@
 # (the box has no .git: every stats file gets a `# commit` line / a COMMIT file from PCG_COMMIT)
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r03}
+TAG=${1:-r04}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 export PCG_COMMIT=${PCG_COMMIT:-unknown}
@@ -37,6 +37,13 @@ for rho in 0.2 0.8; do echo "[collect] bench amazon rho $rho"; python3 $R/bench.
 echo "[collect] bench emb128 b4096"; python3 $R/bench.py --emb 128 --batch-size 4096 --cpu-batches 0 > $O/bench_yelp_emb128_b4096.log 2>&1 || exit 1
 echo "[collect] kernel trace emb128 b4096"; rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_e128 -o y -- python3 $R/bench.py --emb 128 --batch-size 4096 --cpu-batches 0 --report-epochs 0 --verify-batches 0 > $O/trace_e128.log 2>&1 || exit 1
 stamp $O/trace_e128/y_kernel_stats.csv
+E128="--emb 128 --batch-size 4096 --steps 24 --cpu-batches 0 --report-epochs 0 --verify-batches 0 --post-brackets 0"
+echo "[collect] pmc fetch emb128 b4096"; rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_e128 -o y -- python3 $R/bench.py $E128 > $O/pmc_fetch_e128.log 2>&1 || exit 1
+echo "[collect] pmc write emb128 b4096"; rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_e128 -o y -- python3 $R/bench.py $E128 > $O/pmc_write_e128.log 2>&1 || exit 1
+python3 $R/scripts/pmc_traffic.py $O/pmc_fetch_e128/y_counter_collection.csv $O/pmc_write_e128/y_counter_collection.csv yelp_b4096 $O/pmc_traffic.json $O/pmc_fetch_write_per_kernel_e128.csv > $O/pmc_traffic_e128.log 2>&1 || exit 1
+rm -rf $O/pmc_fetch_e128 $O/pmc_write_e128
+echo "[collect] stream / pipelining probes (negative results: scripts/pipe_probe.py)"; python3 $R/scripts/pipe_probe.py > $O/x_decoupled_phases_yelp_probe.log 2>&1 || exit 1
+PROBE_STREAMS=1 python3 $R/scripts/pipe_probe.py > $O/x_stream_pipeline_yelp_probe.log 2>&1 || exit 1
 echo "[collect] partitioned path, world size 1"; python3 $R/bench.py --force-partitioned --cpu-batches 0 > $O/bench_partitioned_w1.log 2>&1 || exit 1
 echo "[collect] kernel trace partitioned path"; rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_part -o y -- python3 $R/bench.py --force-partitioned --cpu-batches 0 > $O/trace_part.log 2>&1 || exit 1
 stamp $O/trace_part/y_kernel_stats.csv
@@ -46,6 +53,11 @@ if [ "$2" != "quick" ]; then
 echo "[collect] bench powerlaw 10M / 200M"; python3 $R/bench.py $PL10 --steps 60 --cpu-batches 0 > $O/bench_powerlaw_10m_200m.log 2>&1 || exit 1
 echo "[collect] kernel trace powerlaw 10M / 200M"; rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_pl10m -o y -- python3 $R/bench.py $PL10 --steps 40 --cpu-batches 0 --report-epochs 0 --verify-batches 0 > $O/trace_pl10m.log 2>&1 || exit 1
 stamp $O/trace_pl10m/y_kernel_stats.csv
+P10="$PL10 --steps 20 --cpu-batches 0 --report-epochs 0 --verify-batches 0 --post-brackets 0"
+echo "[collect] pmc fetch powerlaw 10M"; rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_pl10m -o y -- python3 $R/bench.py $P10 > $O/pmc_fetch_pl10m.log 2>&1 || exit 1
+echo "[collect] pmc write powerlaw 10M"; rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_pl10m -o y -- python3 $R/bench.py $P10 > $O/pmc_write_pl10m.log 2>&1 || exit 1
+python3 $R/scripts/pmc_traffic.py $O/pmc_fetch_pl10m/y_counter_collection.csv $O/pmc_write_pl10m/y_counter_collection.csv powerlaw_10000000_200000000_b4096 $O/pmc_traffic.json $O/pmc_fetch_write_per_kernel_powerlaw_10m.csv > $O/pmc_traffic_pl10m.log 2>&1 || exit 1
+rm -rf $O/pmc_fetch_pl10m $O/pmc_write_pl10m
 echo "[collect] bench powerlaw 10M / 200M, whole table scored"; PCG_TOUCHED=0 python3 $R/bench.py $PL10 --steps 60 --cpu-batches 0 --report-epochs 0 --verify-batches 0 > $O/bench_powerlaw_10m_200m_whole_table.log 2>&1 || exit 1
 echo "[collect] partitioned path, world size 1, sharded power-law 10M / 200M"; python3 $R/bench.py --force-partitioned $PL10 --steps 40 --cpu-batches 0 > $O/bench_partitioned_w1_powerlaw_10m.log 2>&1 || exit 1
 fi

@@ -142,99 +142,92 @@ def host3():
     main.wait_stream(side1); main.wait_stream(side2)
 
 
-# ---- P2: the pipelined step - ONE launch [select(t+1) || gather(t) || adam(t-1) || clf(t+2) || scores(t+2)] + dense(t) --------
-cap = int(lib.pcg_pos_sort_capacity(g.n_pos)) // 2
-s0b = [fz.s0, torch.empty_like(fz.s0)]
-raw = [torch.zeros(cap, dtype=torch.int64, device=dev) for _ in range(2)]
-ring = torch.stack([fz.clf_next.clone() for _ in range(4)])
-clf_counter = torch.zeros(1, dtype=torch.int32, device=dev)
-sort_done = torch.zeros(2, dtype=torch.int32, device=dev)
-keep = []
+# ---- D: the theta-independent half (scores, select, gather) of a whole group of batches on SIDE streams, with no event
+#         inside the group, beside the theta-dependent half (dense + Adam) on the main stream ------------------------------------
+nside = int(os.environ.get("PROBE_SIDE", "4"))
+sides = [torch.cuda.Stream(dev) for _ in range(nside)]
+datas = [torch.zeros_like(fz.data) for _ in range(nside)] if fz.data.numel() < (2 << 30) else None
+cnts = [torch.empty_like(fz.cnt) for _ in range(nside)]
+aggs = [torch.empty_like(fz.agg) for _ in range(nside)]
+s0s = [torch.empty_like(fz.s0) for _ in range(nside)]
+keyss = [torch.zeros_like(fz.keys) for _ in range(nside)]
+syncs = [torch.zeros_like(fz.sync) for _ in range(nside)]
 
 
-def pipe_launch(t, s, rows=True, gat=True, clf=True, score=True):
-    d = _lib.PipeDesc()
-    d.thresholds, d.rho = fz._thr, fz._rhos
-    d.list_capacity = fz.list_capacity
-    d.status, d.sync_words = fz.status.data_ptr(), fz.sync.data_ptr()
-    d.theta, d.m, d.v = fz.theta.data_ptr(), fz.m.data_ptr(), fz.v.data_ptr()
-    d.slabs, d.step_counter = fz.slabs.data_ptr(), fz.step_counter.data_ptr()
-    d.emb, d.apply_adam = fz.E, 1
-    d.lambda_1 = fz.lambda_1
-    d.lr, d.beta1, d.beta2, d.eps, d.weight_decay = fz.lr, b1, b2, fz.eps, fz.wd
-    d.pos_sorted = fz.keys.data_ptr()
-    if rows:
-        ids, lab, Bt, plan = batch(t + 1)
-        q = (t + 1) & 1
-        d.sel_nodes, d.sel_labels, d.sel_B, d.sel_plan = ids.data_ptr(), lab.data_ptr(), Bt, plan
-        d.sel_data, d.sel_cnt, d.sel_s0 = data[q].data_ptr(), cnt[q].data_ptr(), s0b[q].data_ptr()
-        d.sel_raw_keys, d.sel_sort_done = raw[q].data_ptr(), sort_done[q:].data_ptr()
-    if gat:
-        ids, lab, Bt, plan = batch(t)
-        q = t & 1
-        a = agg[0].view(-1)[:g.R * Bt * g.feat_dim].view(g.R, Bt, g.feat_dim)
-        d.gat_B, d.agg_stride, d.gat_plan, d.gat_data, d.gat_cnt, d.agg = Bt, a.stride(-2), plan, data[q].data_ptr(), cnt[q].data_ptr(), a.data_ptr()
-    if clf:
-        ids, lab, Bt, plan = batch(t + 2)
-        d.clf_nodes, d.clf_labels, d.clf_B = ids.data_ptr(), lab.data_ptr(), Bt
-        d.clf_inv_count = 1.0 / Bt
-        d.clf_in, d.clf_out, d.clf_counter = ring[(t + 2) % 4].data_ptr(), ring[(t + 3) % 4].data_ptr(), clf_counter.data_ptr()
-    if score:
-        d.clf_in = ring[(t + 2) % 4].data_ptr()
-        d.score_s0, d.score_raw_keys = s0b[t & 1].data_ptr(), raw[t & 1].data_ptr()
-    d.zero_word = sort_done[(t & 1):].data_ptr()
-    _lib.check(lib.pcg_pipe_step(g.desc_ref(), C.byref(d), st(s)), "pipe")
+def front_k(k, s):
+    _lib.check(lib.pcg_step_scores(g.desc_ref(), _p(fz.clf_next), C.c_void_p(fz.clf_next.data_ptr() + 8 * fz.F), 0, g.n_nodes, _p(s0s[k]),
+                                   None, _p(keyss[k]), -1, _p(syncs[k]), None, st(s)), "scores")
 
 
-def dense_p(t, s):
+def select_k(t, k, s):
     ids, lab, Bt, plan = batch(t)
-    a = agg[0].view(-1)[:g.R * Bt * g.feat_dim].view(g.R, Bt, g.feat_dim)
-    _lib.check(lib.pcg_train_dense(g.desc_ref(), _p(fz.theta), _p(fz.m), _p(fz.v), fz.E, _p(ids), _p(lab), Bt, _p(a), a.stride(1),
-                                   _p(cnt[t & 1]), _p(data[t & 1]), C.c_void_p(plan), fz.list_capacity, fz.lambda_1, 1.0 / Bt, _p(fz.logits),
-                                   _p(fz.center), None, _p(fz.row_loss), _p(fz.slabs), _p(fz.step_counter), _p(fz.sync), fz.lr, b1, b2,
-                                   fz.eps, fz.wd, 2, st(s)), "dense")
+    _lib.check(lib.pcg_choose_select_planned(g.desc_ref(), _p(ids), _p(lab), Bt, _p(s0s[k]), None, _p(keyss[k]), fz._thr, fz._rhos, 1, 0,
+                                             _p(cnts[k]), _p(datas[k]), C.c_void_p(plan), fz.list_capacity, _p(fz.status), _p(syncs[k]), 0,
+                                             st(s)), "select")
 
 
-def pipe_seq(T, s, parts=None):
-    kw = parts or {}
-    pipe_launch(-2, s, rows=False, gat=False)          # fill: clf(0), scores(0)
-    pipe_launch(-1, s, gat=False)                      # rows(0), clf(1), scores(1)
+def gather_k(t, k, s):
+    ids, lab, Bt, plan = batch(t)
+    a = aggs[k].view(-1)[:g.R * Bt * g.feat_dim].view(g.R, Bt, g.feat_dim)
+    _lib.check(lib.pcg_gather_lists_planned(_p(g.X), g.feat_dim, g.X.stride(0), g.n_nodes, g.R * Bt, _p(cnts[k]), g.desc_ref(), Bt,
+                                            _p(datas[k]), C.c_void_p(plan), fz.list_capacity, _p(a), a.stride(-2), _p(fz.status), st(s)), "gather")
+
+
+def adam_only(s):
+    _lib.check(lib.pcg_adam_step(_p(fz.theta), _p(fz.m), _p(fz.v), _p(fz.slabs), lib.pcg_dense_n_tiles(B), fz.n_params,
+                                 _p(fz.step_counter), fz.lr, b1, b2, fz.eps, fz.wd, None, 1, st(s)), "adam")
+
+
+def phase1(T, streams):
+    """scores | select | gather of T batches, batch t on stream t % len(streams): independent chains"""
     for t in range(T):
-        pipe_launch(t, s, **kw)
-        dense_p(t, s)
+        k = t % len(streams)
+        front_k(k, streams[k]); select_k(t, k, streams[k]); gather_k(t, k, streams[k])
 
 
-def seq3(T, s):
-    """the current three-launch step (pcg_choose_gather_train + dense), for reference"""
-    fz._enqueue_refresh()
+def phase2(T, s):
     for t in range(T):
-        ids, lab, Bt, plan = batch(t)
-        a, _ = fz._enqueue_choose_train(ids, lab, Bt, plan, True)
-        fz._enqueue_tail(ids, lab, Bt, a, plan, True)
+        dense(t, s); adam_only(s)
 
 
-pipe_seq(nb, main)
-torch.cuda.synchronize()
-print("status after an eager pipelined epoch:", int(fz.status.item()), flush=True)
-fz.status.zero_()
-grp = torch.cuda.CUDAGraph()
-with torch.cuda.graph(grp):
-    pipe_seq(T, torch.cuda.current_stream(dev))
-timeit(grp.replay, 40, T, f"P2 pipelined step: select_pipe + dense, one graph of {T} steps (+2 fill launches)")
-for name, parts in (("no gather", dict(gat=False)), ("no scores", dict(score=False)), ("no clf", dict(clf=False)), ("rows only", dict(gat=False, score=False, clf=False)),
-                    ("riders only", dict(rows=False))):
-    gq = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(gq):
-        pipe_seq(T, torch.cuda.current_stream(dev), parts)
-    timeit(gq.replay, 40, T, f"P2 {name}")
-g3 = torch.cuda.CUDAGraph()
-seq3(nb, main)
-torch.cuda.synchronize()
-with torch.cuda.graph(g3):
-    seq3(T, torch.cuda.current_stream(dev))
-timeit(g3.replay, 40, T, f"R3 the three-launch step, one graph of {T} steps")
-print("status:", int(fz.status.item()), flush=True)
-fz.status.zero_()
+def decoupled(T, main_s, side_list, overlap):
+    if overlap:                                  # phase 1 (of the "next" group) beside phase 2 (of this one)
+        for s in side_list:
+            s.wait_stream(main_s)
+        phase1(T, side_list)
+        phase2(T, main_s)
+        for s in side_list:
+            main_s.wait_stream(s)
+    else:
+        phase1(T, [main_s]); phase2(T, main_s)
+
+
+if datas is not None:
+    phase1(nb, [main]); phase2(nb, main)
+    torch.cuda.synchronize()
+    fz.status.zero_()
+    timeit(lambda: decoupled(T, main, sides, False), 10, T, "D3h phase 1 then phase 2, one stream, host launches")
+    timeit(lambda: decoupled(T, main, sides, True), 10, T, "D4h phase 1 on %d side streams beside phase 2, host launches" % nside)
+    timeit(lambda: phase2(T, main), 10, T, "D2h phase 2 alone, host launches")
+    for label, fn in (("D0 phase 1 alone (scores|select|gather x T), one stream", lambda m_, sd: phase1(T, [m_])),
+                      ("D1 phase 1 alone on %d streams" % nside, lambda m_, sd: (_fork(m_, sd), phase1(T, sd), _join(m_, sd))),
+                      ("D2 phase 2 alone (dense|adam x T)", lambda m_, sd: phase2(T, m_)),
+                      ("D3 phase 1 then phase 2, one stream", lambda m_, sd: decoupled(T, m_, sd, False)),
+                      ("D4 phase 1 on %d side streams BESIDE phase 2 on the main stream" % nside, lambda m_, sd: decoupled(T, m_, sd, True))):
+        def _fork(m_, sd):
+            for s_ in sd:
+                s_.wait_stream(m_)
+        def _join(m_, sd):
+            for s_ in sd:
+                m_.wait_stream(s_)
+        gq = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gq):
+            cs = torch.cuda.current_stream(dev)
+            sd = [torch.cuda.Stream(dev) for _ in range(nside)]
+            fn(cs, sd)
+        timeit(gq.replay, 30, T, label + " (graph)")
+    print("status:", int(fz.status.item()), flush=True)
+    fz.status.zero_()
 if os.environ.get("PROBE_STREAMS") != "1":
     print("done")
     sys.exit(0)

@@ -16,7 +16,7 @@ from collections import defaultdict
 # the launches of the select + aggregate call.  The training engine's pcg_choose_gather_train = select_rows (+ the label classifier's
 # step) and gather_train_kernel (gather + the deferred Adam update + the next step's score pass); no combine_rows (the dense kernel
 # finishes multi-chunk sums).  gather_chunks / combine_rows: the calls without the training riders.
-CALL_KERNELS = ("select_rows", "gather_train_kernel", "gather_chunks", "combine_rows")
+CALL_KERNELS = ("select_rows", "select_long_rows", "gather_train_kernel", "gather_chunks", "combine_rows")
 # 16 B per lane: FETCH_SIZE x 2.  (gather_train_kernel's Adam workgroups read the gradient slabs 4 B per lane - at most
 # n_tiles x n_params x 4 B per launch, 6.9 MB on the YelpChi-like batch: doubled with the rest, so that entry is an upper bound)
 WIDE_READERS = ("gather_train_kernel", "gather_chunks")
