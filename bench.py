@@ -529,21 +529,25 @@ def main():
         """n_steps training steps of the graph engine, in groups of K epochs (G = K * nb steps; the last group may be cut short).
         A group is ONE graph launch: sampler (pick + shuffle + labels of K epochs), plans of all its batches, every batch's three
         launches.  The second group of a phase and every `event_every`-th after it (the only group, if there is but one) is
-        event-bracketed instead: sampler and plans as launches of their own - the host gets ahead of the device behind them -,
-        the group's FIRST batch kernel by kernel with HIP events around pcg_choose_gather_train (the same kernels in the same
-        order), the rest of the group one graph launch."""
+        event-bracketed instead: one graph launch for everything but the group's LAST batch, which follows kernel by kernel with
+        HIP events around pcg_choose_gather_train (the same kernels in the same order)."""
         fz = tr.fused
         k, gi = 0, 0
         first_timed = 1 if n_steps > G else 0
         while k < n_steps:
             r = min(G, n_steps - k)
             if (gi - first_timed) % args.event_every == 0:
-                ids_all = tr.start_epoch_staged(K)
-                fz.epoch_step_timed(0, eager=True)
-                if measure:
-                    used_ev.append((ids_all[:fz._ep_batches[0][1]].clone(), fz.last_counts.clone()))
+                # (the bracketed batch is the group's LAST: its three kernels and the two event records are enqueued while the
+                #  device is busy with the graph in front of them, so the bracket holds the two kernels and nothing else - and the
+                #  host's launch latency is not paid on an idle device, as it was with the bracket at the head of the group)
                 if r > 1:
-                    fz.epoch_run(first_step=1, n_steps=r, flush=False)
+                    tr.run_epoch_one_graph(flush=False, n_steps=r - 1, n_epochs=K)
+                else:
+                    tr.start_epoch_staged(K)
+                fz.epoch_step_timed(r - 1, eager=True, flush=False)
+                if measure:
+                    lo, bsz = fz._ep_batches[r - 1]
+                    used_ev.append((fz._ep_ids[lo:lo + bsz].clone(), fz.last_counts.clone()))
             else:
                 tr.run_epoch_one_graph(flush=False, n_steps=r, n_epochs=K)
             if measure:

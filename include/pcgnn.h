@@ -259,6 +259,9 @@ int pcg_step_scores(const pcg_graph_desc *g, const float *W, const float *b, int
  * Nothing waits inside a launch for any of this.  On entry s0 / pos_keys hold THIS step's scores / unsorted keys (from the
  * previous step's call with score_next = 1, or from pcg_step_scores(W = clf_next, b = clf_next + 2 * feat_dim)).
  * pcg_adam_flush(..., clf_next) afterwards brings theta up to date (deferred update + the stepped classifier).
+ * acts != NULL (with act_ld; `slabs` is then only the classifier step's scratch, >= 8 * n_params floats): the previous step ran
+ * pcg_train_dense(adam_clf = 3) - no gradient slabs exist; the deferred update's workgroups are the weight-gradient GEMMs over
+ * that step's batch, each 16 x 16 output tile's workgroup applying Adam to its own parameters (pcg_wgrad below).
  * inv_count = 1 / global batch size.  Selection, lists and aggregates: exactly pcg_choose_gather_planned(train_flag = 1). */
 int pcg_choose_gather_train(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B, float *s0,
                             uint64_t *pos_keys, const double *thresholds, const double *rho, int32_t add_self, float *agg,
@@ -266,7 +269,7 @@ int pcg_choose_gather_train(const pcg_graph_desc *g, const int32_t *nodes, const
                             uint32_t *status, uint32_t *sync_words, float *theta, float *m, float *v, int32_t emb, float *clf_next,
                             const float *slabs, const int32_t *step_counter, float lambda_1, float inv_count, double lr, double beta1,
                             double beta2, double eps, double weight_decay, int32_t score_next, const uint8_t *next_touched,
-                            void *stream);
+                            const float *acts, int32_t act_ld, float *wg_scratch, void *stream);
 int32_t pcg_sync_words_count(void);                 /* uint32 words of a `sync_words` buffer (zero-initialised ONCE by the caller; the
                                                         kernels leave every word but [1], [2] zero between launches) */
 int pcg_aggregate_lists_planned(const float *X, int32_t feat_dim, int32_t feat_stride, int64_t table_rows, int32_t n_rows,
@@ -370,6 +373,13 @@ int pcg_adam_step(float *theta, float *m, float *v, const float *slabs, int32_t 
  *   - adam_clf == 2 (training; slabs, sync_words required): gradient slabs only, marked as waiting (sync_words[1] = 1,
  *     sync_words[2] = #slabs) for the deferred update of the next pcg_choose_gather_train / pcg_adam_flush; the label
  *     classifier's own step is pcg_choose_gather_train's (its share of the slabs is written but not used);
+ *   - adam_clf == 3 (training; acts, act_ld, sync_words required; slabs unused): NO gradient slabs.  The launch - one workgroup
+ *     per 16 batch rows - runs forward, loss and the activation gradients and leaves, TRANSPOSED (one batch row per column,
+ *     act_ld floats per row, act_ld >= B rounded up to 16, a multiple of 4; acts 16-byte aligned, pcg_wgrad_act_rows(...) rows):
+ *     [self | h_r] , agg_r, dcomb, dh_r, combined, dlogits, dcentre - what every weight gradient is a GEMM over the batch of
+ *     (src/layers.py:625-629, 284-289; src/model.py:54-61).  It marks them as waiting (sync_words[1] = 2, sync_words[2] = B / 16
+ *     rounded up) for the next pcg_choose_gather_train(acts) / pcg_adam_flush(acts), whose workgroups run those GEMMs (f32 MFMA,
+ *     fixed summation order) and apply Adam tile by tile.  adam_clf == 4: the same without marking (pcg_wgrad follows);
  *   - adam_clf == 1 (training: slabs, m, v, sync_words required): the workgroup that arrives last (device-scope ticket,
  *     write-through partial gradients) sums the label classifier's gradient over the tiles in tile order and applies
  *     Adam to those 2 * feat_dim + 2 parameters - the only ones the next step's score pass reads - and the launch marks the
@@ -386,7 +396,8 @@ int pcg_adam_step(float *theta, float *m, float *v, const float *slabs, int32_t 
  *   touched (may be NULL = score every row): this batch's byte map from pcg_mark_touched - only rows whose byte is set are
  *   scored (bit for bit the scores pcg_score_table gives them); the other entries of s0 keep whatever they held - the batch's
  *   selection never reads them.  For graphs whose feature table is far larger than what a batch touches.
- * pcg_adam_flush applies a still-deferred update now (two or three small launches) - before parameters are read or saved;
+ * pcg_adam_flush applies a still-deferred update now (two or three small launches) - before parameters are read or saved
+ *   (slabs may be NULL when acts is given: a step of adam_clf = 3 is applied by the weight-gradient GEMMs, sync_words[1] == 2);
  *   clf_next != NULL (the pcg_choose_gather_train step): the stepped label classifier is copied into theta [p_end, n_params) too,
  *   if an update was pending. */
 int pcg_step_scores_train(const pcg_graph_desc *g, float *theta, float *m, float *v, int32_t emb, float *s0,
@@ -415,7 +426,7 @@ int pcg_train_dense(const pcg_graph_desc *g, float *theta, float *m, float *v, i
                     const void *workspace, const void *plan, int64_t list_capacity, float lambda_1, float inv_count, float *logits,
                     float *center, float *combined, float *row_loss, float *slabs, int32_t *step_counter,
                     uint32_t *sync_words, double lr, double beta1, double beta2, double eps, double weight_decay,
-                    int32_t adam_clf, void *stream);
+                    int32_t adam_clf, float *acts, int32_t act_ld, void *stream);
 int pcg_step_front_train(const pcg_graph_desc *g, float *theta, float *m, float *v, int32_t emb, float *s0,
                          uint64_t *pos_keys, const int32_t *nodes, const int32_t *labels, int32_t B,
                          const double *thresholds, const double *rho, int32_t add_self, void *workspace,
@@ -434,7 +445,22 @@ int pcg_adam_apply_pending(float *theta, float *m, float *v, const float *grad, 
                            void *stream);
 int pcg_adam_flush(float *theta, float *m, float *v, const float *slabs, int32_t n_slabs, int64_t n_params, int64_t p_end,
                    const int32_t *step_counter, uint32_t *sync_words, double lr, double beta1, double beta2, double eps,
-                   double weight_decay, const float *clf_next, void *stream);
+                   double weight_decay, const float *clf_next, const float *acts, int32_t act_ld, int32_t feat_dim, int32_t emb,
+                   int32_t n_rel, float *wg_scratch, void *stream);
+/* The weight gradients of pcg_train_dense(adam_clf = 3 / 4)'s transposed activations as GEMMs over the batch (B rows; one
+ * 256-thread workgroup per 16 x 16 tile of a weight matrix, its four waves a quarter of the batch each, partial tiles added in
+ * wave order): grad_out [n_params] (may be NULL) gets the gradient, apply != 0 applies torch.optim.Adam's update (coupled weight
+ * decay; t = step_counter[0]) to the tile's parameters.  with_clf == 0 leaves the label classifier's 2 * feat_dim + 2 entries
+ * alone (its step is pcg_choose_gather_train's).  Batches beyond 1024 rows: a tile is shared by one workgroup per 1024 rows, whose
+ * partial tiles meet in wg_scratch (pcg_wgrad_scratch_bytes(feat_dim, emb, n_rel, largest B), zero-initialised ONCE by the caller:
+ * arrival tickets, left zero by every launch, then the partial tiles) and are added in part order by the one that arrives last;
+ * wg_scratch may be NULL for B <= 1024 (act_ld <= 1024 where the batch size is only known on the device: pcg_adam_flush,
+ * pcg_choose_gather_train).  act_ld: a multiple of 16.  Replaces src/model_handler.py:152-153 for those parameters. */
+int64_t pcg_wgrad_act_rows(int32_t feat_dim, int32_t emb, int32_t n_rel);
+int64_t pcg_wgrad_scratch_bytes(int32_t feat_dim, int32_t emb, int32_t n_rel, int32_t B);
+int pcg_wgrad(const float *acts, int32_t act_ld, int32_t B, int32_t feat_dim, int32_t emb, int32_t n_rel, float *theta, float *m,
+              float *v, const int32_t *step_counter, double lr, double beta1, double beta2, double eps, double weight_decay,
+              float *grad_out, int32_t apply, int32_t with_clf, float *wg_scratch, void *stream);
 
 /* ---- multi-GPU halo exchange helpers (no counterpart in the reference) ----------
  * A rank of a partitioned run holds the table [ owned rows | train-pos rows | halo ]; CSR rows and selection lists hold

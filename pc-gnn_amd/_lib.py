@@ -15,7 +15,7 @@ PCG_ST_SEL_OVERFLOW = 1
 PCG_ST_LIST_ID_RANGE = 2
 PCG_ST_SYNC_TIMEOUT = 4
 PCG_NORM_COUNT, PCG_NORM_SQRT_COUNT = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class GraphDesc(C.Structure):
@@ -63,7 +63,7 @@ PROTOTYPES = {
     "pcg_step_scores": (C.c_int, [_G, _P, _P, _I64, _I64, _P, _P, _P, _I64, _P, _P, _P]),
     "pcg_choose_gather_train": (C.c_int, [_G, _P, _P, _I32, _P, _P, C.POINTER(_F64), C.POINTER(_F64), _I32, _P, _I32, _P, _P, _P,
                                           _I64, _P, _P, _P, _P, _P, _I32, _P, _P, _P, C.c_float, C.c_float, _F64, _F64, _F64, _F64,
-                                          _F64, _I32, _P, _P]),
+                                          _F64, _I32, _P, _P, _I32, _P, _P]),
     "pcg_choose_plan_bytes": (_I64, [_G, _I32, _I64]),
     "pcg_choose_data_bytes": (_I64, [_G, _I32, _I64]),
     "pcg_plan_batches": (C.c_int, [_G, _P, _P, _I32, _I32, C.POINTER(_F64), C.POINTER(_F64), _I32, _I32, _P, _I64, _I64, _P, _P,
@@ -85,12 +85,16 @@ PROTOTYPES = {
                                             _P, _I32, _P, _P, _P, _I64, _P, _P, _P]),
     "pcg_gather_lists": (C.c_int, [_P, _I32, _I32, _I64, _I32, _P, _G, _I32, _P, _I64, _P, _I32, _P, _P]),
     "pcg_train_dense": (C.c_int, [_G, _P, _P, _P, _I32, _P, _P, _I32, _P, _I32, _P, _P, _P, _I64, C.c_float, C.c_float, _P, _P, _P,
-                                  _P, _P, _P, _P, _F64, _F64, _F64, _F64, _F64, _I32, _P]),
+                                  _P, _P, _P, _P, _F64, _F64, _F64, _F64, _F64, _I32, _P, _I32, _P]),
     "pcg_step_front_train": (C.c_int, [_G, _P, _P, _P, _I32, _P, _P, _P, _P, _I32, C.POINTER(_F64), C.POINTER(_F64), _I32, _P,
                                        _I64, _P, _P, _P, _P, _F64, _F64, _F64, _F64, _F64, _P]),
     "pcg_grad_reduce": (C.c_int, [_P, _I32, _I64, _P, _P, _P]),
     "pcg_adam_apply_pending": (C.c_int, [_P, _P, _P, _P, _I64, _P, _P, _I32, _F64, _F64, _F64, _F64, _F64, _P]),
-    "pcg_adam_flush": (C.c_int, [_P, _P, _P, _P, _I32, _I64, _I64, _P, _P, _F64, _F64, _F64, _F64, _F64, _P, _P]),
+    "pcg_adam_flush": (C.c_int, [_P, _P, _P, _P, _I32, _I64, _I64, _P, _P, _F64, _F64, _F64, _F64, _F64, _P, _P, _I32, _I32, _I32,
+                                 _I32, _P, _P]),
+    "pcg_wgrad_act_rows": (_I64, [_I32, _I32, _I32]),
+    "pcg_wgrad_scratch_bytes": (_I64, [_I32, _I32, _I32, _I32]),
+    "pcg_wgrad": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _F64, _F64, _F64, _F64, _F64, _P, _I32, _I32, _P, _P]),
     "pcg_debug_set_stamps": (None, [_P]),
     "pcg_debug_set_dense_stamps": (None, [_P]),
     "pcg_sel_capacity_row": (_I64, [_I64, _F64, _F64, _I32, _I32, _I32]),

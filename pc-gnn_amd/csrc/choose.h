@@ -2,6 +2,7 @@
 // (gather.hip): workspace layout, per-row records, launch arguments.
 #pragma once
 #include "common.h"
+#include "wgrad.h"
 
 namespace pcg {
 
@@ -208,7 +209,9 @@ int launch_select_rows(const ChooseArgs &a, hipStream_t st);
 // NEXT step's score pass + unsorted train-pos keys with the classifier the select launch has just stepped.
 struct SideJob {
     DeferredAdam ad;
-    int32_t n_adam_blocks;     // 0: no update
+    int32_t n_adam_blocks;     // 0: no update from slabs
+    WgradArgs wg;              // the deferred update from the dense kernel's transposed activations instead (wgrad.h) ...
+    int32_t n_wgrad_blocks;    // ... by this many workgroups (0: off)
     const float *W, *bias;     // the classifier to score with (ClfStep::clf_next), or null: no score pass
     float *s0;
     const unsigned char *touched;   // byte map of the rows the next batch reads, or null: the whole table

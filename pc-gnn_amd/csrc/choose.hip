@@ -543,7 +543,7 @@ __global__ void __launch_bounds__(FRONT_COUNT_THREADS) front_a_kernel(const Choo
         pos_key_body(a.g.X, a.g.feat_dim, a.g.feat_stride, W, bias, a.g.train_pos, a.g.n_pos, raw_keys, b - n_plan_blocks,
                      n_key_blocks, pos_row_base);
     else if (b < n_plan_blocks + n_key_blocks + n_adam_blocks) {
-        if (ad.pending[0] != 0u)                    // (one word, the same for every thread)
+        if (ad.pending[0] == 1u)                    // (one word, the same for every thread)
             adam_reduce_body(ad.theta, ad.m, ad.v, ad.slabs, (int)ad.pending[1], ad.n_params, 0, ad.p_end, ad.step_counter, ad.h,
                              nullptr, 1, b - n_plan_blocks - n_key_blocks, part);
     } else if (touched)       // only the rows the batch's selection can read (the whole table: row_begin == 0, no row_ids)
@@ -1000,10 +1000,12 @@ int pcg_choose_gather_train(const pcg_graph_desc *g, const int32_t *nodes, const
                             uint32_t *status, uint32_t *sync_words, float *theta, float *m, float *v, int32_t emb, float *clf_next,
                             const float *slabs, const int32_t *step_counter, float lambda_1, float inv_count, double lr, double beta1,
                             double beta2, double eps, double weight_decay, int32_t score_next, const uint8_t *next_touched,
-                            void *stream) {
+                            const float *acts, int32_t act_ld, float *wg_scratch, void *stream) {
     if (!g || B < 0) return PCG_E_ARG;
     if (B == 0) return PCG_OK;
     if (!g->X || !agg || !s0 || !sync_words || !theta || !m || !v || !clf_next || !slabs || !step_counter || !labels) return PCG_E_ARG;
+    if (acts && (act_ld < 16 || act_ld % 16 != 0 || (reinterpret_cast<uintptr_t>(acts) & 15u) != 0 || emb % 16 != 0)) return PCG_E_ARG;
+    if (acts && pcg::wgrad_kparts(act_ld / 16) > 1 && !wg_scratch) return PCG_E_ARG;
     if (g->feat_stride > 512) return PCG_E_UNSUPPORTED;
     const int64_t n_params = pcg_dense_n_params(g->feat_dim, emb, g->n_rel);
     const int64_t o_clf = pcg_dense_param_offset(g->feat_dim, emb, g->n_rel, 3, 0);
@@ -1049,7 +1051,23 @@ int pcg_choose_gather_train(const pcg_graph_desc *g, const int32_t *nodes, const
     sd.ad.step_counter = step_counter;
     sd.ad.pending = sync_words + 1;
     sd.ad.h = h;
-    sd.n_adam_blocks = (int)((o_clf + PCG_WAVE - 1) / PCG_WAVE);
+    sd.n_adam_blocks = acts ? 0 : (int)((o_clf + PCG_WAVE - 1) / PCG_WAVE);
+    // acts: the previous step's pcg_train_dense(adam_clf = 3) left activations, not slabs - the weight gradients are GEMMs over
+    // its batch, each output tile's workgroup applying Adam to its own parameters (wgrad.h)
+    sd.wg.acts = acts; sd.wg.ld = act_ld;
+    sd.wg.F = g->feat_dim; sd.wg.E = emb; sd.wg.R = g->n_rel;
+    sd.wg.theta = theta; sd.wg.m = m; sd.wg.v = v;
+    sd.wg.step_counter = step_counter;
+    sd.wg.h = h;
+    sd.wg.pending = sync_words + 1;
+    sd.wg.n_kblocks = act_ld / 16;               // (the batch size the engine's buffers were made for: the expected one)
+    sd.wg.kparts = acts ? pcg::wgrad_kparts(act_ld / 16) : 1;
+    sd.wg.tickets = reinterpret_cast<uint32_t *>(wg_scratch);
+    sd.wg.partials = wg_scratch ? wg_scratch + (pcg::wgrad_tiles(g->feat_dim, emb, g->n_rel, 1) + 63) / 64 * 64 : nullptr;
+    sd.wg.grad_out = nullptr;
+    sd.wg.apply = 1;
+    sd.wg.with_clf = 0;
+    sd.n_wgrad_blocks = acts ? pcg::wgrad_tiles(g->feat_dim, emb, g->n_rel, 0) * sd.wg.kparts : 0;
     sd.W = score_next ? clf_next : nullptr;
     sd.bias = clf_next + 2 * g->feat_dim;
     sd.s0 = s0;

@@ -21,6 +21,7 @@
 // Gradients never flow into the gathered features or the selection (features frozen,
 // model_handler.py:86; selection is index-only), so backward is dense GEMMs only.
 #include "choose.h"
+#include "wgrad.h"
 
 namespace pcg {
 
@@ -55,6 +56,8 @@ struct DenseArgs {
     float *combined;            // [B, E] or null
     float *row_loss;            // [B] or null
     float *slabs;               // [n_tiles, n_params] or null
+    float *acts;                // [wgrad_act_rows][act_ld] or null: the step's activations / activation gradients, transposed
+    int32_t act_ld;             //   (wgrad.h) INSTEAD of weight-gradient slabs - the weight gradients are GEMMs of a later launch
     int64_t n_params;
     int32_t *step_counter;      // incremented once per training launch (Adam's t), or null
     int32_t n_split;            // training: workgroups per 16-row tile; they all run the forward pass, the weight-gradient tiles are dealt out
@@ -225,13 +228,14 @@ __global__ void __launch_bounds__(DENSE_THREADS) dense_step_kernel(const DenseAr
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int S = a.n_split, tile_id = (int)blockIdx.x / S, sp = (int)blockIdx.x % S;
     const int row0 = tile_id * TB;
-    const bool train = a.slabs != nullptr;
+    const bool acts_mode = a.acts != nullptr;
+    const bool train = a.slabs != nullptr || acts_mode;
     if (train && blockIdx.x == 0 && tid == 0) {
         // (an agent-scope atomic: the workgroup that applies the classifier's Adam reads the new count from another XCD)
         if (a.step_counter) __hip_atomic_fetch_add(a.step_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (a.pending) {
-            a.pending[0] = 1u;                                  // the slabs hold a gradient the other parameters still need
-            a.pending[1] = (unsigned)(gridDim.x / S);           // ... in this many slabs
+            a.pending[0] = acts_mode ? 2u : 1u;                 // the slabs (1) / acts (2) hold a gradient the other parameters still need
+            a.pending[1] = (unsigned)(gridDim.x / S);           // ... in this many slabs / blocks of 16 batch rows
         }
     }
     // wave t's row of the loss phase: its label is requested now, not when the logits are ready
@@ -469,7 +473,7 @@ __global__ void __launch_bounds__(DENSE_THREADS) dense_step_kernel(const DenseAr
     DENSE_STAMP(4);
     if (!train) return;
 
-    float *slab = a.slabs + (size_t)tile_id * a.n_params;
+    float *slab = acts_mode ? nullptr : a.slabs + (size_t)tile_id * a.n_params;
     const bool adam_clf = a.theta != nullptr;
     // ---- backward ----------------------------------------------------------------------------------------------------
     // dcomb = (dlogits W_cls) * relu'(combined);  dW_cls, dW_clf, db_clf
@@ -479,7 +483,7 @@ __global__ void __launch_bounds__(DENSE_THREADS) dense_step_kernel(const DenseAr
         s_dcomb[t * ldE + e] = s_comb[t * ldE + e] > 0.f ? g : 0.f;
     }
     DENSE_STAMP(8);
-    for (int i = tid; i < (sp == 0 ? 2 * E : 0); i += DENSE_THREADS) {
+    for (int i = tid; i < ((sp == 0 && !acts_mode) ? 2 * E : 0); i += DENSE_THREADS) {
         const int cidx = i / E, e = i - cidx * E;
         float sacc = 0.f;
         for (int t = 0; t < TB; ++t) sacc = fmaf(s_dlog[2 * t + cidx], s_comb[t * ldE + e], sacc);
@@ -490,7 +494,7 @@ __global__ void __launch_bounds__(DENSE_THREADS) dense_step_kernel(const DenseAr
     // will read it - that wave's own vmcnt wait, a phase later, then covers every one of them.  The wave chosen has no other
     // global store in between (the last of the waves that only compute a dh_r tile in the next phase), so that wait is free.
     const int clf_wave = (R * ntile_e - 1) & (DENSE_WAVES - 1);
-    if (wave == clf_wave && sp == 0) {
+    if (wave == clf_wave && sp == 0 && !acts_mode) {
         for (int i = lane; i < 2 * F + 2; i += PCG_WAVE) {
             float sacc = 0.f;
             if (i < 2 * F) {
@@ -511,9 +515,10 @@ __global__ void __launch_bounds__(DENSE_THREADS) dense_step_kernel(const DenseAr
     {
         const int mt2 = (K2 + 15) / 16;
         const int n_dh = R * ntile_e, n_all = n_dh + mt2 * ntile_e;
-        float *dst = slab + off_inter(F, E, R);
+        float *dst = slab ? slab + off_inter(F, E, R) : nullptr;
         // every workgroup of the tile needs all of dh_r; the dW_inter tiles are dealt out over the tile's S workgroups
-        for (int t0 = wave; t0 < n_dh + (n_all - n_dh + S - 1) / S; t0 += DENSE_WAVES) {
+        // (acts_mode: dh_r only - the weight gradients are a later launch's)
+        for (int t0 = wave; t0 < (acts_mode ? n_dh : n_dh + (n_all - n_dh + S - 1) / S); t0 += DENSE_WAVES) {
             const int tile = t0 < n_dh ? t0 : n_dh + (t0 - n_dh) * S + sp;
             if (tile >= n_all) continue;
             if (tile < n_dh) {
@@ -543,6 +548,32 @@ __global__ void __launch_bounds__(DENSE_THREADS) dense_step_kernel(const DenseAr
     }
     __syncthreads();
     DENSE_STAMP(6);
+    if (acts_mode) {
+        // everything the weight gradients are made of, transposed (a batch row per column: the GEMMs over the batch then read
+        // both operands contiguously - wgrad.h); rows beyond the batch in this tile are zero in every array (staged as zeros,
+        // no loss gradient).  A thread stores 16-float runs (one act row of this tile: 64 bytes); nothing reads them in this launch.
+        const int n_act = K2 + R * F + E + R * E + E + 4;
+        float *__restrict__ out = a.acts + row0;
+        for (int i = tid; i < n_act * TB; i += DENSE_THREADS) {
+            const int rho = i >> 4, t = i & 15;
+            int q = rho;
+            float v;
+            if (q < K2) v = s_cat[t * ld2 + q];
+            else if ((q -= K2) < R * F) {
+                const int r = q / F, f = q - r * F;
+                v = s_catr[(r * TB + t) * ld1 + F + f];
+            } else if ((q -= R * F) < E) v = s_dcomb[t * ldE + q];
+            else if ((q -= E) < R * E) {
+                const int r = q / E, e = q - r * E;
+                v = s_dh[(r * TB + t) * ldE + e];
+            } else if ((q -= R * E) < E) v = s_comb[t * ldE + q];
+            else if ((q -= E) < 2) v = s_dlog[2 * t + q];
+            else v = s_dcl[2 * t + (q - 2)];
+            out[(size_t)rho * a.act_ld + t] = v;
+        }
+        DENSE_STAMP(7);
+        return;
+    }
     // arrival ticket (the workgroup's classifier gradient - its clf wave's stores, issued a phase ago - is write-through and
     // drained; and a workgroup that has arrived has long read the classifier's weights).  The answer is not needed before the
     // end of the kernel, so nobody waits for it here.
@@ -650,11 +681,17 @@ __global__ void __launch_bounds__(256) adam_reduce_kernel(float *__restrict__ th
                                                           const int32_t *__restrict__ step_counter, AdamHyper h,
                                                           float *__restrict__ grad_out, int apply, const uint32_t *pending) {
     __shared__ float part[4][PCG_WAVE];
-    if (pending) {                                    // the deferred update: nothing to do unless a gradient is waiting
-        if (pending[0] == 0u) return;                 // (wave-uniform: one word)
+    if (pending) {                                    // the deferred update: nothing to do unless a gradient is waiting in the slabs
+        if (pending[0] != 1u) return;                 // (wave-uniform: one word; 2 = it waits in `acts`: wgrad_adam_kernel's)
         n_slabs = (int)pending[1];
     }
     adam_reduce_body(theta, m, v, slabs, n_slabs, n_params, p_begin, p_end, step_counter, h, grad_out, apply, (int)blockIdx.x, part);
+}
+
+// the weight gradients from the dense kernel's transposed activations + Adam (wgrad.h), as a launch of its own
+__global__ void __launch_bounds__(256) wgrad_adam_kernel(const WgradArgs a) {
+    __shared__ float red[4][256];
+    wgrad_adam_body(a, (int)blockIdx.x, red);
 }
 
 __global__ void clear_word_kernel(uint32_t *w) { w[0] = 0u; }
@@ -713,6 +750,8 @@ struct DenseExtra {          // the optional parts of a launch
     int32_t partial_stride = 0;
     float *theta_rw = nullptr, *m = nullptr, *v = nullptr;
     uint32_t *ticket = nullptr, *pending = nullptr, *staged = nullptr;
+    float *acts = nullptr;
+    int32_t act_ld = 0;
     AdamHyper h = {0.f, 0.f, 0.f, 0.f, 0.f};
 };
 
@@ -724,7 +763,8 @@ static int launch_dense(const pcg_graph_desc *g, const float *theta, int32_t emb
     if (B == 0) return PCG_OK;
     if (!ids || !agg || !logits || !center) return PCG_E_ARG;
     if (emb < 16 || emb % 16 != 0 || g->n_rel < 1 || g->n_rel > PCG_MAX_REL) return PCG_E_UNSUPPORTED;
-    if (slabs && !labels) return PCG_E_ARG;
+    if ((slabs || x.acts) && !labels) return PCG_E_ARG;
+    if (x.acts && (x.act_ld < (B + TB - 1) / TB * TB || x.act_ld % 4 != 0 || (reinterpret_cast<uintptr_t>(x.acts) & 15u) != 0)) return PCG_E_ARG;
     if (x.theta_rw && (!slabs || !x.m || !x.v || !x.ticket || !step_counter)) return PCG_E_ARG;
     if (x.chunk_begin && (!x.partial || !x.cnt)) return PCG_E_ARG;
     const int F = g->feat_dim, E = emb, R = g->n_rel;
@@ -757,7 +797,9 @@ static int launch_dense(const pcg_graph_desc *g, const float *theta, int32_t emb
     a.center = center;
     a.combined = combined;
     a.row_loss = row_loss;
-    a.slabs = slabs;
+    a.slabs = x.acts ? nullptr : slabs;
+    a.acts = x.acts;
+    a.act_ld = x.act_ld;
     a.n_params = n_params_of(F, E, R);
     a.step_counter = step_counter;
     a.theta = x.theta_rw;
@@ -770,7 +812,8 @@ static int launch_dense(const pcg_graph_desc *g, const float *theta, int32_t emb
     // few tiles (small batches): up to 4 workgroups per tile, so that the weight-gradient tiles of a 16-row tile are not one
     // CU's serial work while most of the chip idles
     const int n_tiles = (B + TB - 1) / TB;
-    int n_split = slabs ? 256 / n_tiles : 1;
+    // (acts instead of slabs: no weight-gradient tiles to deal out - one workgroup per tile)
+    int n_split = (slabs && !x.acts) ? 256 / n_tiles : 1;
     a.n_split = n_split < 1 ? 1 : (n_split > 4 ? 4 : n_split);
     a.stamps = g_dense_stamps;
     // the instantiated shapes: YelpChi (F 32) and Amazon (F 25) at emb 64 and 128, three relations; anything else: run-time shape
@@ -835,7 +878,8 @@ int pcg_train_dense(const pcg_graph_desc *g, float *theta, float *m, float *v, i
                     const int32_t *labels, int32_t B, const float *agg, int32_t agg_stride, const int32_t *cnt,
                     const void *workspace, const void *plan, int64_t list_capacity, float lambda_1, float inv_count, float *logits, float *center,
                     float *combined, float *row_loss, float *slabs, int32_t *step_counter, uint32_t *sync_words, double lr,
-                    double beta1, double beta2, double eps, double weight_decay, int32_t adam_clf, void *stream) {
+                    double beta1, double beta2, double eps, double weight_decay, int32_t adam_clf, float *acts, int32_t act_ld,
+                    void *stream) {
     if (!g || B < 0) return PCG_E_ARG;
     pcg::DenseExtra x;
     if (workspace) {
@@ -848,7 +892,16 @@ int pcg_train_dense(const pcg_graph_desc *g, float *theta, float *m, float *v, i
         x.cnt = cnt;
         x.partial_stride = g->feat_stride;
     }
-    if (adam_clf == 2) {                     // the label classifier is stepped elsewhere (pcg_choose_gather_train): slabs + "pending" only
+    if (adam_clf == 3) {                     // no slabs: transposed activations for the weight-gradient GEMMs of a later launch
+        if (!acts || !sync_words) return PCG_E_ARG;
+        x.pending = sync_words + 1;
+        x.acts = acts;
+        x.act_ld = act_ld;
+    } else if (adam_clf == 4) {              // the same without marking anything as waiting (pcg_wgrad follows: gradients only)
+        if (!acts) return PCG_E_ARG;
+        x.acts = acts;
+        x.act_ld = act_ld;
+    } else if (adam_clf == 2) {              // the label classifier is stepped elsewhere (pcg_choose_gather_train): slabs + "pending" only
         if (!slabs || !sync_words) return PCG_E_ARG;
         x.pending = sync_words + 1;
     } else if (adam_clf) {
@@ -903,15 +956,86 @@ int pcg_adam_apply_pending(float *theta, float *m, float *v, const float *grad, 
     return PCG_OK;
 }
 
+static int wgrad_args(pcg::WgradArgs &w, const float *acts, int32_t act_ld, int32_t feat_dim, int32_t emb, int32_t n_rel,
+                      int32_t n_kblocks, float *scratch) {
+    if (!acts || act_ld < 16 || act_ld % 16 != 0 || (reinterpret_cast<uintptr_t>(acts) & 15u) != 0) return PCG_E_ARG;
+    if (feat_dim < 1 || emb < 16 || emb % 16 != 0 || n_rel < 1 || n_rel > PCG_MAX_REL) return PCG_E_UNSUPPORTED;
+    if (n_kblocks < 1 || n_kblocks * 16 > act_ld) return PCG_E_ARG;
+    w.acts = acts;
+    w.ld = act_ld;
+    w.F = feat_dim;
+    w.E = emb;
+    w.R = n_rel;
+    w.n_kblocks = n_kblocks;
+    w.kparts = pcg::wgrad_kparts(n_kblocks);
+    w.tickets = nullptr;
+    w.partials = nullptr;
+    if (w.kparts > 1) {
+        if (!scratch) return PCG_E_ARG;
+        const int t = pcg::wgrad_tiles(feat_dim, emb, n_rel, 1);
+        w.tickets = reinterpret_cast<uint32_t *>(scratch);
+        w.partials = scratch + (t + 63) / 64 * 64;
+    }
+    return PCG_OK;
+}
+
+int64_t pcg_wgrad_act_rows(int32_t feat_dim, int32_t emb, int32_t n_rel) {
+    if (feat_dim < 1 || emb < 1 || n_rel < 1 || n_rel > PCG_MAX_REL) return PCG_E_ARG;
+    return pcg::wgrad_act_rows(feat_dim, emb, n_rel);
+}
+
+int64_t pcg_wgrad_scratch_bytes(int32_t feat_dim, int32_t emb, int32_t n_rel, int32_t B) {
+    if (feat_dim < 1 || emb < 16 || emb % 16 != 0 || n_rel < 1 || n_rel > PCG_MAX_REL || B < 1) return PCG_E_ARG;
+    return 4 * pcg::wgrad_scratch_floats(feat_dim, emb, n_rel, (B + 15) / 16);
+}
+
+int pcg_wgrad(const float *acts, int32_t act_ld, int32_t B, int32_t feat_dim, int32_t emb, int32_t n_rel, float *theta, float *m,
+              float *v, const int32_t *step_counter, double lr, double beta1, double beta2, double eps, double weight_decay,
+              float *grad_out, int32_t apply, int32_t with_clf, float *scratch, void *stream) {
+    pcg::WgradArgs w;
+    if (B < 1) return PCG_E_ARG;
+    const int rc = wgrad_args(w, acts, act_ld, feat_dim, emb, n_rel, (B + 15) / 16, scratch);
+    if (rc != PCG_OK) return rc;
+    if (apply && (!theta || !m || !v || !step_counter)) return PCG_E_ARG;
+    if (!apply && !grad_out) return PCG_E_ARG;
+    w.theta = theta; w.m = m; w.v = v;
+    w.step_counter = step_counter;
+    w.h = {(float)lr, (float)beta1, (float)beta2, (float)eps, (float)weight_decay};
+    w.pending = nullptr;
+    w.grad_out = grad_out;
+    w.apply = apply;
+    w.with_clf = with_clf ? 1 : 0;
+    hipLaunchKernelGGL(pcg::wgrad_adam_kernel, dim3((unsigned)(pcg::wgrad_tiles(feat_dim, emb, n_rel, w.with_clf) * w.kparts)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), w);
+    PCG_LAUNCH_CHECK();
+    return PCG_OK;
+}
+
 int pcg_adam_flush(float *theta, float *m, float *v, const float *slabs, int32_t n_slabs, int64_t n_params, int64_t p_end,
                    const int32_t *step_counter, uint32_t *sync_words, double lr, double beta1, double beta2, double eps,
-                   double weight_decay, const float *clf_next, void *stream) {
-    if (!theta || !m || !v || !slabs || !step_counter || !sync_words || n_slabs < 0 || n_params < 1 || p_end < 0 ||
+                   double weight_decay, const float *clf_next, const float *acts, int32_t act_ld, int32_t feat_dim, int32_t emb,
+                   int32_t n_rel, float *wg_scratch, void *stream) {
+    if (!theta || !m || !v || (!slabs && !acts) || !step_counter || !sync_words || n_slabs < 0 || n_params < 1 || p_end < 0 ||
         p_end > n_params)
         return PCG_E_ARG;
     const pcg::AdamHyper h = {(float)lr, (float)beta1, (float)beta2, (float)eps, (float)weight_decay};
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (p_end > 0) {
+    if (acts) {                              // a step of pcg_train_dense(adam_clf = 3) waiting (sync_words[1] == 2): weight-gradient GEMMs + Adam
+        pcg::WgradArgs w;
+        const int rc = wgrad_args(w, acts, act_ld, feat_dim, emb, n_rel, act_ld / 16, wg_scratch);
+        if (rc != PCG_OK) return rc;
+        if (pcg::n_params_of(feat_dim, emb, n_rel) != n_params) return PCG_E_ARG;
+        w.theta = theta; w.m = m; w.v = v;
+        w.step_counter = step_counter;
+        w.h = h;
+        w.pending = sync_words + 1;
+        w.grad_out = nullptr;
+        w.apply = 1;
+        w.with_clf = p_end > pcg::off_clf(feat_dim, emb, n_rel) ? 1 : 0;
+        hipLaunchKernelGGL(pcg::wgrad_adam_kernel, dim3((unsigned)(pcg::wgrad_tiles(feat_dim, emb, n_rel, w.with_clf) * w.kparts)), dim3(256), 0, st, w);
+        PCG_LAUNCH_CHECK();
+    }
+    if (p_end > 0 && slabs) {
         hipLaunchKernelGGL(pcg::adam_reduce_kernel, dim3((unsigned)((p_end + PCG_WAVE - 1) / PCG_WAVE)), dim3(256), 0, st, theta, m,
                            v, slabs, n_slabs, n_params, (int64_t)0, p_end, step_counter, h, (float *)nullptr, 1,
                            (const uint32_t *)(sync_words + 1));

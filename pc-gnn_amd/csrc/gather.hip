@@ -171,19 +171,27 @@ __global__ void __launch_bounds__(256) gather_chunks(const AggArgs a) {
 template <int NACC>
 __global__ void __launch_bounds__(256) PCG_GT_ATTR gather_train_kernel(const AggArgs a, const SideJob s, int n_gather_blocks, int64_t n_nodes,
                                                            const int32_t *__restrict__ train_pos, int n_pos) {
-    __shared__ float part[4][PCG_WAVE];
+    __shared__ float part[4][256];                            // adam_reduce_body uses [4][64] of it, wgrad_adam_body all
     __shared__ unsigned short sel[4 * MARK_GROUP];            // score_marked_body
     int b = (int)blockIdx.x;
     if (s.zero_word && b == 0 && threadIdx.x == 0) s.zero_word[0] = 0u;     // the select kernel's arrival counter, for its next launch
+    // the previous step's weight gradients (GEMMs over its batch) + Adam (wgrad.h) come FIRST in the launch's workgroup order:
+    // two memory round trips + a few dozen matrix instructions per wave is the longest chain in the launch - dispatched behind
+    // the gather's workgroups it started when they ended
+    if (b < s.n_wgrad_blocks) {
+        wgrad_adam_body(s.wg, b, part);
+        return;
+    }
+    b -= s.n_wgrad_blocks;
     if (b < n_gather_blocks) {
         gather_chunks_body<NACC>(a, (uint32_t)b, (uint32_t)n_gather_blocks);
         return;
     }
     b -= n_gather_blocks;
     if (b < s.n_adam_blocks) {
-        if (s.ad.pending[0] != 0u)                            // (one word, the same for every thread)
+        if (s.ad.pending[0] == 1u)                            // (one word, the same for every thread)
             adam_reduce_body(s.ad.theta, s.ad.m, s.ad.v, s.ad.slabs, (int)s.ad.pending[1], s.ad.n_params, 0, s.ad.p_end,
-                             s.ad.step_counter, s.ad.h, nullptr, 1, b, part);
+                             s.ad.step_counter, s.ad.h, nullptr, 1, b, reinterpret_cast<float (*)[PCG_WAVE]>(&part[0][0]));
         return;
     }
     b -= s.n_adam_blocks;
@@ -285,7 +293,7 @@ int launch_gather_train(const float *X, int32_t feat_dim, int32_t feat_stride, i
     if ((reinterpret_cast<uintptr_t>(X) & 15u) != 0) return PCG_E_ARG;
     AggArgs a;
     fill_agg_args(a, X, feat_dim, feat_stride, table_rows, g->n_rel * B, cnt, w, PCG_NORM_COUNT, agg, agg_stride, status);
-    const int extra = side.n_adam_blocks + side.n_key_blocks + side.n_score_blocks;
+    const int extra = side.n_adam_blocks + side.n_wgrad_blocks + side.n_key_blocks + side.n_score_blocks;
     // workgroups of the gather group: half the stand-alone launch's - the riders' workgroups are dispatched behind them, and at
     // dataset scale most of the 2048 found no chunk (measured, 2048 / 1024 / 512: YelpChi-like 53.3 / 51.9 / 52.8 us per step,
     // power-law 2 M 149.2 / 146.4 / - )

@@ -286,7 +286,7 @@ int pcg_gather_rows(const pcg_graph_desc *g, const int32_t *ids, int32_t n_ids, 
     return PCG_OK;
 }
 
-const char *pcg_version(void) { return "pcgnn_hip gfx950 abi2"; }
-int pcg_abi_version(void) { return 2; }
+const char *pcg_version(void) { return "pcgnn_hip gfx950 abi3"; }
+int pcg_abi_version(void) { return 3; }
 
 }  // extern "C"

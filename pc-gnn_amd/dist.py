@@ -521,7 +521,7 @@ class DistributedPCGNN:
                                   agg.stride(1), _p(self.cnt), _p(self.data), C.c_void_p(plan), self.list_capacity, float(c["alpha"]),
                                   1.0 / (B * self.world), _p(self.logits), _p(self.center), None, _p(self.row_loss),
                                   _p(self.slabs), _p(self.step_counter), None, c["lr"], 0.9, 0.999, 1e-8, c["weight_decay"], 0,
-                                  st), "pcg_train_dense")
+                                  None, 0, st), "pcg_train_dense")
         check(lib.pcg_grad_reduce(_p(self.slabs), lib.pcg_dense_n_tiles(B), self.n_params, _p(self.grad), _p(self.opt_flag), st),
               "pcg_grad_reduce")
 

@@ -153,7 +153,14 @@ class FusedPCGNN:
         self.logits = torch.empty(B, 2, dtype=torch.float32, device=dev)
         self.center = torch.empty(B, 2, dtype=torch.float32, device=dev)
         self.row_loss = torch.zeros(B, dtype=torch.float32, device=dev)
-        self.slabs = torch.empty(lib.pcg_dense_n_tiles(B), self.n_params, dtype=torch.float32, device=dev)
+        self.slabs = torch.empty(max(lib.pcg_dense_n_tiles(B), 8), self.n_params, dtype=torch.float32, device=dev)
+        # the training step's dense kernel leaves no gradient slabs: it leaves the step's activations / activation gradients,
+        # transposed ([rows][act_ld], a batch row per column), and the weight gradients are GEMMs over the batch riding in the next
+        # step's gather launch (pcg_train_dense(adam_clf = 3), wgrad.h).  (slabs: the gradient-only paths - gradients(via="slabs"),
+        # data-parallel all-reduce - and the classifier step's scratch)
+        self.act_ld = 16 * int(lib.pcg_dense_n_tiles(B))
+        self.acts = torch.zeros(int(lib.pcg_wgrad_act_rows(self.F, self.E, self.R)), self.act_ld, dtype=torch.float32, device=dev)
+        self.wg_scratch = torch.zeros(int(lib.pcg_wgrad_scratch_bytes(self.F, self.E, self.R, self.act_ld)) // 4, dtype=torch.float32, device=dev)
         self.ids_buf = torch.zeros(B, dtype=torch.int32, device=dev)
         self.lab_buf = torch.zeros(B, dtype=torch.int32, device=dev)
 
@@ -256,7 +263,8 @@ class FusedPCGNN:
             _p(agg), agg.stride(-2), _p(cnt), _p(self.data), C.c_void_p(plan), self.list_capacity, _p(self.status), _p(self.sync),
             _p(self.theta), _p(self.m), _p(self.v), self.E, _p(self.clf_next), _p(self.slabs), _p(self.step_counter),
             self.lambda_1, 1.0 / (B * self.scale), self.lr, b1, b2, self.eps, self.wd, 1 if score_next else 0,
-            None if next_touched is None else C.c_void_p(next_touched), self._stream()), "pcg_choose_gather_train")
+            None if next_touched is None else C.c_void_p(next_touched), _p(self.acts), self.act_ld, _p(self.wg_scratch),
+            self._stream()), "pcg_choose_gather_train")
         if timed:
             ev[1].record()
             self._prof.append(ev)
@@ -288,19 +296,21 @@ class FusedPCGNN:
 
     def _enqueue_tail(self, ids, labels, B, agg, plan: int, train: bool, combined=None, adam_clf: Optional[bool] = None):
         """dense tail reading the gather's partial sums (no combine launch); training: the gradient slabs are left pending
-        (adam_clf 2: the next step's gather launch or flush() applies them; the label classifier has been stepped by this step's
-        select launch).  adam_clf=0 (training): gradient slabs only - the caller reduces / all-reduces them itself; 1: the
-        label classifier's Adam by the kernel's last workgroup (the four-launch step of pcg_step_scores_train)."""
+        (adam_clf 3, the default: no slabs at all - the kernel leaves its transposed activations and the next step's gather launch
+        or flush() runs the weight-gradient GEMMs + Adam; 2: the same with per-tile gradient slabs; either way the label
+        classifier has been stepped by this step's select launch).  adam_clf=0 (training): gradient slabs only - the caller
+        reduces / all-reduces them itself; 1: the label classifier's Adam by the kernel's last workgroup (the four-launch step of
+        pcg_step_scores_train); 4: transposed activations only, nothing marked as waiting (gradients())."""
         g = self.g
         cnt = self.cnt.view(-1)[:g.R * B]
         b1, b2 = self.betas
-        adam_clf = (2 if train else 0) if adam_clf is None else int(adam_clf)
+        adam_clf = (3 if train else 0) if adam_clf is None else int(adam_clf)
         _lib.check(self.lib.pcg_train_dense(
             g.desc_ref(), _p(self.theta), _p(self.m), _p(self.v), self.E, _p(ids), _p(labels), B, _p(agg), agg.stride(1),
             _p(cnt), _p(self.data), C.c_void_p(plan), self.list_capacity, self.lambda_1, 1.0 / (B * self.scale), _p(self.logits),
             _p(self.center), _p(combined), _p(self.row_loss) if labels is not None else None, _p(self.slabs) if train else None,
             _p(self.step_counter) if train else None, _p(self.sync), self.lr, b1, b2, self.eps, self.wd, adam_clf,
-            self._stream()), "pcg_train_dense")
+            _p(self.acts) if adam_clf in (3, 4) else None, self.act_ld, self._stream()), "pcg_train_dense")
         if adam_clf == 1:                           # (the four-launch step updates theta's classifier in place)
             self.clf_next.copy_(self.theta[self.n_rest:])
 
@@ -309,7 +319,8 @@ class FusedPCGNN:
         b1, b2 = self.betas
         _lib.check(self.lib.pcg_adam_flush(
             _p(self.theta), _p(self.m), _p(self.v), _p(self.slabs), 0, self.n_params, self.n_rest, _p(self.step_counter),
-            _p(self.sync), self.lr, b1, b2, self.eps, self.wd, _p(self.clf_next), self._stream()), "pcg_adam_flush")
+            _p(self.sync), self.lr, b1, b2, self.eps, self.wd, _p(self.clf_next), _p(self.acts), self.act_ld, self.F, self.E, self.R,
+            _p(self.wg_scratch), self._stream()), "pcg_adam_flush")
 
     def _enqueue_step(self, ids, labels, B, plan: int, defer: bool, touched: Optional[int] = None,
                       next_touched: Optional[int] = None):
@@ -413,11 +424,21 @@ class FusedPCGNN:
             self.flush()
         torch.cuda.current_stream(self.dev).wait_stream(s)
         graphs = []
-        for fn in fns:
-            gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr):
-                fn()
-            graphs.append(gr)
+        # (no garbage collection while a stream is capturing: a collected engine of the caller's - tensors, events, other graphs -
+        #  is torn down with HIP calls that are not allowed during a capture and end the process)
+        import gc
+        gc.collect()
+        was_on = gc.isenabled()
+        gc.disable()
+        try:
+            for fn in fns:
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr):
+                    fn()
+                graphs.append(gr)
+        finally:
+            if was_on:
+                gc.enable()
         for dst, src in zip((self.theta, self.m, self.v, self.step_counter, self.clf_next), state):
             dst.copy_(src)
         self._fresh = False                          # (s0 holds the warm-up's scores)
@@ -574,7 +595,7 @@ class FusedPCGNN:
         gr.replay()
         self._fresh = (not self.touched_on) or self._ep_next_touch(b) is not None
 
-    def epoch_step_timed(self, b: int, eager: bool = True):
+    def epoch_step_timed(self, b: int, eager: bool = True, flush: bool = True):
         """Batch b of the staged epoch with HIP events around the select + gather call (appended to ``_prof``): the same
         kernels in the same order as one step of ``epoch_run``, reading the staged ids in place (no copies, no label
         gather).  eager: the four kernels launched one by one with the two event records between them (the host stays
@@ -591,7 +612,9 @@ class FusedPCGNN:
         plan = self._ep_plan(b)
         agg = self.agg.view(-1)[:g.R * B * g.feat_dim].view(g.R, B, g.feat_dim)
         keys = self.keys if g.n_pos else None
-        last = b + 1 >= len(self._ep_batches)     # the staged sequence's last batch: nothing follows that would apply the deferred update
+        # the staged sequence's last batch: nothing follows that would apply the deferred update (flush=False: the caller's next
+        # launches - the next group's first gather launch, or its own flush - do)
+        last = flush and b + 1 >= len(self._ep_batches)
         touched, nxt = self._ep_touch(b), self._ep_next_touch(b)
         score_next = (not self.touched_on) or nxt is not None
         if not self._fresh:
@@ -770,15 +793,27 @@ class FusedPCGNN:
         B = self._lastB
         return self.row_loss[:B].sum() / (B * self.scale)
 
-    def gradients(self, ids: torch.Tensor, labels: torch.Tensor) -> Dict[str, torch.Tensor]:
-        """loss.backward() without the optimizer step: per-parameter gradients (parity tests)."""
+    def gradients(self, ids: torch.Tensor, labels: torch.Tensor, via: str = "acts") -> Dict[str, torch.Tensor]:
+        """loss.backward() without the optimizer step: per-parameter gradients (parity tests).  via="acts": the training
+        step's kernels (dense kernel -> transposed activations -> the weight-gradient GEMMs of pcg_wgrad, the label
+        classifier's tiles included); via="slabs": per-tile gradient slabs summed in tile order (the data-parallel paths')."""
         B = ids.numel()
         self.flush()
         if B > self.maxB:
             self._alloc(B)
-        self._enqueue_grad_slabs(ids, labels, B)
-        self.step_counter -= 1                   # the dense kernel counted a step that is not taken
-        self._enqueue_adam(B, apply=False, want_grad=True)
+        if via == "slabs":
+            self._enqueue_grad_slabs(ids, labels, B)
+            self.step_counter -= 1               # the dense kernel counted a step that is not taken
+            self._enqueue_adam(B, apply=False, want_grad=True)
+        else:
+            plan = self._enqueue_plan_one(ids, labels, B, True)
+            keys = self._enqueue_scores(True)
+            agg, _ = self._enqueue_choose(ids, labels, B, keys, True, plan, sort_in_kernel=False)
+            self._enqueue_tail(ids, labels, B, agg, plan, True, adam_clf=4)
+            self.step_counter -= 1
+            b1, b2 = self.betas
+            _lib.check(self.lib.pcg_wgrad(_p(self.acts), self.act_ld, B, self.F, self.E, self.R, None, None, None, None, self.lr,
+                                          b1, b2, self.eps, self.wd, _p(self.grad), 0, 1, _p(self.wg_scratch), self._stream()), "pcg_wgrad")
         self._lastB = B
         out = {}
         for name, view in self.views.items():

@@ -530,10 +530,13 @@ def test_fused_forward_grads_adam_golden(P, case):
     np.testing.assert_allclose(lg.cpu().numpy(), c.z[f"{tag}_train_logits"], rtol=0, atol=LOGIT_TOL)
     np.testing.assert_allclose(cs.cpu().numpy(), c.z[f"{tag}_train_center_scores"], rtol=0, atol=1e-5)
     # gradients of every parameter
-    grads = fz.gradients(ids, lab)
-    assert abs(float(fz.last_loss()) - float(c.z[tag + "_loss"])) < LOGIT_TOL
-    for k in PARAM_KEYS(c.R):
-        np.testing.assert_allclose(grads[k].cpu().numpy(), c.z[f"{tag}_grad_{k}"], rtol=0, atol=2e-5, err_msg=k)
+    # (both ways the engine forms them: the training step's - transposed activations, weight gradients as GEMMs over the batch -
+    #  and the data-parallel paths' per-tile slabs summed in tile order)
+    for via in ("slabs", "acts"):
+        grads = fz.gradients(ids, lab, via=via)
+        assert abs(float(fz.last_loss()) - float(c.z[tag + "_loss"])) < LOGIT_TOL
+        for k in PARAM_KEYS(c.R):
+            np.testing.assert_allclose(grads[k].cpu().numpy(), c.z[f"{tag}_grad_{k}"], rtol=0, atol=2e-5, err_msg=f"{k} via {via}")
     # one Adam step: where the reference's own gradient is well away from zero the first update is -lr * g'/(|g'| + eps)
     # with g' = g + wd * p (coupled decay) - elementwise tight there; loose where |g'| ~ the gradient tolerance
     p0 = {k: v.clone() for k, v in c.params().items()}
