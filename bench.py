@@ -269,6 +269,14 @@ def run_partitioned(args, w, B, lr, wd, dev, dist, world, rank):
     W = max(1, args.window)
     gloo = dist.get_backend() == "gloo"          # rehearsal of the N > 1 flow on one GPU (PCG_BENCH_BACKEND=gloo): collectives staged through the host
     d = DistributedPCGNN(w, cfg, dev, window=W, stage_host=gloo)
+    try:
+        return _run_partitioned(args, w, B, d, dev, dist, world, rank, W, gloo)
+    finally:
+        d.close()                           # (captured collectives go before their communicator does - also on an error)
+        dist.destroy_process_group()
+
+
+def _run_partitioned(args, w, B, d, dev, dist, world, rank, W, gloo):
     n_nodes, feat, n_rel = w.n, d.F, d.R
 
     def all_reduce(t, op=None):
@@ -299,13 +307,20 @@ def run_partitioned(args, w, B, lr, wd, dev, dist, world, rank):
     # captured inside the timed region
     warmup = max(args.warmup, W)
     run_steps(0, warmup)
-    prof = d.profile_select(args.event_every) if rank == 0 else None
+    # (rank 0 runs every 6th window step by step, its steps bracketed by events - the other windows are one graph launch each)
+    prof = d.profile_select(max(args.event_every, 6)) if rank == 0 else None
     barrier()
     t0 = time.perf_counter()
     run_steps(warmup, args.steps)
+    ta = time.perf_counter()
     d.flush()                               # the last step's Adam update (it otherwise rides at the head of the next step's graph)
+    tb = time.perf_counter()
+    torch.cuda.synchronize(dev)
+    tc = time.perf_counter()
     barrier()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("PCG_BENCH_DEBUG"):
+        print(f"[debug] enqueue {ta - t0:.4f} flush {tb - ta:.4f} sync {tc - tb:.4f} barrier {t0 + elapsed - tc:.4f}", file=sys.stderr)
     d.check()                               # raises on every rank if any rank's exchange / lists went over capacity
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     fr, seen = d.feature_rows, d.halo.max_seen
@@ -340,9 +355,12 @@ def run_partitioned(args, w, B, lr, wd, dev, dist, world, rank):
             ab.append(algorithmic_bytes(g, ids_h, cnt.view(g.R, -1).cpu().numpy()) + U * (4 * g.feat_dim + 4))
         avg_ms = float(np.mean(ms)) if ms else float("nan")
         achieved = float(np.mean(ab)) / (avg_ms * 1e-3) / 1e9 if ms else float("nan")
-        roofline = {"bound": "hbm", "kernel": "the step graph of rank 0 (score pass over owned + train-pos + halo rows, plan, train-pos "
-                                              "sort, select_rows, halo look-up, gather_chunks, dense_step, slab sum): one launch per step; "
-                                              "bytes = select + gather + U x F scored rows (U = the batch's unique nodes)",
+        roofline = {"bound": "hbm", "kernel": "the step graph of rank 0: front (Adam from the all-reduced gradient || train-pos keys || score "
+                                              "pass over owned + train-pos + halo rows), select_rows (sorts the keys), gather_chunks_dist "
+                                              "(translates node ids to table rows as it reads the lists), dense_step (transposed activations, "
+                                              "no slabs), wgrad (weight-gradient GEMMs over the batch)"
+                                              + (", the gradient all-reduce (captured in the graph)" if d.collectives_in_graph else "")
+                                              + ": one launch per step; bytes = select + gather + U x F scored rows (U = the batch's unique nodes)",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                     "traffic_note": "no PMC pass of the partitioned step has been collected (profiles/): null",
                     "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": float(np.mean(ab)) if ab else None,
@@ -359,8 +377,9 @@ def run_partitioned(args, w, B, lr, wd, dev, dist, world, rank):
                                    f"batch={B}/GPU rho={args.rho}",
                        "global_batch": B * world, "parallelism": f"node-partition x{world} (in-edge balanced): id + feature-row "
                        f"all-to-all once per window of {W} steps (feature rows are immutable), every rank scores the rows it holds, "
-                       "grad all-reduce per step (RCCL)", "engine": "one graph replay + one all-reduce + Adam per step; no host "
-                       "synchronisation", "window_steps": W,
+                       "grad all-reduce per step (RCCL)", "engine": ("one graph replay per step (five launches + the captured all-reduce)"
+                       if d.collectives_in_graph else "one graph replay (five launches) + one eager all-reduce per step") + "; no host "
+                       "synchronisation", "collectives_in_graph": bool(d.collectives_in_graph), "window_steps": W,
                        "nodes_processed": int(nodes_total),
                        "per_rank_per_window": {"halo_rows_needed_max_seen": hr, "rows_served_last_window": rm,
                                                "all_to_all_row_bytes_fixed_pitch": en},
@@ -369,8 +388,7 @@ def run_partitioned(args, w, B, lr, wd, dev, dist, world, rank):
                                                      "halo_rows_max_seen": int(mem[1].item()), "unpartitioned_table": int(n_nodes)}},
             "roofline": roofline,
         }
-        print(json.dumps(out))
-    dist.destroy_process_group()
+        print(json.dumps(out), flush=True)
 
 
 def self_launch(args):

@@ -443,6 +443,28 @@ int pcg_grad_reduce(const float *slabs, int32_t n_slabs, int64_t n_params, float
 int pcg_adam_apply_pending(float *theta, float *m, float *v, const float *grad, int64_t n_params, const int32_t *step_counter,
                            uint32_t *flag, int32_t clear, double lr, double beta1, double beta2, double eps, double weight_decay,
                            void *stream);
+/* The partitioned step's front and gather (pc-gnn_amd/dist.py; the reference has no distributed code).
+ * pcg_step_scores_dist = pcg_step_scores with the optimizer riding in it, ONE launch behind the gradient all-reduce: if
+ *   sync_words[1] == 1 (pcg_wgrad(flag_set) / pcg_grad_reduce) torch.optim.Adam's update from grad [n_params] (the all-reduced
+ *   gradient) is applied to EVERY parameter by some workgroups while the others score rows [row_begin, row_end) ->
+ *   s0_out[row_ids[row]] and form the train positives' unsorted keys (rows pos_row_base + i; pos_keys may be NULL) with the label
+ *   classifier AFTER that update - each works it out for itself from clf_snap [3 * (2 feat_dim + 2)] (the classifier's
+ *   parameters, m, v as of the last applied update) and the gradient, same arithmetic, same bits.  The flag is cleared by the
+ *   step's select launch (pcg_choose_select_planned(sync_words)); the launch zeroes sync_words[3].
+ * pcg_gather_lists_dist = pcg_gather_lists_planned over lists of NODE ids: translated to rows of the extended table
+ *   [ owned | train-pos | halo ] as they are read (table / counts / pos_ids / pos_idx as pcg_halo_lookup; the list is left as it
+ *   is; an id in none of the three is skipped and sets overflow bit 4 in counts[128]); snap_dst != NULL: the launch also copies
+ *   theta / m / v [clf_offset, clf_offset + clf_n) to snap_dst [3 * clf_n] - the snapshot the NEXT step's pcg_step_scores_dist reads. */
+int pcg_step_scores_dist(const pcg_graph_desc *g, float *theta, float *m, float *v, int32_t emb, const float *grad,
+                         const float *clf_snap, int64_t row_begin, int64_t row_end, float *s0_out, const int32_t *row_ids,
+                         uint64_t *pos_keys, int64_t pos_row_base, const int32_t *step_counter, uint32_t *sync_words, double lr,
+                         double beta1, double beta2, double eps, double weight_decay, void *stream);
+int pcg_gather_lists_dist(const float *X, int32_t feat_dim, int32_t feat_stride, int64_t table_rows, int32_t n_rows,
+                          const int32_t *cnt, const pcg_graph_desc *g, int32_t B, void *workspace, const void *plan,
+                          int64_t list_capacity, float *agg, int32_t agg_stride, uint32_t *status, int32_t lo, int32_t hi,
+                          int32_t n_local, const int32_t *pos_ids, const int32_t *pos_idx, int32_t n_pos, const uint32_t *table,
+                          int64_t table_slots, uint32_t *counts, int32_t halo_cap, int32_t halo_base, const float *theta,
+                          const float *m, const float *v, int64_t clf_offset, int32_t clf_n, float *snap_dst, void *stream);
 int pcg_adam_flush(float *theta, float *m, float *v, const float *slabs, int32_t n_slabs, int64_t n_params, int64_t p_end,
                    const int32_t *step_counter, uint32_t *sync_words, double lr, double beta1, double beta2, double eps,
                    double weight_decay, const float *clf_next, const float *acts, int32_t act_ld, int32_t feat_dim, int32_t emb,
@@ -455,12 +477,13 @@ int pcg_adam_flush(float *theta, float *m, float *v, const float *slabs, int32_t
  * partial tiles meet in wg_scratch (pcg_wgrad_scratch_bytes(feat_dim, emb, n_rel, largest B), zero-initialised ONCE by the caller:
  * arrival tickets, left zero by every launch, then the partial tiles) and are added in part order by the one that arrives last;
  * wg_scratch may be NULL for B <= 1024 (act_ld <= 1024 where the batch size is only known on the device: pcg_adam_flush,
- * pcg_choose_gather_train).  act_ld: a multiple of 16.  Replaces src/model_handler.py:152-153 for those parameters. */
+ * pcg_choose_gather_train).  act_ld: a multiple of 16.  flag_set (may be NULL): a device word the launch sets to 1 - "a gradient
+ * is waiting" for pcg_step_scores_dist / pcg_adam_apply_pending.  Replaces src/model_handler.py:152-153 for those parameters. */
 int64_t pcg_wgrad_act_rows(int32_t feat_dim, int32_t emb, int32_t n_rel);
 int64_t pcg_wgrad_scratch_bytes(int32_t feat_dim, int32_t emb, int32_t n_rel, int32_t B);
 int pcg_wgrad(const float *acts, int32_t act_ld, int32_t B, int32_t feat_dim, int32_t emb, int32_t n_rel, float *theta, float *m,
               float *v, const int32_t *step_counter, double lr, double beta1, double beta2, double eps, double weight_decay,
-              float *grad_out, int32_t apply, int32_t with_clf, float *wg_scratch, void *stream);
+              float *grad_out, int32_t apply, int32_t with_clf, float *wg_scratch, uint32_t *flag_set, void *stream);
 
 /* ---- multi-GPU halo exchange helpers (no counterpart in the reference) ----------
  * A rank of a partitioned run holds the table [ owned rows | train-pos rows | halo ]; CSR rows and selection lists hold

@@ -94,7 +94,11 @@ PROTOTYPES = {
                                  _I32, _P, _P]),
     "pcg_wgrad_act_rows": (_I64, [_I32, _I32, _I32]),
     "pcg_wgrad_scratch_bytes": (_I64, [_I32, _I32, _I32, _I32]),
-    "pcg_wgrad": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _F64, _F64, _F64, _F64, _F64, _P, _I32, _I32, _P, _P]),
+    "pcg_wgrad": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _F64, _F64, _F64, _F64, _F64, _P, _I32, _I32, _P, _P, _P]),
+    "pcg_step_scores_dist": (C.c_int, [_G, _P, _P, _P, _I32, _P, _P, _I64, _I64, _P, _P, _P, _I64, _P, _P, _F64, _F64, _F64, _F64, _F64,
+                                       _P]),
+    "pcg_gather_lists_dist": (C.c_int, [_P, _I32, _I32, _I64, _I32, _P, _G, _I32, _P, _P, _I64, _P, _I32, _P, _I32, _I32, _I32, _P, _P,
+                                        _I32, _P, _I64, _P, _I32, _I32, _P, _P, _P, _I64, _I32, _P, _P]),
     "pcg_debug_set_stamps": (None, [_P]),
     "pcg_debug_set_dense_stamps": (None, [_P]),
     "pcg_sel_capacity_row": (_I64, [_I64, _F64, _F64, _I32, _I32, _I32]),

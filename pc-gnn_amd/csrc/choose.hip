@@ -556,6 +556,60 @@ __global__ void __launch_bounds__(FRONT_COUNT_THREADS) front_a_kernel(const Choo
                          (int)gridDim.x - n_plan_blocks - n_key_blocks - n_adam_blocks, row_ids);
 }
 
+// The front of a PARTITIONED rank's training step (pc-gnn_amd/dist.py), one launch behind the gradient all-reduce:
+//   [Adam on EVERY parameter from the all-reduced gradient, if one is waiting (ad.pending[0] == 1; ad.slabs = that gradient, one
+//    "slab") || the train positives' unsorted keys from their replicated rows || the score of every row the rank holds, stored by
+//    node id]
+// The score and key workgroups need the label classifier AFTER that update, which other workgroups of this launch are storing:
+// each works it out for itself - 2F + 2 parameters - from a snapshot of the classifier's parameters and Adam state taken after
+// the previous update (pcg_gather_lists_dist refreshes it every step) and the gradient, with the same statement of the
+// arithmetic (adam_update), into LDS.  Nothing in the launch waits for anything inside it.
+struct FrontDist {
+    pcg_graph_desc g;
+    int64_t row_begin, row_end;
+    float *s0;
+    const int32_t *row_ids;
+    int64_t pos_row_base;
+    uint64_t *raw_keys;
+    int32_t n_key_blocks, n_adam_blocks;
+    DeferredAdam ad;
+    const float *snap;         // [3][nc]: the classifier's parameters, m, v as of the last applied update
+    int32_t nc;                // 2F + 2
+    int64_t off_clf;
+    uint32_t *zero_word;
+};
+constexpr int FRONT_DIST_NC = 2 * 512 + 2;
+__global__ void __launch_bounds__(FRONT_COUNT_THREADS) front_dist_kernel(const FrontDist f) {
+    __shared__ float part[4][PCG_WAVE];
+    __shared__ float wl[FRONT_DIST_NC + 2];
+    const int b = (int)blockIdx.x;
+    if (f.zero_word && b == 0 && threadIdx.x == 0) f.zero_word[0] = 0u;
+    const bool waiting = f.ad.pending[0] == 1u;                     // (one word, the same for every thread)
+    if (b < f.n_adam_blocks) {
+        if (waiting)
+            adam_reduce_body(f.ad.theta, f.ad.m, f.ad.v, f.ad.slabs, 1, f.ad.n_params, 0, f.ad.p_end, f.ad.step_counter, f.ad.h, nullptr,
+                             1, b, part);
+        return;
+    }
+    const float t = (float)f.ad.step_counter[0];
+    for (int i = (int)threadIdx.x; i < f.nc; i += FRONT_COUNT_THREADS) {
+        float p = f.snap[i];
+        if (waiting) {
+            float mi, vi;
+            p = adam_update(p, f.snap[f.nc + i], f.snap[2 * f.nc + i], f.ad.slabs[f.off_clf + i], t, f.ad.h, mi, vi);
+        }
+        wl[i] = p;
+    }
+    __syncthreads();
+    const float *W = wl, *bias = wl + (f.nc - 2);
+    if (b < f.n_adam_blocks + f.n_key_blocks)
+        pos_key_body(f.g.X, f.g.feat_dim, f.g.feat_stride, W, bias, f.g.train_pos, f.g.n_pos, f.raw_keys, b - f.n_adam_blocks,
+                     f.n_key_blocks, f.pos_row_base);
+    else
+        score_table_body(f.g.X, f.g.feat_dim, f.g.feat_stride, W, bias, f.row_begin, f.row_end, f.s0,
+                         b - f.n_adam_blocks - f.n_key_blocks, (int)gridDim.x - f.n_adam_blocks - f.n_key_blocks, f.row_ids);
+}
+
 __global__ void __launch_bounds__(PLAN_THREADS) front_b_kernel(const ChooseArgs a, const PlanTotals *totals, int n_write_blocks,
                                                                int n_count_blocks, uint64_t *__restrict__ keys, int cap,
                                                                const uint64_t *__restrict__ raw_keys, uint32_t *pending,
@@ -938,6 +992,57 @@ int pcg_step_scores(const pcg_graph_desc *g, const float *W, const float *b, int
     return PCG_OK;
 }
 
+/* pcg_step_scores for a partitioned rank's TRAINING step, with the optimizer riding in it (one launch, behind the all-reduce):
+ * if sync_words[1] == 1 ("a gradient is waiting": pcg_wgrad(flag_set) / pcg_grad_reduce) torch.optim.Adam's update from `grad`
+ * (the all-reduced gradient, n_params floats) is applied to EVERY parameter by some workgroups, while the others score rows
+ * [row_begin, row_end) -> s0_out[row_ids[row]] and form the train positives' unsorted keys (rows pos_row_base + i) with the label
+ * classifier AFTER that update, which each works out for itself from clf_snap [3 * (2 feat_dim + 2)] - the classifier's
+ * parameters, m, v as of the last applied update (pcg_gather_lists_dist refreshes it every step; the caller after a flush) -
+ * and the gradient.  The flag is cleared by the step's select launch (pcg_choose_select_planned(sync_words)); the launch zeroes
+ * sync_words[3].  n_pos > 16384: pos_keys must be NULL (the caller sorts by its own launches). */
+int pcg_step_scores_dist(const pcg_graph_desc *g, float *theta, float *m, float *v, int32_t emb, const float *grad,
+                         const float *clf_snap, int64_t row_begin, int64_t row_end, float *s0_out, const int32_t *row_ids,
+                         uint64_t *pos_keys, int64_t pos_row_base, const int32_t *step_counter, uint32_t *sync_words, double lr,
+                         double beta1, double beta2, double eps, double weight_decay, void *stream) {
+    if (!g || !g->X || !theta || !m || !v || !grad || !clf_snap || !s0_out || !step_counter || !sync_words) return PCG_E_ARG;
+    if (g->feat_dim < 1 || g->feat_dim > 512 || g->feat_stride < g->feat_dim || g->feat_stride % 4 != 0) return PCG_E_ARG;
+    if ((reinterpret_cast<uintptr_t>(g->X) & 15u) != 0) return PCG_E_ARG;
+    if (row_begin < 0 || row_end > g->n_nodes || row_begin > row_end) return PCG_E_ARG;
+    if (pos_keys && (pos_row_base < 0 || pos_row_base + g->n_pos > g->n_nodes || g->n_pos > pcg::RANK_MAX)) return PCG_E_ARG;
+    const int64_t n_params = pcg_dense_n_params(g->feat_dim, emb, g->n_rel);
+    const int64_t o_clf = pcg_dense_param_offset(g->feat_dim, emb, g->n_rel, 3, 0);
+    if (n_params < 0 || o_clf < 0) return PCG_E_ARG;
+    pcg::FrontDist f;
+    f.g = *g;
+    f.row_begin = row_begin;
+    f.row_end = row_end;
+    f.s0 = s0_out;
+    f.row_ids = row_ids;
+    f.pos_row_base = pos_row_base;
+    const bool raw = pos_keys && g->n_pos > 0;
+    f.raw_keys = raw ? pos_keys + pcg_pos_sort_capacity(g->n_pos) / 2 : nullptr;
+    const int rows_per_block = 4 * (PCG_WAVE / pcg::lanes_per_row(g->feat_stride));
+    int n_key = raw ? (g->n_pos + rows_per_block - 1) / rows_per_block : 0;
+    f.n_key_blocks = n_key > 256 ? 256 : n_key;
+    f.n_adam_blocks = (int)((n_params + PCG_WAVE - 1) / PCG_WAVE);
+    f.ad.theta = theta; f.ad.m = m; f.ad.v = v;
+    f.ad.slabs = grad;
+    f.ad.n_params = n_params;
+    f.ad.p_end = n_params;
+    f.ad.step_counter = step_counter;
+    f.ad.pending = sync_words + 1;
+    f.ad.h = {(float)lr, (float)beta1, (float)beta2, (float)eps, (float)weight_decay};
+    f.snap = clf_snap;
+    f.nc = 2 * g->feat_dim + 2;
+    f.off_clf = o_clf;
+    f.zero_word = sync_words + 3;
+    const int n_score = (int)pcg::score_table_blocks(row_end - row_begin, g->feat_stride);
+    hipLaunchKernelGGL(pcg::front_dist_kernel, dim3(f.n_adam_blocks + f.n_key_blocks + n_score), dim3(pcg::FRONT_COUNT_THREADS), 0,
+                       static_cast<hipStream_t>(stream), f);
+    PCG_LAUNCH_CHECK();
+    return PCG_OK;
+}
+
 int32_t pcg_pos_sort_in_select(int32_t n_pos) { return n_pos > 0 && n_pos <= pcg::RANK_MAX ? 1 : 0; }
 
 /* uint32 words of the `sync_words` buffer: [0] dense ticket, [1] update pending, [2] its slab count, [3] the in-kernel sort's group
@@ -1065,6 +1170,7 @@ int pcg_choose_gather_train(const pcg_graph_desc *g, const int32_t *nodes, const
     sd.wg.tickets = reinterpret_cast<uint32_t *>(wg_scratch);
     sd.wg.partials = wg_scratch ? wg_scratch + (pcg::wgrad_tiles(g->feat_dim, emb, g->n_rel, 1) + 63) / 64 * 64 : nullptr;
     sd.wg.grad_out = nullptr;
+    sd.wg.flag_set = nullptr;
     sd.wg.apply = 1;
     sd.wg.with_clf = 0;
     sd.n_wgrad_blocks = acts ? pcg::wgrad_tiles(g->feat_dim, emb, g->n_rel, 0) * sd.wg.kparts : 0;

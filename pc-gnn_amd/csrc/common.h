@@ -438,6 +438,19 @@ __device__ __forceinline__ void rank_sort_body(const float *__restrict__ s0, con
 struct AdamHyper {
     float lr, beta1, beta2, eps, wd;
 };
+// torch.optim.Adam's update of one parameter (coupled L2 weight decay; t = the step's number, 1-based): ONE statement of the
+// arithmetic, for every place that applies it - two workgroups that work out the same parameter's update from the same inputs
+// (the partitioned path's score pass recomputes the label classifier's while other workgroups of its launch store it) must
+// arrive at the same bits, so nothing here is left to the compiler's choice of contraction
+__device__ __forceinline__ float adam_update(float p, float m_old, float v_old, float g, float t, const AdamHyper &h, float &mi, float &vi) {
+#pragma clang fp contract(off)
+    g = __builtin_fmaf(h.wd, p, g);
+    mi = __builtin_fmaf(h.beta1, m_old, (1.f - h.beta1) * g);
+    vi = __builtin_fmaf(h.beta2, v_old, ((1.f - h.beta2) * g) * g);
+    const float bc1 = 1.f - powf(h.beta1, t), bc2 = 1.f - powf(h.beta2, t);
+    const float denom = sqrtf(vi) / sqrtf(bc2) + h.eps;
+    return p - (h.lr / bc1) * (mi / denom);
+}
 constexpr int ADAM_ACC = 16;
 __device__ __forceinline__ void adam_reduce_body(float *__restrict__ theta, float *__restrict__ m, float *__restrict__ v,
                                                  const float *__restrict__ slabs, int n_slabs, int64_t n_params,
@@ -476,14 +489,11 @@ __device__ __forceinline__ void adam_reduce_body(float *__restrict__ theta, floa
     float g = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
     if (grad_out) grad_out[i] = g;
     if (!apply) return;
-    g = fmaf(h.wd, p, g);
-    const float mi = h.beta1 * m_old + (1.f - h.beta1) * g;
-    const float vi = h.beta2 * v_old + (1.f - h.beta2) * g * g;
+    float mi, vi;
+    const float pn = adam_update(p, m_old, v_old, g, t, h, mi, vi);
     m[i] = mi;
     v[i] = vi;
-    const float bc1 = 1.f - powf(h.beta1, t), bc2 = 1.f - powf(h.beta2, t);
-    const float denom = sqrtf(vi) / sqrtf(bc2) + h.eps;
-    theta[i] = p - (h.lr / bc1) * (mi / denom);
+    theta[i] = pn;
 }
 
 // two-class cross entropy and its gradient from the logit difference: one v_exp_f32, one v_log_f32, one v_rcp_f32
@@ -503,15 +513,11 @@ __device__ __forceinline__ void xent2(float a, float b, int y, float &loss, floa
 
 // the same update for one parameter whose summed gradient g is already known
 __device__ __forceinline__ void adam_apply_one(float *theta, float *m, float *v, int64_t i, float g, float t, AdamHyper h) {
-    const float p = theta[i];
-    g = fmaf(h.wd, p, g);
-    const float mi = h.beta1 * m[i] + (1.f - h.beta1) * g;
-    const float vi = h.beta2 * v[i] + (1.f - h.beta2) * g * g;
+    float mi, vi;
+    const float pn = adam_update(theta[i], m[i], v[i], g, t, h, mi, vi);
     m[i] = mi;
     v[i] = vi;
-    const float bc1 = 1.f - powf(h.beta1, t), bc2 = 1.f - powf(h.beta2, t);
-    const float denom = sqrtf(vi) / sqrtf(bc2) + h.eps;
-    theta[i] = p - (h.lr / bc1) * (mi / denom);
+    theta[i] = pn;
 }
 
 // what the step-front kernel needs to apply the previous step's deferred update (all parameters below p_end)

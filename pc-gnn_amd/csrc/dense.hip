@@ -991,7 +991,7 @@ int64_t pcg_wgrad_scratch_bytes(int32_t feat_dim, int32_t emb, int32_t n_rel, in
 
 int pcg_wgrad(const float *acts, int32_t act_ld, int32_t B, int32_t feat_dim, int32_t emb, int32_t n_rel, float *theta, float *m,
               float *v, const int32_t *step_counter, double lr, double beta1, double beta2, double eps, double weight_decay,
-              float *grad_out, int32_t apply, int32_t with_clf, float *scratch, void *stream) {
+              float *grad_out, int32_t apply, int32_t with_clf, float *scratch, uint32_t *flag_set, void *stream) {
     pcg::WgradArgs w;
     if (B < 1) return PCG_E_ARG;
     const int rc = wgrad_args(w, acts, act_ld, feat_dim, emb, n_rel, (B + 15) / 16, scratch);
@@ -1003,6 +1003,7 @@ int pcg_wgrad(const float *acts, int32_t act_ld, int32_t B, int32_t feat_dim, in
     w.h = {(float)lr, (float)beta1, (float)beta2, (float)eps, (float)weight_decay};
     w.pending = nullptr;
     w.grad_out = grad_out;
+    w.flag_set = flag_set;
     w.apply = apply;
     w.with_clf = with_clf ? 1 : 0;
     hipLaunchKernelGGL(pcg::wgrad_adam_kernel, dim3((unsigned)(pcg::wgrad_tiles(feat_dim, emb, n_rel, w.with_clf) * w.kparts)), dim3(256), 0,
@@ -1030,6 +1031,7 @@ int pcg_adam_flush(float *theta, float *m, float *v, const float *slabs, int32_t
         w.h = h;
         w.pending = sync_words + 1;
         w.grad_out = nullptr;
+        w.flag_set = nullptr;
         w.apply = 1;
         w.with_clf = p_end > pcg::off_clf(feat_dim, emb, n_rel) ? 1 : 0;
         hipLaunchKernelGGL(pcg::wgrad_adam_kernel, dim3((unsigned)(pcg::wgrad_tiles(feat_dim, emb, n_rel, w.with_clf) * w.kparts)), dim3(256), 0, st, w);

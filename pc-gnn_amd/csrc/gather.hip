@@ -6,6 +6,7 @@
 //   combine  rows longer than one chunk: partial sums added in chunk order (bitwise reproducible), divided by |set|
 //            (or its sqrt)
 #include "choose.h"
+#include "halo_map.h"
 
 namespace pcg {
 
@@ -29,6 +30,7 @@ struct AggArgs {
     int32_t agg_stride, norm;
     int64_t table_rows;         // rows of X: a list entry outside [0, table_rows) is not gathered (a hole) and reported
     uint32_t *status;           // device status word (PCG_ST_LIST_ID_RANGE), or null
+    HaloMap hm;                 // hm.keys != null (a partitioned rank's extended table): the list holds node ids - translated here
 };
 
 struct RowGeom {  // how one wave-instruction covers feature rows
@@ -61,7 +63,7 @@ __device__ __forceinline__ void store_row(float *out, const float4 (&acc)[NACC],
 }
 
 // workgroup `block` of `n_blocks` (256 threads each)
-template <int NACC>
+template <int NACC, bool MAP = false>
 __device__ __forceinline__ void gather_chunks_body(const AggArgs &a, uint32_t block, uint32_t n_blocks) {
     const int lane = lane_id();
     const RowGeom q = row_geom(a.feat_stride, lane);
@@ -90,8 +92,10 @@ __device__ __forceinline__ void gather_chunks_body(const AggArgs &a, uint32_t bl
         bool bad = false;                                              // an entry that names no row of the table
         // (negative = nothing there, or a hole left by a duplicate.  The sign bit is OR-ed in rather than the value replaced:
         //  a value that is only used under a condition gets its load sunk into a branch again)
+        bool miss = false;                                             // MAP: an id that is nowhere in this rank's table
         int my = list[lane < n ? lane : (n > 0 ? n - 1 : 0)];
         my |= (lane >= n || lane >= per_iter) ? (int)0x80000000 : 0;
+        if constexpr (MAP) my = halo_translate(a.hm, my, miss);        // node id -> row of the extended table (halo_map.h)
         for (int base = 0; base < n; base += per_iter) {
             const int ln = base + per_iter + lane;
             int nxt = list[ln < n ? ln : n - 1];
@@ -123,7 +127,13 @@ __device__ __forceinline__ void gather_chunks_body(const AggArgs &a, uint32_t bl
                     acc[x].z += ok ? v[u][x].z : 0.f;
                     acc[x].w += ok ? v[u][x].w : 0.f;
                 }
+            // (the next iteration's ids are translated behind this iteration's rows: owned ids - most - cost a compare, fetched
+            //  ones one or two probes of the window's hash table)
+            if constexpr (MAP) nxt = halo_translate(a.hm, nxt, miss);
             my = nxt;
+        }
+        if constexpr (MAP) {
+            if (miss && a.hm.overflow) atomicOr(a.hm.overflow, 4u);
         }
 #pragma unroll
         for (int x = 0; x < NACC; ++x)
@@ -153,6 +163,21 @@ __device__ __forceinline__ void gather_chunks_body(const AggArgs &a, uint32_t bl
 template <int NACC>
 __global__ void __launch_bounds__(256) gather_chunks(const AggArgs a) {
     gather_chunks_body<NACC>(a, blockIdx.x, gridDim.x);
+}
+// The partitioned path's gather: the lists hold node ids, translated to rows of the rank's extended table as they are read (no
+// look-up launch, no rewritten list); the launch's first workgroup also refreshes the label classifier's snapshot (its parameters
+// and Adam state as the launches of this step see them: what the NEXT step's score pass recomputes the classifier's update from,
+// pcg_step_scores_dist)
+struct SnapCopy {
+    const float *src[3];        // theta, m, v at the classifier's offset
+    float *dst;                 // [3][n] or null
+    int32_t n;
+};
+template <int NACC>
+__global__ void __launch_bounds__(256) gather_chunks_dist(const AggArgs a, const SnapCopy sc) {
+    if (sc.dst && blockIdx.x == 0)
+        for (int i = (int)threadIdx.x; i < 3 * sc.n; i += 256) sc.dst[i] = sc.src[i / sc.n][i % sc.n];
+    gather_chunks_body<NACC, true>(a, blockIdx.x, gridDim.x);
 }
 
 // The gather launch of a TRAINING step, with what else fits beside it (SideJob, choose.h): workgroups
@@ -282,6 +307,7 @@ static void fill_agg_args(AggArgs &a, const float *X, int32_t feat_dim, int32_t 
     a.norm = norm;
     a.table_rows = table_rows;
     a.status = status;
+    a.hm = HaloMap{};
 }
 
 int launch_gather_train(const float *X, int32_t feat_dim, int32_t feat_stride, int64_t table_rows, const int32_t *cnt,
@@ -352,6 +378,51 @@ int pcg_gather_lists_planned(const float *X, int32_t feat_dim, int32_t feat_stri
                              int64_t list_capacity, float *agg, int32_t agg_stride, uint32_t *status, void *stream) {
     return aggregate(X, feat_dim, feat_stride, table_rows, n_rows, cnt, g, B, workspace, list_capacity, PCG_NORM_COUNT, agg,
                      agg_stride, false, status, stream, plan);
+}
+
+/* pcg_gather_lists_planned for a partitioned rank (pc-gnn_amd/dist.py): the lists hold NODE ids; the gather translates them to rows
+ * of the extended table [ owned | train-pos | halo ] as it reads them (the window's hash table of pcg_halo_collect; pos_ids /
+ * pos_idx as pcg_halo_lookup) - the list itself is left as it is; an id that is in none of the three is skipped and sets
+ * overflow bit 4 in counts[128].  snap_dst != NULL: the launch also copies the label classifier's parameters and Adam state
+ * (theta / m / v at clf_offset, clf_n floats each) to snap_dst [3 * clf_n] (pcg_step_scores_dist reads them in the next step). */
+int pcg_gather_lists_dist(const float *X, int32_t feat_dim, int32_t feat_stride, int64_t table_rows, int32_t n_rows,
+                          const int32_t *cnt, const pcg_graph_desc *g, int32_t B, void *workspace, const void *plan,
+                          int64_t list_capacity, float *agg, int32_t agg_stride, uint32_t *status, int32_t lo, int32_t hi,
+                          int32_t n_local, const int32_t *pos_ids, const int32_t *pos_idx, int32_t n_pos, const uint32_t *table,
+                          int64_t table_slots, uint32_t *counts, int32_t halo_cap, int32_t halo_base, const float *theta,
+                          const float *m, const float *v, int64_t clf_offset, int32_t clf_n, float *snap_dst, void *stream) {
+    if (!X || !cnt || !g || !workspace || !agg || n_rows < 0 || B < 0 || table_rows < 1) return PCG_E_ARG;
+    if (n_rows != g->n_rel * B) return PCG_E_ARG;
+    if (n_rows == 0) return PCG_OK;
+    if (feat_stride % 4 != 0 || feat_stride < feat_dim || agg_stride < feat_dim) return PCG_E_ARG;
+    if (feat_stride > 512) return PCG_E_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(X) & 15u) != 0) return PCG_E_ARG;
+    if (!table || !counts || table_slots < 1024 || (table_slots & (table_slots - 1)) != 0 || lo > hi || n_pos < 0 ||
+        (n_pos > 0 && (!pos_ids || !pos_idx)))
+        return PCG_E_ARG;
+    if (snap_dst && (!theta || !m || !v || clf_n < 1 || clf_offset < 0)) return PCG_E_ARG;
+    pcg::Workspace w;
+    pcg::carve1(g, B, list_capacity, static_cast<unsigned char *>(workspace), &w, static_cast<unsigned char *>(const_cast<void *>(plan)));
+    pcg::AggArgs a;
+    pcg::fill_agg_args(a, X, feat_dim, feat_stride, table_rows, n_rows, cnt, w, PCG_NORM_COUNT, agg, agg_stride, status);
+    a.hm.keys = table;
+    a.hm.vals = table + table_slots;
+    a.hm.mask = (uint32_t)(table_slots - 1);
+    a.hm.lo = lo; a.hm.hi = hi; a.hm.n_local = n_local;
+    a.hm.pos_ids = pos_ids; a.hm.pos_idx = pos_idx; a.hm.n_pos = n_pos;
+    a.hm.halo_cap = halo_cap; a.hm.halo_base = halo_base;
+    a.hm.overflow = counts + 128;
+    pcg::SnapCopy sc;
+    sc.src[0] = theta ? theta + clf_offset : nullptr;
+    sc.src[1] = m ? m + clf_offset : nullptr;
+    sc.src[2] = v ? v + clf_offset : nullptr;
+    sc.dst = snap_dst;
+    sc.n = clf_n;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (feat_stride <= 256) hipLaunchKernelGGL(pcg::gather_chunks_dist<1>, dim3(pcg::GATHER_BLOCKS), dim3(256), 0, st, a, sc);
+    else hipLaunchKernelGGL(pcg::gather_chunks_dist<2>, dim3(pcg::GATHER_BLOCKS), dim3(256), 0, st, a, sc);
+    PCG_LAUNCH_CHECK();
+    return PCG_OK;
 }
 
 /* gather + combine (finished means) with the plan part outside the workspace */

@@ -17,26 +17,11 @@
 // Work and memory are proportional to the window's CSR rows / the list's entries - nothing is sized by, or walks, the
 // node-id space.  The reference has no distributed code; see SURVEY.md section 8(e).
 #include "choose.h"
+#include "halo_map.h"
 
 namespace pcg {
 
-constexpr uint32_t HALO_EMPTY = 0xFFFFFFFFu;
 constexpr int HALO_MAX_WORLD = 64;
-// Longest probe sequence any table operation walks.  The table has at least two slots per halo row, so a run of 128 occupied
-// slots means it is over-full (a capacity error): the insert then reports "full" (overflow bit 1) instead of walking the whole
-// table for every later neighbour - O(ids x slots) probes would look like a hang.  An id that WAS inserted sits within this many
-// probes of its hash slot (no deletions), so look-ups bounded the same way find everything that is there.
-constexpr uint32_t HALO_MAX_PROBE = 128;
-
-__device__ __forceinline__ uint32_t halo_hash(uint32_t x) {
-    x ^= x >> 16;
-    x *= 0x7feb352dU;
-    x ^= x >> 15;
-    x *= 0x846ca68bU;
-    x ^= x >> 16;
-    return x;
-}
-
 __device__ __forceinline__ int owner_of(const int32_t *s_bounds, int world, int32_t id) {
     int lo = 0, hi = world;          // largest r with bounds[r] <= id
     while (hi - lo > 1) {
@@ -74,17 +59,6 @@ struct HaloArgs {
     const int64_t *indptr[PCG_MAX_REL];
     const int32_t *indices[PCG_MAX_REL];
 };
-
-// first train-pos id >= id (binary search in the ascending ids); returns its position or -1
-__device__ __forceinline__ int pos_find(const int32_t *__restrict__ pos_ids, int n_pos, int32_t id) {
-    int plo = 0, phi = n_pos;
-    while (plo < phi) {
-        const int mid = (plo + phi) >> 1;
-        if (pos_ids[mid] < id) plo = mid + 1;
-        else phi = mid;
-    }
-    return (plo < n_pos && pos_ids[plo] == id) ? plo : -1;
-}
 
 // insert a remote id (first insert counts it for its owner); false: the table is full
 __device__ __forceinline__ bool halo_insert(const HaloArgs &a, const int32_t *s_bounds, int32_t id) {

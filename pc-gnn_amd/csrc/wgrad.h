@@ -40,6 +40,7 @@ struct WgradArgs {
     uint32_t *tickets;         // kparts > 1: [tiles] arrival counters, zero between launches
     float *partials;           // kparts > 1: [tiles][kparts][256] partial tiles (write-through)
     float *grad_out;           // [n_params] or null
+    uint32_t *flag_set;        // device word set to 1 by the launch ("a gradient is waiting": the partitioned path), or null
     int32_t apply;
     int32_t with_clf;          // also the label classifier's tiles (its step is pcg_choose_gather_train's otherwise)
 };
@@ -65,6 +66,7 @@ __device__ __forceinline__ void wgrad_adam_body(const WgradArgs &a, int wg, floa
     typedef float f4 __attribute__((ext_vector_type(4)));
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const int KP = a.kparts > 1 ? a.kparts : 1;
+    if (a.flag_set && wg == 0 && threadIdx.x == 0) a.flag_set[0] = 1u;
     int b = wg / KP;
     const int tile = b, kp = wg - b * KP;
     // the words that say whether (and how much) there is to do are requested first, the first operands - for the batch size
@@ -193,15 +195,11 @@ __device__ __forceinline__ void wgrad_adam_body(const WgradArgs &a, int wg, floa
     if (!pok) return;
     if (a.grad_out) a.grad_out[pidx] = g;
     if (!a.apply) return;
-    const AdamHyper h = a.h;
-    g = fmaf(h.wd, p_old, g);                                      // torch.optim.Adam, coupled weight decay (as adam_apply_one)
-    const float mi = h.beta1 * m_old + (1.f - h.beta1) * g;
-    const float vi = h.beta2 * v_old + (1.f - h.beta2) * g * g;
+    float mi, vi;
+    const float p_new = adam_update(p_old, m_old, v_old, g, tstep, a.h, mi, vi);   // torch.optim.Adam, coupled weight decay
     a.m[pidx] = mi;
     a.v[pidx] = vi;
-    const float bc1 = 1.f - powf(h.beta1, tstep), bc2 = 1.f - powf(h.beta2, tstep);
-    const float denom = sqrtf(vi) / sqrtf(bc2) + h.eps;
-    a.theta[pidx] = p_old - (h.lr / bc1) * (mi / denom);
+    a.theta[pidx] = p_new;
 }
 
 }  // namespace pcg

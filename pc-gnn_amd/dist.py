@@ -15,15 +15,18 @@ reference has no distributed code at all; this is new des
   returns them into the halo region of the extended table ``[owned | train-pos | halo]``.  Owner o's
   requests sit in a fixed range of the request list, so both all-to-alls have equal splits and nothing
   waits for the host.  xGMI is point-to-point: the all-to-alls use all 7 links of a GPU at once.
-* **Per step** (each rank works on centres it owns), one hipGraph replay + ONE collective:
-    1. class-0 scores of every row the rank holds (owned, train-pos, halo - every node a list of this
-       window can name), stored by global node id (``pcg_step_front_a`` with ``row_ids``): no score
-       exchange - a row's score is the same arithmetic on whichever rank computes it;
-    2. train-pos sort + choose (``pcg_choose_select_planned``) -> selection lists of global ids ->
-       rows of the extended table (``pcg_halo_lookup``);
-    3. ``pcg_gather_lists`` over the extended table, ``pcg_train_dense`` on the local batch with the
-       loss scaled by 1 / global batch;
-    4. gradient ``all_reduce`` (~107 KB, latency-bound), identical Adam on every rank.
+* **Per step** (each rank works on centres it owns): ONE hipGraph replay - five launches and the step's only
+  collective, captured with them (RCCL all-reduce inside the graph; probed at construction, eager otherwise):
+    1. front (``pcg_step_scores_dist``): Adam on every parameter from the previous step's all-reduced gradient ||
+       the train positives' unsorted keys || class-0 scores of every row the rank holds (owned, train-pos, halo -
+       every node a list of this window can name), stored by global node id: no score exchange - a row's score
+       is the same arithmetic on whichever rank computes it.  The score workgroups recompute the label
+       classifier's update themselves (from a snapshot of its state + the gradient), so nothing waits inside;
+    2. select (``pcg_choose_select_planned``): sorts the keys itself, centres' scores by global id -> lists of ids;
+    3. gather over the extended table (``pcg_gather_lists_dist``): translates the lists' ids as it reads them;
+    4. ``pcg_train_dense`` on the local batch, loss scaled by 1 / global batch -> transposed activations (no slabs);
+    5. ``pcg_wgrad``: the weight gradients as GEMMs over the local batch -> the flat gradient; then its
+       ``all_reduce`` (~107 KB, latency-bound); identical Adam on every rank (the next step's front launch).
 * **Memory per rank**: owned rows + train-pos rows + a halo region sized from the window's expected
   demand (``halo_rows``: distinct remote neighbours of window x batch picked centres, x a margin,
   never more than the remote nodes there are) - not from the node count; no per-node flag / slot /
@@ -428,7 +431,18 @@ class DistributedPCGNN:
         self.logits = torch.empty(B, 2, dtype=torch.float32, device=self.dev)
         self.center = torch.empty(B, 2, dtype=torch.float32, device=self.dev)
         self.row_loss = torch.zeros(B, dtype=torch.float32, device=self.dev)
-        self.slabs = torch.empty(self.lib.pcg_dense_n_tiles(B), n, dtype=torch.float32, device=self.dev)
+        # the dense kernel leaves the step's transposed activations (no gradient slabs); the weight gradients are GEMMs over the
+        # local batch (pcg_wgrad -> self.grad, which the all-reduce sums over the ranks)
+        self.act_ld = 16 * int(self.lib.pcg_dense_n_tiles(B))
+        self.acts = torch.zeros(int(self.lib.pcg_wgrad_act_rows(F, self.E, self.R)), self.act_ld, dtype=torch.float32, device=self.dev)
+        self.wg_scratch = torch.zeros(int(self.lib.pcg_wgrad_scratch_bytes(F, self.E, self.R, self.act_ld)) // 4, dtype=torch.float32,
+                                      device=self.dev)
+        # the label classifier's parameters, m, v as of the last applied update: the step's front launch recomputes the
+        # classifier's Adam update from them while other workgroups of the same launch store it (pcg_step_scores_dist)
+        self.n_clf = 2 * F + 2
+        self.off_clf = int(o3)
+        self.clf_snap = torch.zeros(3 * self.n_clf, dtype=torch.float32, device=self.dev)
+        self._snap_refresh()
         self.thresholds, self.rho = [0.5] * g.R, [cfg["rho"]] * g.R
         self.sampler = PickSampler(sh["idx_train_local"] - part.lo, y_loc, sh["homo_deg_train"],
                                    self.dev, seed=cfg["seed"] + 7919 * self.rank)
@@ -441,6 +455,47 @@ class DistributedPCGNN:
         self.win_ids = torch.zeros(B * self.window, dtype=torch.int32, device=self.dev)
         self.win_lab = torch.zeros(B * self.window, dtype=torch.int32, device=self.dev)
         self._graphs = {}
+        # the gradient all-reduce INSIDE the step's hipGraph (RCCL collectives can be stream-captured): a step is then one graph
+        # launch and nothing else - no eager collective, no second host call per step.  Probed once (a captured all-reduce of
+        # eight floats, replayed and checked) and only used if every rank's probe passed; PCG_DIST_GRAPH_COLLECTIVES=0 turns it off.
+        self.collectives_in_graph = self._probe_collective_capture()
+        import os
+        self.window_graphs = self.collectives_in_graph and os.environ.get("PCG_DIST_WINDOW_GRAPH", "1") != "0"
+        if self.collectives_in_graph:
+            # graphs holding captured collectives must be gone before the communicator is torn down (close()): also when the
+            # process ends without the caller having said so
+            import atexit
+            import weakref
+            ref = weakref.ref(self)
+            atexit.register(lambda: ref() is not None and ref().close())
+
+    def _probe_collective_capture(self) -> bool:
+        import os
+        if self.stage_host or os.environ.get("PCG_DIST_GRAPH_COLLECTIVES", "1") == "0":
+            return False
+        ok = False
+        try:
+            if dist.get_backend(self.group) == "nccl":
+                t = torch.ones(8, dtype=torch.float32, device=self.dev)
+                dist.all_reduce(t, group=self.group)               # (the communicator is set up outside the capture)
+                torch.cuda.synchronize(self.dev)
+                a_in = torch.full((self.world * 4,), float(self.rank), dtype=torch.float32, device=self.dev)
+                a_out = torch.empty_like(a_in)
+                dist.all_to_all_single(a_out, a_in, group=self.group)
+                torch.cuda.synchronize(self.dev)
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr, capture_error_mode="thread_local"):
+                    dist.all_reduce(t, group=self.group)
+                    dist.all_to_all_single(a_out, a_in, group=self.group)
+                t.fill_(1.0)
+                a_out.fill_(-1.0)
+                gr.replay()
+                torch.cuda.synchronize(self.dev)
+                want = torch.arange(self.world, dtype=torch.float32, device=self.dev).repeat_interleave(4)
+                ok = bool((t == float(self.world)).all().item()) and bool(torch.equal(a_out, want))
+        except Exception:                                           # (any refusal to capture: the eager collective stays)
+            ok = False
+        return self._agree_max(0 if ok else 1) == 0
 
     def _agree_max(self, value: int) -> int:
         """the largest `value` over the ranks (construction-time collective)"""
@@ -504,26 +559,52 @@ class DistributedPCGNN:
             _p(self.sync) if (in_select or train_flag) else None, part.lo, st), "pcg_choose_select_planned")
         self.halo.lookup(self.data, plan, self.list_capacity, B, g)
 
+    def _snap_refresh(self):
+        """the classifier snapshot from theta / m / v (construction, and after an update applied outside a step: flush())"""
+        n, o = self.n_clf, self.off_clf
+        for j, src in enumerate((self.theta, self.m, self.v)):
+            self.clf_snap[j * n:(j + 1) * n].copy_(src[o:o + n])
+
     def _seg_step(self, ids_local, labels, B, plan: int):
-        """the collective-free part of a training step: scores, select, look-up, gather over the extended table, dense step (it
-        finishes the long rows' means), this rank's gradient (slabs summed in tile order)."""
+        """the collective-free part of a training step, five launches:
+          front   [Adam on every parameter from the all-reduced gradient, if one is waiting || the train positives' unsorted keys ||
+                   the score of every row this rank holds (owned, train-pos, halo), by node id - with the classifier AFTER that
+                   update, recomputed from its snapshot]                                     (pcg_step_scores_dist)
+          select  [sorts the keys itself, reads the centres' scores by node id; lists of node ids; clears the "waiting" flag]
+          gather  over the extended table, translating the lists' node ids as it reads them (no look-up launch) [+ the snapshot]
+          dense   forward, loss (scaled by 1 / global batch), activation gradients -> transposed activations (no slabs)
+          wgrad   the weight gradients as GEMMs over the local batch -> self.grad; marks it as waiting
+        (round 3: seven - apply_pending, front, select, halo_lookup, gather, dense, grad_reduce)."""
         import ctypes as C
-        ops, g, lib, _p = self.ops, self.g, self.lib, self.ops._p
-        self._enqueue_apply()                      # the previous step's (all-reduced) gradient, if one is waiting
-        self._seg_front(ids_local, labels, B, True, plan)
-        st = ops._stream(self.dev)
+        ops, g, part, lib, _p = self.ops, self.g, self.part, self.lib, self.ops._p
         check, c = self._libmod.check, self.cfg
+        st = ops._stream(self.dev)
+        P = g.n_pos
+        in_select = P > 0 and bool(lib.pcg_pos_sort_in_select(P))
+        check(lib.pcg_step_scores_dist(g.desc_ref(), _p(self.theta), _p(self.m), _p(self.v), self.E, _p(self.grad), _p(self.clf_snap), 0,
+                                       g.n_nodes, _p(self.s0_full), _p(self.row_gid), _p(self.keys) if in_select else None,
+                                       part.n_local, _p(self.step_counter), _p(self.sync), c["lr"], 0.9, 0.999, 1e-8,
+                                       c["weight_decay"], st), "pcg_step_scores_dist")
+        if P > 0 and not in_select:          # too many positives for the in-kernel sort: the bucket sort's launches
+            ops.pos_sort(g, self.s0_full, self.keys)
+        check(lib.pcg_choose_select_planned(
+            g.desc_ref(), _p(ids_local), _p(labels), B, _p(self.s0_full), None, _p(self.keys) if P > 0 else None, self._thr, self._rhos,
+            1, 0, _p(self.cnt[:g.R * B]), _p(self.data), C.c_void_p(plan), self.list_capacity, _p(self.status), _p(self.sync),
+            part.lo, st), "pcg_choose_select_planned")
         agg = self.agg.view(-1)[:g.R * B * self.F].view(g.R, B, self.F)
-        check(lib.pcg_gather_lists_planned(_p(g.X), g.feat_dim, g.X.stride(0), g.X.shape[0], g.R * B, _p(self.cnt), g.desc_ref(), B,
-                                           _p(self.data), C.c_void_p(plan), self.list_capacity, _p(agg), agg.stride(1), _p(self.status), st),
-              "pcg_gather_lists_planned")
+        h = self.halo
+        check(lib.pcg_gather_lists_dist(
+            _p(g.X), g.feat_dim, g.X.stride(0), g.X.shape[0], g.R * B, _p(self.cnt), g.desc_ref(), B, _p(self.data), C.c_void_p(plan),
+            self.list_capacity, _p(agg), agg.stride(1), _p(self.status), part.lo, part.hi, part.n_local, _p(h.pos_ids32),
+            _p(h.pos_idx32), h.P, _p(h.table), h.slots, _p(h.counts), h.halo_cap, h.halo_base, _p(self.theta), _p(self.m), _p(self.v),
+            self.off_clf, self.n_clf, _p(self.clf_snap), st), "pcg_gather_lists_dist")
         check(lib.pcg_train_dense(g.desc_ref(), _p(self.theta), None, None, self.E, _p(ids_local), _p(labels), B, _p(agg),
                                   agg.stride(1), _p(self.cnt), _p(self.data), C.c_void_p(plan), self.list_capacity, float(c["alpha"]),
                                   1.0 / (B * self.world), _p(self.logits), _p(self.center), None, _p(self.row_loss),
-                                  _p(self.slabs), _p(self.step_counter), None, c["lr"], 0.9, 0.999, 1e-8, c["weight_decay"], 0,
-                                  None, 0, st), "pcg_train_dense")
-        check(lib.pcg_grad_reduce(_p(self.slabs), lib.pcg_dense_n_tiles(B), self.n_params, _p(self.grad), _p(self.opt_flag), st),
-              "pcg_grad_reduce")
+                                  None, _p(self.step_counter), None, c["lr"], 0.9, 0.999, 1e-8, c["weight_decay"], 4,
+                                  _p(self.acts), self.act_ld, st), "pcg_train_dense")
+        check(lib.pcg_wgrad(_p(self.acts), self.act_ld, B, self.F, self.E, self.R, None, None, None, None, c["lr"], 0.9, 0.999, 1e-8,
+                            c["weight_decay"], _p(self.grad), 0, 1, _p(self.wg_scratch), _p(self.opt_flag), st), "pcg_wgrad")
 
     def _enqueue_apply(self, clear: bool = False):
         """Adam from self.grad on every parameter if a gradient is waiting (device flag; a no-op launch otherwise).  Inside a
@@ -537,6 +618,7 @@ class DistributedPCGNN:
         """Apply the last step's Adam update now (it otherwise rides at the head of the next step's launches): call before
         the parameters are read.  Enqueued, not synchronised; every rank applies the same all-reduced gradient."""
         self._enqueue_apply(clear=True)
+        self._snap_refresh()
 
     def forward_sample(self, ids_local: torch.Tensor, labels: Optional[torch.Tensor], train_flag: bool = True,
                        prefetch: bool = True):
@@ -584,16 +666,20 @@ class DistributedPCGNN:
         # thread_local: RCCL's watchdog thread may query events while this thread captures
         with torch.cuda.graph(gr, capture_error_mode="thread_local"):
             step()
+            if self.collectives_in_graph:          # the step's only collective, captured behind its last kernel
+                dist.all_reduce(self.grad, group=self.group)
         self.step_counter.copy_(counter)
         self._graphs[(B, slot)] = (gr, ids)
         return gr, ids
 
-    def _replay_step(self, gr, ids, B):
-        """graph replay (bracketed by HIP events on every `profile_select`-th step), gradient all-reduce, Adam"""
+    def _replay_step(self, gr, ids, B, timed: Optional[bool] = None):
+        """graph replay (bracketed by HIP events on every `profile_select`-th step, or as the caller says), gradient all-reduce"""
         prof = getattr(self, "_prof", None)
-        timed = prof is not None and self._prof_step % self._prof_every == 0
-        if prof is not None:
-            self._prof_step += 1
+        if timed is None:
+            timed = prof is not None and self._prof_step % self._prof_every == 0
+            if prof is not None:
+                self._prof_step += 1
+        timed = timed and prof is not None
         if timed:      # on the launching stream: bench.py's roofline at N > 1
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
@@ -601,7 +687,8 @@ class DistributedPCGNN:
         if timed:
             ev[1].record()
             prof.append((ev[0], ev[1], ids.clone(), self.cnt[:self.g.R * B].clone()))
-        self._all_reduce(self.grad)                # (its Adam update rides at the head of the next step's graph; flush() applies it now)
+        if not self.collectives_in_graph:
+            self._all_reduce(self.grad)            # (its Adam update rides in the next step's front launch; flush() applies it now)
 
     def train_step(self, ids_local: torch.Tensor, labels: torch.Tensor, use_graphs: bool = True):
         """COLLECTIVE.  One training step on centres the current window covers (begin_window): one graph replay (or the same
@@ -622,18 +709,63 @@ class DistributedPCGNN:
         tail batch may be shorter; every rank must pass the same number of centres).  With graphs, the window's ids and
         labels are copied once into static buffers that the steps' graphs (one per batch position) read in place."""
         n = ids_window_local.numel()
-        self.begin_window(ids_window_local)
         if use_graphs and n <= self.win_ids.numel():
             self.win_ids[:n].copy_(ids_window_local)
             self.win_lab[:n].copy_(labels_window)
+            # With the collectives capturable the WHOLE window is one hipGraph: the halo exchange (collect, both all-to-alls, serve),
+            # the plans, every step's five launches and its all-reduce - one launch per window, no gap between its kernels.
+            # (A window of a size not seen yet runs step by step once - which also warms every kernel up - and is captured
+            #  afterwards; so does every `profile_select`-th window, all of its steps bracketed by events.)
+            prof = getattr(self, "_prof", None)
+            bracket = prof is not None and self._prof_win % self._prof_every == 0
+            if prof is not None:
+                self._prof_win += 1
+            gr_w = self._graphs.get(("window", n)) if self.window_graphs else None
+            if gr_w is not None and not bracket:
+                gr_w.replay()
+                return
+            self.begin_window(self.win_ids[:n])
             self._plan(self.win_ids, self.win_lab, n, self.B, self.win_plans, True)     # every batch of the window: one launch
             for slot, b0 in enumerate(range(0, n, self.B)):
                 B = min(self.B, n - b0)
                 gr, ids = self._graph_for(B, slot)
-                self._replay_step(gr, ids, B)
+                self._replay_step(gr, ids, B, timed=bracket)
+            if self.window_graphs and gr_w is None:
+                self._capture_window(n)
         else:
+            self.begin_window(ids_window_local)
             for b0 in range(0, n, self.B):
                 self.train_step(ids_window_local[b0:b0 + self.B], labels_window[b0:b0 + self.B], use_graphs)
+
+    def _capture_window(self, n: int) -> None:
+        """one hipGraph of a whole window of n centres in the static buffers (every kernel in it has run at least once)"""
+        torch.cuda.synchronize(self.dev)           # no collective of ours is in flight while capturing
+        gr = torch.cuda.CUDAGraph()
+        import gc
+        gc.collect()
+        was_on = gc.isenabled()
+        gc.disable()                               # (a collection tears tensors / events down with calls a capture does not allow)
+        try:
+            with torch.cuda.graph(gr, capture_error_mode="thread_local"):
+                self.begin_window(self.win_ids[:n])
+                self._plan(self.win_ids, self.win_lab, n, self.B, self.win_plans, True)
+                for slot, b0 in enumerate(range(0, n, self.B)):
+                    B = min(self.B, n - b0)
+                    self._seg_step(self.win_ids[b0:b0 + B], self.win_lab[b0:b0 + B], B, self.win_plans.data_ptr() + slot * self.plan_stride)
+                    dist.all_reduce(self.grad, group=self.group)
+        finally:
+            if was_on:
+                gc.enable()
+        self._graphs[("window", n)] = gr
+
+    def close(self) -> None:
+        """Drop every captured graph (call before ``destroy_process_group``: graphs that hold captured collectives must be gone
+        before their communicator is torn down - with a whole window's all-to-alls captured the teardown otherwise never returned)."""
+        import gc
+        torch.cuda.synchronize(self.dev)
+        self._graphs.clear()
+        gc.collect()
+        torch.cuda.synchronize(self.dev)
 
     def check(self) -> None:
         """COLLECTIVE.  Raise - on every rank, or on none - if any rank's exchange or selection list went over capacity, or a
@@ -669,8 +801,9 @@ class DistributedPCGNN:
             raise RuntimeError("partitioned step over capacity on some rank: " + "; ".join(what))
 
     def profile_select(self, every: int = 10):
-        """Start collecting (start event, end event, ids, |set| counts) of every `every`-th step's select segment."""
-        self._prof, self._prof_every, self._prof_step = [], every, 0
+        """Start collecting (start event, end event, ids, |set| counts) of the steps of every `every`-th window (train_window;
+        every `every`-th step of train_step calls)."""
+        self._prof, self._prof_every, self._prof_step, self._prof_win = [], every, 0, 0
         return self._prof
 
     def pick_epoch(self, size: int, epoch: int) -> torch.Tensor:

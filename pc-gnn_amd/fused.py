@@ -813,7 +813,7 @@ class FusedPCGNN:
             self.step_counter -= 1
             b1, b2 = self.betas
             _lib.check(self.lib.pcg_wgrad(_p(self.acts), self.act_ld, B, self.F, self.E, self.R, None, None, None, None, self.lr,
-                                          b1, b2, self.eps, self.wd, _p(self.grad), 0, 1, _p(self.wg_scratch), self._stream()), "pcg_wgrad")
+                                          b1, b2, self.eps, self.wd, _p(self.grad), 0, 1, _p(self.wg_scratch), None, self._stream()), "pcg_wgrad")
         self._lastB = B
         out = {}
         for name, view in self.views.items():

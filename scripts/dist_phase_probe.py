@@ -1,4 +1,5 @@
-"""Phase timing of the partitioned step at world size 1 (RCCL), with a sync after every phase."""
+"""Where the partitioned step's time goes at world size 1 (RCCL): a window's prefetch, its plans, graph replays alone, the
+collective alone - each timed over many repetitions with one synchronisation at the end."""
 import os, sys, time, torch, torch.distributed as dist
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29544")
@@ -7,18 +8,41 @@ dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 from pcgnn_amd import synth
 from pcgnn_amd.dist import DistributedPCGNN
 w = synth.yelp_like(0)
-d = DistributedPCGNN(w, dict(batch_size=1024), dev)
-ops, g, part = d.ops, d.g, d.part
+B, W = 1024, 8
+d = DistributedPCGNN(w, dict(batch_size=B), dev, window=W)
+print("collectives_in_graph", d.collectives_in_graph)
 def T():
     torch.cuda.synchronize(); return time.perf_counter()
-acc = {}
-for it in range(12):
-    ids = d.pick_epoch(1024, it); lab = d.labels_of(ids)
-    t = [T(), T()]
-    t0 = T(); d.train_step(ids, lab); t1 = T()
-    t2 = T(); d.train_step(ids, lab, use_graphs=False); t3 = T()
-    if it >= 2: acc['eager train_step'] = acc.get('eager train_step', 0) + (t3 - t2)
-    if it >= 2:
-        acc["whole train_step"] = acc.get("whole train_step", 0) + (t1 - t0)
-for k, v in acc.items(): print(f"{k:18s} {v / 10 * 1e6:8.1f} us")
+def timed(name, fn, reps, per=1):
+    fn(); fn()
+    t0 = T()
+    for _ in range(reps): fn()
+    t1 = T()
+    print(f"{name:44s} {(t1 - t0) / reps / per * 1e6:9.1f} us")
+state = {"e": 0}
+def window():
+    ids = d.pick_epoch(W * B, state["e"]); state["e"] += W
+    d.train_window(ids, d.labels_of(ids))
+for _ in range(3): window()
+timed("train_window / step", window, 20, W)
+ids = d.pick_epoch(W * B, 1000); lab = d.labels_of(ids)
+timed("pick_epoch + labels_of / window", lambda: d.labels_of(d.pick_epoch(W * B, 7)), 20)
+timed("begin_window / window", lambda: d.begin_window(ids), 20)
+d.win_ids[:W * B].copy_(ids); d.win_lab[:W * B].copy_(lab)
+timed("plan of a window / window", lambda: d._plan(d.win_ids, d.win_lab, W * B, B, d.win_plans, True), 20)
+grs = [d._graph_for(B, s)[0] for s in range(W)]
+def replays():
+    for g in grs: g.replay()
+timed("graph replay alone / step", replays, 20, W)
+timed("all_reduce(grad) alone", lambda: d._all_reduce(d.grad), 50)
+def replays_ar():
+    for g in grs:
+        g.replay()
+        if not d.collectives_in_graph: d._all_reduce(d.grad)
+timed("replay + collective / step", replays_ar, 20, W)
+d.check()
+print("checked", flush=True)
+d.close()
+print("closed", flush=True)
 dist.destroy_process_group()
+print("destroyed", flush=True)
