@@ -262,6 +262,10 @@ int pcg_step_scores(const pcg_graph_desc *g, const float *W, const float *b, int
  * acts != NULL (with act_ld; `slabs` is then only the classifier step's scratch, >= 8 * n_params floats): the previous step ran
  * pcg_train_dense(adam_clf = 3) - no gradient slabs exist; the deferred update's workgroups are the weight-gradient GEMMs over
  * that step's batch, each 16 x 16 output tile's workgroup applying Adam to its own parameters (pcg_wgrad below).
+ * keys_sorted != 0: pos_keys' first half holds THIS step's train-pos keys SORTED already (the previous step's
+ * pcg_train_dense(adam_clf = 3, sort_keys) sorted them on CUs its tiles leave idle, or pcg_pos_sort behind pcg_step_scores): the
+ * select launch sorts nothing, no row waits, and a positive hub row's minority window search runs on one of its waves beside the
+ * others' key pass.  Same lists either way, bit for bit.
  * inv_count = 1 / global batch size.  Selection, lists and aggregates: exactly pcg_choose_gather_planned(train_flag = 1). */
 int pcg_choose_gather_train(const pcg_graph_desc *g, const int32_t *nodes, const int32_t *labels, int32_t B, float *s0,
                             uint64_t *pos_keys, const double *thresholds, const double *rho, int32_t add_self, float *agg,
@@ -269,7 +273,7 @@ int pcg_choose_gather_train(const pcg_graph_desc *g, const int32_t *nodes, const
                             uint32_t *status, uint32_t *sync_words, float *theta, float *m, float *v, int32_t emb, float *clf_next,
                             const float *slabs, const int32_t *step_counter, float lambda_1, float inv_count, double lr, double beta1,
                             double beta2, double eps, double weight_decay, int32_t score_next, const uint8_t *next_touched,
-                            const float *acts, int32_t act_ld, float *wg_scratch, void *stream);
+                            const float *acts, int32_t act_ld, float *wg_scratch, int32_t keys_sorted, void *stream);
 int32_t pcg_sync_words_count(void);                 /* uint32 words of a `sync_words` buffer (zero-initialised ONCE by the caller; the
                                                         kernels leave every word but [1], [2] zero between launches) */
 int pcg_aggregate_lists_planned(const float *X, int32_t feat_dim, int32_t feat_stride, int64_t table_rows, int32_t n_rows,
@@ -379,7 +383,11 @@ int pcg_adam_step(float *theta, float *m, float *v, const float *slabs, int32_t 
  *     [self | h_r] , agg_r, dcomb, dh_r, combined, dlogits, dcentre - what every weight gradient is a GEMM over the batch of
  *     (src/layers.py:625-629, 284-289; src/model.py:54-61).  It marks them as waiting (sync_words[1] = 2, sync_words[2] = B / 16
  *     rounded up) for the next pcg_choose_gather_train(acts) / pcg_adam_flush(acts), whose workgroups run those GEMMs (f32 MFMA,
- *     fixed summation order) and apply Adam tile by tile.  adam_clf == 4: the same without marking (pcg_wgrad follows);
+ *     fixed summation order) and apply Adam tile by tile.  adam_clf == 4: the same without marking (pcg_wgrad follows).
+ *     sort_keys != NULL (adam_clf == 3 only; the pos_keys buffer whose scratch half holds the NEXT step's unsorted train-pos keys,
+ *     formed by the pcg_choose_gather_train(score_next) before this launch): if pcg_dense_sorts_keys(B, n_pos) the launch carries
+ *     ceil(n_pos / 64) more workgroups that rank-sort them into the first half (src/layers.py:683-691's order) - one workgroup
+ *     per 16 rows leaves most CUs of a batch of <= ~3000 rows idle; the next pcg_choose_gather_train is then told keys_sorted;
  *   - adam_clf == 1 (training: slabs, m, v, sync_words required): the workgroup that arrives last (device-scope ticket,
  *     write-through partial gradients) sums the label classifier's gradient over the tiles in tile order and applies
  *     Adam to those 2 * feat_dim + 2 parameters - the only ones the next step's score pass reads - and the launch marks the
@@ -426,7 +434,8 @@ int pcg_train_dense(const pcg_graph_desc *g, float *theta, float *m, float *v, i
                     const void *workspace, const void *plan, int64_t list_capacity, float lambda_1, float inv_count, float *logits,
                     float *center, float *combined, float *row_loss, float *slabs, int32_t *step_counter,
                     uint32_t *sync_words, double lr, double beta1, double beta2, double eps, double weight_decay,
-                    int32_t adam_clf, float *acts, int32_t act_ld, void *stream);
+                    int32_t adam_clf, float *acts, int32_t act_ld, uint64_t *sort_keys, void *stream);
+int32_t pcg_dense_sorts_keys(int32_t B, int32_t n_pos);   /* 1: the launch above (adam_clf = 3, sort_keys) sorts n_pos keys at batch B */
 int pcg_step_front_train(const pcg_graph_desc *g, float *theta, float *m, float *v, int32_t emb, float *s0,
                          uint64_t *pos_keys, const int32_t *nodes, const int32_t *labels, int32_t B,
                          const double *thresholds, const double *rho, int32_t add_self, void *workspace,

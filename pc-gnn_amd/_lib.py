@@ -63,7 +63,7 @@ PROTOTYPES = {
     "pcg_step_scores": (C.c_int, [_G, _P, _P, _I64, _I64, _P, _P, _P, _I64, _P, _P, _P]),
     "pcg_choose_gather_train": (C.c_int, [_G, _P, _P, _I32, _P, _P, C.POINTER(_F64), C.POINTER(_F64), _I32, _P, _I32, _P, _P, _P,
                                           _I64, _P, _P, _P, _P, _P, _I32, _P, _P, _P, C.c_float, C.c_float, _F64, _F64, _F64, _F64,
-                                          _F64, _I32, _P, _P, _I32, _P, _P]),
+                                          _F64, _I32, _P, _P, _I32, _P, _I32, _P]),
     "pcg_choose_plan_bytes": (_I64, [_G, _I32, _I64]),
     "pcg_choose_data_bytes": (_I64, [_G, _I32, _I64]),
     "pcg_plan_batches": (C.c_int, [_G, _P, _P, _I32, _I32, C.POINTER(_F64), C.POINTER(_F64), _I32, _I32, _P, _I64, _I64, _P, _P,
@@ -85,7 +85,8 @@ PROTOTYPES = {
                                             _P, _I32, _P, _P, _P, _I64, _P, _P, _P]),
     "pcg_gather_lists": (C.c_int, [_P, _I32, _I32, _I64, _I32, _P, _G, _I32, _P, _I64, _P, _I32, _P, _P]),
     "pcg_train_dense": (C.c_int, [_G, _P, _P, _P, _I32, _P, _P, _I32, _P, _I32, _P, _P, _P, _I64, C.c_float, C.c_float, _P, _P, _P,
-                                  _P, _P, _P, _P, _F64, _F64, _F64, _F64, _F64, _I32, _P, _I32, _P]),
+                                  _P, _P, _P, _P, _F64, _F64, _F64, _F64, _F64, _I32, _P, _I32, _P, _P]),
+    "pcg_dense_sorts_keys": (_I32, [_I32, _I32]),
     "pcg_step_front_train": (C.c_int, [_G, _P, _P, _P, _I32, _P, _P, _P, _P, _I32, C.POINTER(_F64), C.POINTER(_F64), _I32, _P,
                                        _I64, _P, _P, _P, _P, _F64, _F64, _F64, _F64, _F64, _P]),
     "pcg_grad_reduce": (C.c_int, [_P, _I32, _I64, _P, _P, _P]),

@@ -1105,7 +1105,7 @@ int pcg_choose_gather_train(const pcg_graph_desc *g, const int32_t *nodes, const
                             uint32_t *status, uint32_t *sync_words, float *theta, float *m, float *v, int32_t emb, float *clf_next,
                             const float *slabs, const int32_t *step_counter, float lambda_1, float inv_count, double lr, double beta1,
                             double beta2, double eps, double weight_decay, int32_t score_next, const uint8_t *next_touched,
-                            const float *acts, int32_t act_ld, float *wg_scratch, void *stream) {
+                            const float *acts, int32_t act_ld, float *wg_scratch, int32_t keys_sorted, void *stream) {
     if (!g || B < 0) return PCG_E_ARG;
     if (B == 0) return PCG_OK;
     if (!g->X || !agg || !s0 || !sync_words || !theta || !m || !v || !clf_next || !slabs || !step_counter || !labels) return PCG_E_ARG;
@@ -1122,7 +1122,9 @@ int pcg_choose_gather_train(const pcg_graph_desc *g, const int32_t *nodes, const
     if (!cnt) return PCG_E_ARG;
     const bool rank = g->n_pos > 0 && g->n_pos <= pcg::RANK_MAX;
     const int64_t cap = g->n_pos > 0 ? pcg_pos_sort_capacity(g->n_pos) / 2 : 0;
-    if (rank) {                                        // the select kernel sorts the unsorted keys itself
+    // keys_sorted: pos_keys' first half holds THIS step's keys sorted already (the previous step's pcg_train_dense(sort_keys), or
+    // pcg_pos_sort behind pcg_step_scores): no in-kernel sort, no row waits, a hub row's window search runs beside its key pass
+    if (rank && !keys_sorted) {                        // the select kernel sorts the unsorted keys itself
         a.sort_out = pos_keys;
         a.raw_keys = pos_keys + cap;
         a.sort_cap = (int32_t)cap;

@@ -68,7 +68,13 @@ struct DenseArgs {
     uint32_t *pending;          // two device words: [0] = 1 "the slabs hold a gradient not yet applied to the other parameters", [1] = its slab count
     AdamHyper h;
     unsigned long long *stamps; // diagnostic only (pcg_debug_set_dense_stamps): [tiles][16] wall-clock ticks, else null
+    // optional riders: the NEXT step's train-pos sort (rank sort of the unsorted keys the gather launch before this one formed), by
+    // workgroups behind the tiles' - only when tiles and sort together leave no CU with two workgroups (a batch of <= ~3000 rows)
+    const uint64_t *sort_raw;   // null: off
+    uint64_t *sort_out;
+    int32_t sort_n, sort_cap, n_tile_blocks;
 };
+constexpr int DENSE_SORT_TILE = 4096;     // keys per LDS tile of the riding sort (32 KB of the launch's dynamic LDS)
 #define DENSE_STAMP(slot) do { if (a.stamps && threadIdx.x == 0 && sp == 0) a.stamps[(size_t)tile_id * 16 + (slot)] = wall_clock64(); } while (0)
 
 // flat parameter / gradient order: W_cls | W_inter | W_intra[0..R) | W_clf | b_clf
@@ -207,6 +213,16 @@ __device__ __forceinline__ float row16_sum(float p) {
 template <bool WLDS, int F_, int E_, int R_>
 __global__ void __launch_bounds__(DENSE_THREADS) dense_step_kernel(const DenseArgs a) {
     extern __shared__ __align__(16) float sm[];
+    if (a.sort_raw && (int)blockIdx.x >= a.n_tile_blocks) {
+        // the next step's sorted train-pos keys (pos_rank_sort's body: a workgroup ranks 64 keys against all of them): the select
+        // launch that follows finds them sorted - no in-kernel sort, no row waiting for it, and a positive hub row's window
+        // search can run beside its key pass
+        uint64_t *sh = reinterpret_cast<uint64_t *>(sm);
+        int *part = reinterpret_cast<int *>(sh + DENSE_SORT_TILE);
+        rank_sort_body<DENSE_SORT_TILE, DENSE_WAVES, false>(nullptr, nullptr, a.sort_n, a.sort_cap, a.sort_out,
+                                                            (int)blockIdx.x - a.n_tile_blocks, sh, part, a.sort_raw);
+        return;
+    }
     const int F = F_ > 0 ? F_ : a.feat_dim, E = E_ > 0 ? E_ : a.emb, R = R_ > 0 ? R_ : a.n_rel;
     const int K1 = 2 * F, K1p = (K1 + KPAD - 1) / KPAD * KPAD, K2 = F + R * E, K2p = (K2 + KPAD - 1) / KPAD * KPAD;
     const int ld1 = K1p + 1, ld2 = K2p + 1, ldE = E + 1, ldW = E + 4;   // ldW: rows stay 16-B aligned (ds_write_b128)
@@ -235,7 +251,7 @@ __global__ void __launch_bounds__(DENSE_THREADS) dense_step_kernel(const DenseAr
         if (a.step_counter) __hip_atomic_fetch_add(a.step_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (a.pending) {
             a.pending[0] = acts_mode ? 2u : 1u;                 // the slabs (1) / acts (2) hold a gradient the other parameters still need
-            a.pending[1] = (unsigned)(gridDim.x / S);           // ... in this many slabs / blocks of 16 batch rows
+            a.pending[1] = (unsigned)(a.n_tile_blocks / S);           // ... in this many slabs / blocks of 16 batch rows
         }
     }
     // wave t's row of the loss phase: its label is requested now, not when the logits are ready
@@ -604,14 +620,14 @@ __global__ void __launch_bounds__(DENSE_THREADS) dense_step_kernel(const DenseAr
     // ---- the workgroup whose ticket was the last: sum of every tile's share of the classifier gradient (tile order), Adam
     //      for those 2F + 2 parameters (model_handler.py:153) - the only ones the next step's score pass reads ----------
     if (!adam_clf) return;
-    if (wave == clf_wave && lane == 0) s_flag[0] = sp == 0 && ticket_old == (unsigned)gridDim.x / (unsigned)S - 1u;
+    if (wave == clf_wave && lane == 0) s_flag[0] = sp == 0 && ticket_old == (unsigned)a.n_tile_blocks / (unsigned)S - 1u;
     __syncthreads();
     if (s_flag[0]) {
         if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         DENSE_STAMP(14);
-        const int n_tiles = (int)gridDim.x / S;
+        const int n_tiles = a.n_tile_blocks / S;
         unsigned staged_seen = (tid == 0 && S > 1) ? __hip_atomic_load(a.staged, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         const int64_t oc = off_clf(F, E, R);
         const int NC = 2 * F + 2;
@@ -655,7 +671,7 @@ __global__ void __launch_bounds__(DENSE_THREADS) dense_step_kernel(const DenseAr
                 // every workgroup without a ticket has long staged the old classifier (it said so ~10 us ago); the count was
                 // requested before the gradient's loads, so the check costs nothing in all but pathological schedules; bounded
                 if (tid == 0)
-                    for (int spins = 0; staged_seen < (unsigned)gridDim.x - (unsigned)n_tiles && spins < (1 << 20); ++spins) {
+                    for (int spins = 0; staged_seen < (unsigned)a.n_tile_blocks - (unsigned)n_tiles && spins < (1 << 20); ++spins) {
                         __builtin_amdgcn_s_sleep(4);
                         staged_seen = __hip_atomic_load(a.staged, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
@@ -743,6 +759,15 @@ static bool dense_wlds(int F, int E, int R) {
 
 static unsigned long long *g_dense_stamps = nullptr;
 
+}  // namespace pcg
+/* 1: pcg_train_dense(adam_clf = 3, sort_keys) for a batch of B rows also sorts the next step's train-pos keys (n_pos of them) -
+ * its tiles' workgroups and the sort's together leave no CU with two of them, and the rank sort fits (host helper) */
+extern "C" int32_t pcg_dense_sorts_keys(int32_t B, int32_t n_pos) {
+    if (B < 1 || n_pos < 1 || n_pos > pcg::RANK_MAX) return 0;
+    return (B + pcg::TB - 1) / pcg::TB + (n_pos + PCG_WAVE - 1) / PCG_WAVE <= 256 ? 1 : 0;
+}
+namespace pcg {
+
 struct DenseExtra {          // the optional parts of a launch
     const int32_t *chunk_begin = nullptr;
     const float *partial = nullptr;
@@ -752,6 +777,7 @@ struct DenseExtra {          // the optional parts of a launch
     uint32_t *ticket = nullptr, *pending = nullptr, *staged = nullptr;
     float *acts = nullptr;
     int32_t act_ld = 0;
+    uint64_t *sort_keys = nullptr;          // the riding sort of the next step's train-pos keys (pcg_train_dense)
     AdamHyper h = {0.f, 0.f, 0.f, 0.f, 0.f};
 };
 
@@ -816,6 +842,19 @@ static int launch_dense(const pcg_graph_desc *g, const float *theta, int32_t emb
     int n_split = (slabs && !x.acts) ? 256 / n_tiles : 1;
     a.n_split = n_split < 1 ? 1 : (n_split > 4 ? 4 : n_split);
     a.stamps = g_dense_stamps;
+    a.sort_raw = nullptr;
+    a.sort_out = nullptr;
+    a.sort_n = a.sort_cap = 0;
+    a.n_tile_blocks = n_tiles * a.n_split;
+    int n_sort_blocks = 0;
+    if (x.sort_keys && pcg_dense_sorts_keys(B, g->n_pos)) {
+        const int64_t cap = pcg_pos_sort_capacity(g->n_pos) / 2;
+        a.sort_out = x.sort_keys;
+        a.sort_raw = x.sort_keys + cap;
+        a.sort_n = g->n_pos;
+        a.sort_cap = (int32_t)cap;
+        n_sort_blocks = (g->n_pos + PCG_WAVE - 1) / PCG_WAVE;
+    }
     // the instantiated shapes: YelpChi (F 32) and Amazon (F 25) at emb 64 and 128, three relations; anything else: run-time shape
     typedef void (*kern_t)(const DenseArgs);
     kern_t kern;
@@ -837,8 +876,9 @@ static int launch_dense(const pcg_graph_desc *g, const float *theta, int32_t emb
                 break;
             }
     }
-    const dim3 grid(n_tiles * a.n_split), block(DENSE_THREADS);
-    hipLaunchKernelGGL(kern, grid, block, smem, static_cast<hipStream_t>(stream), a);
+    const dim3 grid(n_tiles * a.n_split + n_sort_blocks), block(DENSE_THREADS);
+    const size_t sort_smem = n_sort_blocks ? sizeof(uint64_t) * DENSE_SORT_TILE + sizeof(int) * DENSE_THREADS : 0;
+    hipLaunchKernelGGL(kern, grid, block, smem > sort_smem ? smem : sort_smem, static_cast<hipStream_t>(stream), a);
     PCG_LAUNCH_CHECK();
     return PCG_OK;
 }
@@ -879,7 +919,7 @@ int pcg_train_dense(const pcg_graph_desc *g, float *theta, float *m, float *v, i
                     const void *workspace, const void *plan, int64_t list_capacity, float lambda_1, float inv_count, float *logits, float *center,
                     float *combined, float *row_loss, float *slabs, int32_t *step_counter, uint32_t *sync_words, double lr,
                     double beta1, double beta2, double eps, double weight_decay, int32_t adam_clf, float *acts, int32_t act_ld,
-                    void *stream) {
+                    uint64_t *sort_keys, void *stream) {
     if (!g || B < 0) return PCG_E_ARG;
     pcg::DenseExtra x;
     if (workspace) {
@@ -897,6 +937,7 @@ int pcg_train_dense(const pcg_graph_desc *g, float *theta, float *m, float *v, i
         x.pending = sync_words + 1;
         x.acts = acts;
         x.act_ld = act_ld;
+        x.sort_keys = sort_keys;             // (only this mode has one workgroup per tile: CUs to spare for the riding sort)
     } else if (adam_clf == 4) {              // the same without marking anything as waiting (pcg_wgrad follows: gradients only)
         if (!acts) return PCG_E_ARG;
         x.acts = acts;

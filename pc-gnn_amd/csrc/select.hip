@@ -269,6 +269,103 @@ __device__ __forceinline__ void wave_kth(uint32_t ck, bool have, int n, int want
     need = want - __builtin_amdgcn_readlane(lt, src);
 }
 
+// The window of a positive centre's minority picks in the sorted train-pos keys (layers.py:675-691): the m nearest are
+// [L, R) (strictly nearer than the m-th distance) plus need_t of the ties [L2, L) and [R, R2) - those whose train_pos position is
+// <= tau.  One wave works it out (every lane gets the result); it needs the centre's score and the sorted keys, nothing of the row.
+struct MinorWindow {
+    int L, R, L2, R2, tau, need_t;
+};
+__device__ __forceinline__ MinorWindow minority_window(const ChooseArgs &a, int m, float c, int lane, const int *sortw) {
+    const uint64_t *__restrict__ pk = a.pos_keys;
+    const int P = a.g.n_pos;
+    int L, R, L2, R2, tau = INT_MAX, need_t = 0;
+    if (m >= P) {
+        L = L2 = 0;
+        R = R2 = P;
+    } else {
+        // window [lo, lo+m) of the m nearest: first lo whose left end is not farther than the element right of the window.
+        // With pc = the number of keys whose score is below c: the predicate is false for every x >= pc (the left end is not
+        // below c) and true for every x < pc - m (the element right of the window is still below c), so lo is in
+        // [pc - m, pc]; the workgroup's search index (every stride-th key's score, in LDS) brackets pc to one stride.
+        int lo_min = 0, lo_max = P - m;
+        if (a.n_sort > 0 && sortw) {
+            const int n_idx = sortw[2], stride = sortw[3];
+            const uint32_t *ix = reinterpret_cast<const uint32_t *>(sortw + 4);
+            const int t = wave_partition_point(0, n_idx, lane, [&](int x) { return from_orderable(ix[x]) < c; });
+            const int pc_lo = t > 0 ? (t - 1) * stride + 1 : 0, pc_hi = t * stride < P ? t * stride : P;
+            lo_min = pc_lo - m > 0 ? pc_lo - m : 0;
+            lo_max = pc_hi < P - m ? pc_hi : P - m;
+            lo_max = lo_max < lo_min ? lo_min : lo_max;
+        }
+        const int lo = wave_partition_point(lo_min, lo_max, lane, [&](int x) {
+            return (c - pos_score(pk, x)) > (pos_score(pk, x + m) - c);
+        });
+        // one batch of six independent loads decides the usual tie-free case
+        const uint32_t NOKEY = 0xFFFFFFFEu;    // never equals a distance key (keys have bit 31 clear)
+        const uint32_t ka = pos_dkey(pk, lo, c), kb = pos_dkey(pk, lo + m - 1, c);
+        const uint32_t ka1 = m > 1 ? pos_dkey(pk, lo + 1, c) : NOKEY;
+        const uint32_t kb1 = m > 1 ? pos_dkey(pk, lo + m - 2, c) : NOKEY;
+        const uint32_t kl = lo > 0 ? pos_dkey(pk, lo - 1, c) : NOKEY;
+        const uint32_t kr = lo + m < P ? pos_dkey(pk, lo + m, c) : NOKEY;
+        const uint32_t ks = ka > kb ? ka : kb;  // m-th smallest distance
+        const bool tie_l = ka == ks, tie_r = kb == ks;
+        const bool none_outside = kl != ks && kr != ks;
+        if (none_outside && m == 1) {                  // the window is one element; it is the single tie
+            L2 = lo;
+            L = R = R2 = lo + 1;
+        } else if (none_outside && !(tie_l && tie_r) && (tie_l ? ka1 != ks : kb1 != ks)) {
+            // exactly one element at distance ks, at one end of the window; no tie outside it
+            L2 = L = tie_l ? lo + 1 : lo;
+            R = R2 = tie_l ? lo + m : lo + m - 1;
+            if (tie_l) L2 = lo; else R2 = lo + m;      // that one element is the (single) tie, and it is taken
+        } else {
+            L = run_end_fwd(pk, c, ks, lo, lo + m, lane);
+            R = (L == lo + m) ? L : run_begin_bwd(pk, c, ks, lo + m - 1, L, lane);
+            L2 = run_begin_bwd(pk, c, ks, lo - 1, 0, lane);
+            R2 = run_end_fwd(pk, c, ks, lo + m, P, lane);
+        }
+        // ties are [L2, L) and [R, R2); strictly nearer ones are [L, R)
+        need_t = m - (R - L);
+        const int T = (L - L2) + (R2 - R);
+        if (T == need_t) {               // every tie is taken (the usual case): one contiguous, fully parallel range
+            L = L2;
+            R = R2;
+            need_t = 0;
+        } else if (T > PCG_WAVE) {       // many ties: threshold on the train_pos position by bisection
+            int plo = 0, phi = P - 1;
+            while (plo < phi) {
+                const int mid = (plo + phi) >> 1;
+                int cn = 0;
+                for (int i0 = L2; i0 < L; i0 += PCG_WAVE) {
+                    const int i = i0 + lane;
+                    cn += wave_count(i < L && (int)(uint32_t)pk_ld(pk, i) <= mid);
+                }
+                for (int i0 = R; i0 < R2; i0 += PCG_WAVE) {
+                    const int i = i0 + lane;
+                    cn += wave_count(i < R2 && (int)(uint32_t)pk_ld(pk, i) <= mid);
+                }
+                if (cn >= need_t) phi = mid;
+                else plo = mid + 1;
+            }
+            tau = plo;
+        } else {                          // a few ties: one per lane, the need_t smallest positions by in-register ranking
+            const int nl = L - L2;
+            const int ti = lane < nl ? L2 + lane : R + (lane - nl);
+            const bool tv = lane < T;
+            const int tp = tv ? (int)(uint32_t)pk_ld(pk, ti) : INT_MAX;
+            int rank = 0;
+            for (int j = 0; j < T; ++j) rank += __builtin_amdgcn_readlane(tp, j) < tp;
+            // tau = the need_t-th smallest position among the ties (positions are distinct)
+            const uint64_t hit = __ballot(tv && rank == need_t - 1);
+            const int src = __ffsll((unsigned long long)hit) - 1;
+            tau = __builtin_amdgcn_readlane(tp, src < 0 ? 0 : src);
+        }
+    }
+    MinorWindow w;
+    w.L = L; w.R = R; w.L2 = L2; w.R2 = R2; w.tau = tau; w.need_t = need_t;
+    return w;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Shared tail of every row (layers.py:675-694): minority over-sampling for positive centres, GCN-style self union,
 // the kept ids to the list (unless the caller has stored them already), |set|, length and the chunk fill counts.
@@ -277,7 +374,8 @@ __device__ __forceinline__ void wave_kth(uint32_t ck, bool have, int n, int want
 // ---------------------------------------------------------------------------------------------------------------------
 template <int NW>
 __device__ __forceinline__ void finish_row(const ChooseArgs &a, int row, const RowRec &p, float c, const uint32_t *sel, int ns,
-                                           bool sel_stored, int wave, int lane, int *red, int &keys_ok, int *sortw) {
+                                           bool sel_stored, int wave, int lane, int *red, int &keys_ok, int *sortw,
+                                           const int *pre_window = nullptr) {
     constexpr int NT = NW * PCG_WAVE;
     const int tid = wave * PCG_WAVE + lane;
     const int m = p.m, node = p.node;
@@ -285,92 +383,15 @@ __device__ __forceinline__ void finish_row(const ChooseArgs &a, int row, const R
     int mt = 0;        // slots used
     int valid = 0;     // per-thread count of non-duplicate minority picks
     if (m > 0) {
-        wait_sorted_keys(a, keys_ok, lane, sortw);
-        PCG_STAMP(7);
         const uint64_t *__restrict__ pk = a.pos_keys;
-        const int P = a.g.n_pos;
-        int L, R, L2, R2, tau = INT_MAX, need_t = 0;
-        if (m >= P) {
-            L = L2 = 0;
-            R = R2 = P;
+        int L, R, L2, R2, tau, need_t;
+        if (pre_window) {                        // worked out by a wave of this workgroup beside the row's key pass (select_wg_row)
+            L = pre_window[0]; R = pre_window[1]; L2 = pre_window[2]; R2 = pre_window[3]; tau = pre_window[4]; need_t = pre_window[5];
         } else {
-            // window [lo, lo+m) of the m nearest: first lo whose left end is not farther than the element right of the window.
-            // With pc = the number of keys whose score is below c: the predicate is false for every x >= pc (the left end is not
-            // below c) and true for every x < pc - m (the element right of the window is still below c), so lo is in
-            // [pc - m, pc]; the workgroup's search index (every stride-th key's score, in LDS) brackets pc to one stride.
-            int lo_min = 0, lo_max = P - m;
-            if (a.n_sort > 0 && sortw) {
-                const int n_idx = sortw[2], stride = sortw[3];
-                const uint32_t *ix = reinterpret_cast<const uint32_t *>(sortw + 4);
-                const int t = wave_partition_point(0, n_idx, lane, [&](int x) { return from_orderable(ix[x]) < c; });
-                const int pc_lo = t > 0 ? (t - 1) * stride + 1 : 0, pc_hi = t * stride < P ? t * stride : P;
-                lo_min = pc_lo - m > 0 ? pc_lo - m : 0;
-                lo_max = pc_hi < P - m ? pc_hi : P - m;
-                lo_max = lo_max < lo_min ? lo_min : lo_max;
-            }
-            const int lo = wave_partition_point(lo_min, lo_max, lane, [&](int x) {
-                return (c - pos_score(pk, x)) > (pos_score(pk, x + m) - c);
-            });
-            // one batch of six independent loads decides the usual tie-free case
-            const uint32_t NOKEY = 0xFFFFFFFEu;    // never equals a distance key (keys have bit 31 clear)
-            const uint32_t ka = pos_dkey(pk, lo, c), kb = pos_dkey(pk, lo + m - 1, c);
-            const uint32_t ka1 = m > 1 ? pos_dkey(pk, lo + 1, c) : NOKEY;
-            const uint32_t kb1 = m > 1 ? pos_dkey(pk, lo + m - 2, c) : NOKEY;
-            const uint32_t kl = lo > 0 ? pos_dkey(pk, lo - 1, c) : NOKEY;
-            const uint32_t kr = lo + m < P ? pos_dkey(pk, lo + m, c) : NOKEY;
-            const uint32_t ks = ka > kb ? ka : kb;  // m-th smallest distance
-            const bool tie_l = ka == ks, tie_r = kb == ks;
-            const bool none_outside = kl != ks && kr != ks;
-            if (none_outside && m == 1) {                  // the window is one element; it is the single tie
-                L2 = lo;
-                L = R = R2 = lo + 1;
-            } else if (none_outside && !(tie_l && tie_r) && (tie_l ? ka1 != ks : kb1 != ks)) {
-                // exactly one element at distance ks, at one end of the window; no tie outside it
-                L2 = L = tie_l ? lo + 1 : lo;
-                R = R2 = tie_l ? lo + m : lo + m - 1;
-                if (tie_l) L2 = lo; else R2 = lo + m;      // that one element is the (single) tie, and it is taken
-            } else {
-                L = run_end_fwd(pk, c, ks, lo, lo + m, lane);
-                R = (L == lo + m) ? L : run_begin_bwd(pk, c, ks, lo + m - 1, L, lane);
-                L2 = run_begin_bwd(pk, c, ks, lo - 1, 0, lane);
-                R2 = run_end_fwd(pk, c, ks, lo + m, P, lane);
-            }
-            // ties are [L2, L) and [R, R2); strictly nearer ones are [L, R)
-            need_t = m - (R - L);
-            const int T = (L - L2) + (R2 - R);
-            if (T == need_t) {               // every tie is taken (the usual case): one contiguous, fully parallel range
-                L = L2;
-                R = R2;
-                need_t = 0;
-            } else if (T > PCG_WAVE) {       // many ties: threshold on the train_pos position by bisection
-                int plo = 0, phi = P - 1;
-                while (plo < phi) {
-                    const int mid = (plo + phi) >> 1;
-                    int cn = 0;
-                    for (int i0 = L2; i0 < L; i0 += PCG_WAVE) {
-                        const int i = i0 + lane;
-                        cn += wave_count(i < L && (int)(uint32_t)pk_ld(pk, i) <= mid);
-                    }
-                    for (int i0 = R; i0 < R2; i0 += PCG_WAVE) {
-                        const int i = i0 + lane;
-                        cn += wave_count(i < R2 && (int)(uint32_t)pk_ld(pk, i) <= mid);
-                    }
-                    if (cn >= need_t) phi = mid;
-                    else plo = mid + 1;
-                }
-                tau = plo;
-            } else {                          // a few ties: one per lane, the need_t smallest positions by in-register ranking
-                const int nl = L - L2;
-                const int ti = lane < nl ? L2 + lane : R + (lane - nl);
-                const bool tv = lane < T;
-                const int tp = tv ? (int)(uint32_t)pk_ld(pk, ti) : INT_MAX;
-                int rank = 0;
-                for (int j = 0; j < T; ++j) rank += __builtin_amdgcn_readlane(tp, j) < tp;
-                // tau = the need_t-th smallest position among the ties (positions are distinct)
-                const uint64_t hit = __ballot(tv && rank == need_t - 1);
-                const int src = __ffsll((unsigned long long)hit) - 1;
-                tau = __builtin_amdgcn_readlane(tp, src < 0 ? 0 : src);
-            }
+            wait_sorted_keys(a, keys_ok, lane, sortw);
+            PCG_STAMP(7);
+            const MinorWindow mw = minority_window(a, m, c, lane, sortw);
+            L = mw.L; R = mw.R; L2 = mw.L2; R2 = mw.R2; tau = mw.tau; need_t = mw.need_t;
         }
         PCG_STAMP(4);
         // strictly nearer ones: slot = i - L, every thread of the group strides over them
@@ -726,24 +747,37 @@ __device__ __forceinline__ void select_wg_row(const ChooseArgs &a, int row, uint
 
     uint32_t kstar = 0xFFFFFFFFu;
     int need = 0, n_equal = 0;
+    // A positive centre's minority window needs the centre's score and the sorted train-pos keys - nothing of the row.  When the
+    // keys were sorted BEFORE this launch (a.n_sort == 0: the previous step's dense launch did it on CUs it leaves idle) the
+    // group's last wave works the window out (three dependent rounds of key loads, ~2.3 us) while the others form the row's
+    // distance keys, and leaves it in LDS for the row's tail: the search is off the row's chain.
+    int *win = sortw ? sortw + 4 : nullptr;                       // (the search index's place: unused when nothing is sorted in here)
+    const bool early = !keep_all && p.m > 0 && a.n_sort == 0 && win != nullptr && NW > 1;
     // (a row too long for the LDS keeps its keys in global scratch, gk: written by pass 1, read back coalesced by the later passes)
     if (!keep_all) {
         // ---- 1. distance keys (-> LDS), their range ----
         uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
         constexpr int KU1 = 16;     // pass 1 of a workgroup row: sixteen gathers in flight per lane (a 6 000-neighbour row: one round)
-        for (int base = tid; base < d; base += NT * KU1) {
+        const int nt1 = early ? NT - PCG_WAVE : NT;                // threads that share the key pass
+        if (early && wave == NW - 1) {
+            const MinorWindow mw = minority_window(a, p.m, c, lane, nullptr);
+            if (lane == 0) {
+                win[0] = mw.L; win[1] = mw.R; win[2] = mw.L2; win[3] = mw.R2; win[4] = mw.tau; win[5] = mw.need_t;
+            }
+        } else
+        for (int base = tid; base < d; base += nt1 * KU1) {
             uint32_t id[KU1];
             float sc[KU1];
 #pragma unroll
             for (int u = 0; u < KU1; ++u) {
-                const int i = base + u * NT;
+                const int i = base + u * nt1;
                 id[u] = (uint32_t)nbr[i < d ? i : d - 1];
             }
 #pragma unroll
             for (int u = 0; u < KU1; ++u) sc[u] = s0_ld<1>(s0, id[u]);
 #pragma unroll
             for (int u = 0; u < KU1; ++u) {
-                const int i = base + u * NT;
+                const int i = base + u * nt1;
                 if (i < d) {
                     const uint32_t key = dist_key(c, sc[u]);
                     if constexpr (LDSK) keys[i] = key;
@@ -973,8 +1007,9 @@ __device__ __forceinline__ void select_wg_row(const ChooseArgs &a, int row, uint
         PCG_STAMP(6);
         return;
     }
-    if constexpr (LDSK) finish_row<NW>(a, row, p, c, keys, ns, false, wave, lane, red, keys_ok, sortw);
-    else finish_row<NW>(a, row, p, c, selbuf, ns, !sel_in_lds, wave, lane, red, keys_ok, sortw);
+    // (early: the window is in LDS since before the first barrier of the k-th selection)
+    if constexpr (LDSK) finish_row<NW>(a, row, p, c, keys, ns, false, wave, lane, red, keys_ok, sortw, early ? win : nullptr);
+    else finish_row<NW>(a, row, p, c, selbuf, ns, !sel_in_lds, wave, lane, red, keys_ok, sortw, early ? win : nullptr);
 }
 
 // One persistent launch selects every row of the batch, longest rows first.  The work is one queue of workgroup-sized units,

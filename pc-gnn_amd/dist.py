@@ -602,7 +602,7 @@ class DistributedPCGNN:
                                   agg.stride(1), _p(self.cnt), _p(self.data), C.c_void_p(plan), self.list_capacity, float(c["alpha"]),
                                   1.0 / (B * self.world), _p(self.logits), _p(self.center), None, _p(self.row_loss),
                                   None, _p(self.step_counter), None, c["lr"], 0.9, 0.999, 1e-8, c["weight_decay"], 4,
-                                  _p(self.acts), self.act_ld, st), "pcg_train_dense")
+                                  _p(self.acts), self.act_ld, None, st), "pcg_train_dense")
         check(lib.pcg_wgrad(_p(self.acts), self.act_ld, B, self.F, self.E, self.R, None, None, None, None, c["lr"], 0.9, 0.999, 1e-8,
                             c["weight_decay"], _p(self.grad), 0, 1, _p(self.wg_scratch), _p(self.opt_flag), st), "pcg_wgrad")
 

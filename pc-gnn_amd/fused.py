@@ -30,6 +30,7 @@ Reference loop replaced: src/model_handler.py:147-153 (and :305 of utils.py for
 ``predict``).
 """
 import ctypes as C
+import os
 from typing import Dict, Optional
 
 import torch
@@ -109,7 +110,6 @@ class FusedPCGNN:
         # (PCG_TOUCHED=0/1 overrides; default: tables of 512 MB and more.  Measured, power-law graphs, batch 4096: 10 M nodes
         #  (1.28 GB): score pass 232 -> 63 us per step for ~35 us per step of map building; 2 M nodes (256 MB): 48 -> 25 us for
         #  ~30 us - not worth it there)
-        import os
         env = os.environ.get("PCG_TOUCHED")
         self.touched_on = (env == "1") if env in ("0", "1") else g.n_nodes * g.X.stride(0) * 4 >= (512 << 20)
         self._touch_stride = int(lib.pcg_touched_bytes(g.n_nodes)) if self.touched_on else 0
@@ -161,6 +161,11 @@ class FusedPCGNN:
         self.act_ld = 16 * int(lib.pcg_dense_n_tiles(B))
         self.acts = torch.zeros(int(lib.pcg_wgrad_act_rows(self.F, self.E, self.R)), self.act_ld, dtype=torch.float32, device=dev)
         self.wg_scratch = torch.zeros(int(lib.pcg_wgrad_scratch_bytes(self.F, self.E, self.R, self.act_ld)) // 4, dtype=torch.float32, device=dev)
+        # One dense workgroup per 16 rows leaves most CUs of a batch of <= ~3000 rows idle: the dense launch then also SORTS the
+        # next step's train-pos keys (formed beside the gather before it), and the select launch that follows is told so - it
+        # sorts nothing, no row waits for the sort, a positive hub row's window search runs beside its key pass.  The engine's
+        # invariant in this mode: whenever s0 / the keys are fresh (_fresh) the keys are SORTED (a refresh sorts them itself).
+        self.presort = bool(lib.pcg_dense_sorts_keys(B, g.n_pos)) and os.environ.get("PCG_PRESORT", "1") != "0"
         self.ids_buf = torch.zeros(B, dtype=torch.int32, device=dev)
         self.lab_buf = torch.zeros(B, dtype=torch.int32, device=dev)
 
@@ -245,6 +250,8 @@ class FusedPCGNN:
             g.desc_ref(), _p(self.clf_next), C.c_void_p(self.clf_next.data_ptr() + 8 * F), 0, g.n_nodes, _p(self.s0), None,
             _p(self.keys) if g.n_pos else None, -1, _p(self.sync), None if touched is None else C.c_void_p(touched),
             self._stream()), "pcg_step_scores")
+        if self.presort:                             # (the steps that follow are told the keys are sorted)
+            ops.pos_sort(g, self.s0, self.keys)
         self._fresh = True
 
     def _enqueue_choose_train(self, ids, labels, B, plan: int, score_next: bool, next_touched: Optional[int] = None):
@@ -264,7 +271,7 @@ class FusedPCGNN:
             _p(self.theta), _p(self.m), _p(self.v), self.E, _p(self.clf_next), _p(self.slabs), _p(self.step_counter),
             self.lambda_1, 1.0 / (B * self.scale), self.lr, b1, b2, self.eps, self.wd, 1 if score_next else 0,
             None if next_touched is None else C.c_void_p(next_touched), _p(self.acts), self.act_ld, _p(self.wg_scratch),
-            self._stream()), "pcg_choose_gather_train")
+            1 if self.presort else 0, self._stream()), "pcg_choose_gather_train")
         if timed:
             ev[1].record()
             self._prof.append(ev)
@@ -310,7 +317,9 @@ class FusedPCGNN:
             _p(cnt), _p(self.data), C.c_void_p(plan), self.list_capacity, self.lambda_1, 1.0 / (B * self.scale), _p(self.logits),
             _p(self.center), _p(combined), _p(self.row_loss) if labels is not None else None, _p(self.slabs) if train else None,
             _p(self.step_counter) if train else None, _p(self.sync), self.lr, b1, b2, self.eps, self.wd, adam_clf,
-            _p(self.acts) if adam_clf in (3, 4) else None, self.act_ld, self._stream()), "pcg_train_dense")
+            _p(self.acts) if adam_clf in (3, 4) else None, self.act_ld,
+            # (the next step's keys: formed by the gather launch before this one if it scored ahead - then sorted here)
+            _p(self.keys) if (adam_clf == 3 and self.presort and self._fresh) else None, self._stream()), "pcg_train_dense")
         if adam_clf == 1:                           # (the four-launch step updates theta's classifier in place)
             self.clf_next.copy_(self.theta[self.n_rest:])
 

@@ -73,7 +73,7 @@ def dense(t, s):
     _lib.check(lib.pcg_train_dense(g.desc_ref(), _p(fz.theta), _p(fz.m), _p(fz.v), fz.E, _p(ids), _p(lab), Bt, _p(a), a.stride(1),
                                    _p(cnt[t & 1]), _p(data[t & 1]), C.c_void_p(plan), fz.list_capacity, fz.lambda_1, 1.0 / Bt, _p(fz.logits),
                                    _p(fz.center), None, _p(fz.row_loss), _p(fz.slabs), _p(fz.step_counter), _p(fz.sync), fz.lr, b1, b2,
-                                   fz.eps, fz.wd, 2, None, 0, st(s)), "dense")
+                                   fz.eps, fz.wd, 2, None, 0, None, st(s)), "dense")
 
 
 def seq(T, main):

@@ -896,6 +896,43 @@ def test_epoch_as_one_graph_equals_step_by_step(P):
     assert torch.isfinite(a.fused.theta).all() and not torch.equal(a.fused.theta, torch.zeros_like(a.fused.theta))
 
 
+def test_keys_sorted_a_launch_early_equal_the_in_kernel_sort(P, monkeypatch):
+    """At batch sizes whose dense launch leaves CUs idle the dense launch sorts the NEXT step's train-pos keys and the select
+    launch is told so (it sorts nothing, no row waits, a positive hub row's window search runs on one wave beside the others'
+    key pass).  Same lists, same aggregates, same everything as the in-kernel sort (PCG_PRESORT=0), bit for bit: three epochs
+    as graph launches + single steps with another batch size, on a graph with hub rows of a few thousand neighbours (workgroup
+    rows of positive centres: the overlapped window search) and on the YelpChi-shaped one."""
+    from pcgnn_amd import synth
+    from pcgnn_amd.handler import PCGNNTrainer
+    for w, B in ((synth.make_workload("hubs", 30000, 32, (20000, 150000, 900000), 0.15, seed=4, skew=1.2, max_share=5e-3), 512),
+                 (synth.yelp_like(0), 1024)):
+        engines = []
+        for presort in ("1", "0"):
+            monkeypatch.setenv("PCG_PRESORT", presort)
+            t = PCGNNTrainer(w, dict(engine="graph", batch_size=B, seed=5), dev())
+            assert t.fused.presort == (presort == "1")
+            engines.append(t)
+        a, b = engines
+        b.fused.theta.copy_(a.fused.theta)
+        b.fused.params_changed()
+        if B == 512:
+            deg = np.concatenate([np.diff(ip)[w.train_pos] for ip, _ in w.csr])
+            assert (deg > 512).any(), "positive centres with workgroup rows must exist"
+        for t in (a, b):
+            for _ in range(3):
+                t.run_epoch_one_graph()
+            ids = t.sampler.pick(B // 2 + 7, 99)
+            t.fused.train_step(ids, t.labels_i32[ids.long()])
+            t.fused.train_step(ids[:100], t.labels_i32[ids[:100].long()], defer=True)
+            t.fused.flush()
+        torch.cuda.synchronize()
+        for t in (a, b):
+            t.fused.check()
+        for name in ("theta", "m", "v", "step_counter", "clf_next"):
+            assert torch.equal(getattr(a.fused, name), getattr(b.fused, name)), f"{name} ({w.name})"
+        assert torch.equal(a.fused.agg, b.fused.agg) and torch.equal(a.fused.cnt, b.fused.cnt)
+
+
 def test_epoch_groups_equal_epochs_one_by_one(P):
     """Several epochs sampled, planned and replayed TOGETHER (one sampler launch, one plan launch, one graph launch for the
     group: PCGNNTrainer.run_epoch_one_graph(n_epochs=K), what bench.py times) leave bit for bit what the same epochs leave one
