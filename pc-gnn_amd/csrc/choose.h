@@ -174,6 +174,11 @@ struct ChooseArgs {
     int32_t n_sort, sort_cap, sort_slices, sort_slice_len;
     uint32_t *pending_clear;   // device word the select kernel zeroes ("the deferred Adam update has been applied"), or null
     ClfStep clf;               // the label classifier's step for this batch (one workgroup), or clf.clf_next == null
+    // the previous step's weight gradients + Adam (wgrad.h) by the first n_wg_units row workgroups of the select launch, two 16 x 16
+    // tiles each (four waves a tile), before they start on rows - they take the LAST of the first units (short rows), like the
+    // sorting workgroups: small batches only (one K part); n_wg_units == 0: the gather launch's riders do it
+    WgradArgs wg;
+    int32_t n_wg_units;
     double thr[PCG_MAX_REL];
     double rho[PCG_MAX_REL];
     int32_t train_flag, add_self;
@@ -212,6 +217,7 @@ struct SideJob {
     int32_t n_adam_blocks;     // 0: no update from slabs
     WgradArgs wg;              // the deferred update from the dense kernel's transposed activations instead (wgrad.h) ...
     int32_t n_wgrad_blocks;    // ... by this many workgroups (0: off)
+    int32_t wg_prio;           // A/B knob: the weight-gradient workgroups raise their wave priority
     const float *W, *bias;     // the classifier to score with (ClfStep::clf_next), or null: no score pass
     float *s0;
     const unsigned char *touched;   // byte map of the rows the next batch reads, or null: the whole table

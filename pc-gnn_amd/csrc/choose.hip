@@ -733,6 +733,7 @@ static int choose_args(pcg::ChooseArgs &a, const pcg_graph_desc *g, const int32_
     a.n_sort = a.sort_cap = a.sort_slices = a.sort_slice_len = 0;
     a.pending_clear = nullptr;
     a.clf.clf_next = nullptr;
+    a.n_wg_units = 0;
     pcg::carve1(g, B, list_capacity, static_cast<unsigned char *>(workspace), &a.w,
                 static_cast<unsigned char *>(const_cast<void *>(plan)));
     return PCG_OK;
@@ -1148,6 +1149,39 @@ int pcg_choose_gather_train(const pcg_graph_desc *g, const int32_t *nodes, const
     a.clf.part_stride = n_params;
     a.clf.ticket = sync_words;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // the deferred update's weight-gradient workgroups (acts): in the gather launch (where they cost ~3 us of its ~10) - or, an
+    // option that measured slower, as the first units of the select launch
+    pcg::WgradArgs wga = {};
+    int wg_tiles = 0;
+    if (acts) {
+        wga.acts = acts; wga.ld = act_ld;
+        wga.F = g->feat_dim; wga.E = emb; wga.R = g->n_rel;
+        wga.theta = theta; wga.m = m; wga.v = v;
+        wga.step_counter = step_counter;
+        wga.h = h;
+        wga.pending = sync_words + 1;
+        wga.n_kblocks = act_ld / 16;             // (the batch size the engine's buffers were made for: the expected one)
+        wga.kparts = pcg::wgrad_kparts(act_ld / 16);
+        wga.tickets = reinterpret_cast<uint32_t *>(wg_scratch);
+        wga.partials = wg_scratch ? wg_scratch + (pcg::wgrad_tiles(g->feat_dim, emb, g->n_rel, 1) + 63) / 64 * 64 : nullptr;
+        wga.grad_out = nullptr;
+        wga.flag_set = nullptr;
+        wga.apply = 1;
+        wga.with_clf = 0;
+        wg_tiles = pcg::wgrad_tiles(g->feat_dim, emb, g->n_rel, 0);
+        // (A/B knob PCG_WGRAD_IN_SELECT=1.  Measured, YelpChi-like batch 1024: select_rows 16.2 -> 19.9 us, gather launch 10.5 -> 8.2:
+        //  43.8 vs 42.9 us per step - the workgroups that start on their rows ~7 us late end the launch later than the gather's
+        //  riders cost.  Off; profiles/r04/x_wgrad_in_select_yelp_bench.log)
+        static int in_select = -1;
+        if (in_select < 0) {
+            const char *e = getenv("PCG_WGRAD_IN_SELECT");
+            in_select = e ? atoi(e) : 0;
+        }
+        if (in_select && wga.kparts == 1 && wg_tiles % 2 == 0 && wg_tiles / 2 <= 96 && g->feat_stride <= 256) {
+            a.wg = wga;
+            a.n_wg_units = wg_tiles / 2;
+        }
+    }
     rc = pcg::launch_select(a, st, true);
     if (rc != PCG_OK) return rc;
     pcg::SideJob sd;
@@ -1160,22 +1194,19 @@ int pcg_choose_gather_train(const pcg_graph_desc *g, const int32_t *nodes, const
     sd.ad.h = h;
     sd.n_adam_blocks = acts ? 0 : (int)((o_clf + PCG_WAVE - 1) / PCG_WAVE);
     // acts: the previous step's pcg_train_dense(adam_clf = 3) left activations, not slabs - the weight gradients are GEMMs over
-    // its batch, each output tile's workgroup applying Adam to its own parameters (wgrad.h)
-    sd.wg.acts = acts; sd.wg.ld = act_ld;
-    sd.wg.F = g->feat_dim; sd.wg.E = emb; sd.wg.R = g->n_rel;
-    sd.wg.theta = theta; sd.wg.m = m; sd.wg.v = v;
-    sd.wg.step_counter = step_counter;
-    sd.wg.h = h;
-    sd.wg.pending = sync_words + 1;
-    sd.wg.n_kblocks = act_ld / 16;               // (the batch size the engine's buffers were made for: the expected one)
-    sd.wg.kparts = acts ? pcg::wgrad_kparts(act_ld / 16) : 1;
-    sd.wg.tickets = reinterpret_cast<uint32_t *>(wg_scratch);
-    sd.wg.partials = wg_scratch ? wg_scratch + (pcg::wgrad_tiles(g->feat_dim, emb, g->n_rel, 1) + 63) / 64 * 64 : nullptr;
-    sd.wg.grad_out = nullptr;
-    sd.wg.flag_set = nullptr;
-    sd.wg.apply = 1;
-    sd.wg.with_clf = 0;
-    sd.n_wgrad_blocks = acts ? pcg::wgrad_tiles(g->feat_dim, emb, g->n_rel, 0) * sd.wg.kparts : 0;
+    // its batch, each output tile's workgroup applying Adam to its own parameters (wgrad.h) - here unless the select launch did it
+    sd.wg = wga;
+    sd.n_wgrad_blocks = (acts && a.n_wg_units == 0) ? wg_tiles * wga.kparts : 0;
+    {
+        static int prio = -1, off = -1;          // A/B knobs (timing experiments only: PCG_WGRAD_OFF=1 skips the update)
+        if (prio < 0) {
+            const char *e = getenv("PCG_WGRAD_PRIO"), *o = getenv("PCG_WGRAD_OFF");
+            prio = e ? atoi(e) : 0;
+            off = o ? atoi(o) : 0;
+        }
+        sd.wg_prio = prio;
+        if (off) sd.n_wgrad_blocks = 0;
+    }
     sd.W = score_next ? clf_next : nullptr;
     sd.bias = clf_next + 2 * g->feat_dim;
     sd.s0 = s0;

@@ -204,6 +204,7 @@ __global__ void __launch_bounds__(256) PCG_GT_ATTR gather_train_kernel(const Agg
     // two memory round trips + a few dozen matrix instructions per wave is the longest chain in the launch - dispatched behind
     // the gather's workgroups it started when they ended
     if (b < s.n_wgrad_blocks) {
+        if (s.wg_prio) __builtin_amdgcn_s_setprio(3);             // (A/B knob PCG_WGRAD_PRIO)
         wgrad_adam_body(s.wg, b, part);
         return;
     }

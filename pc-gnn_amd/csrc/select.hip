@@ -1361,9 +1361,22 @@ __global__ void __launch_bounds__(SEL_NW *PCG_WAVE) __attribute__((amdgpu_waves_
         return;
     }
 
+    int u = bid;
+    // The previous step's weight gradients (GEMMs over its batch) + Adam, two tiles per workgroup, before its rows (CLF launches
+    // of small batches: choose.h).  Nothing in this launch reads what they write (the dense launch, two launches on, does).
+    if (CLF && a.n_wg_units > 0) {
+        if (u < a.n_wg_units) {
+            float(*wred)[256] = reinterpret_cast<float(*)[256]>(lds + ((int)threadIdx.x >> 8) * 1024);
+            const int n_tiles = wgrad_tiles(a.wg.F, a.wg.E, a.wg.R, 0);
+            const int tile = 2 * u + ((int)threadIdx.x >> 8);
+            // (an odd tile count: the last unit's second half works on the last tile again - same result, stored twice)
+            wgrad_adam_body<4>(a.wg, tile < n_tiles ? tile : n_tiles - 1, wred, (int)threadIdx.x & 255);
+            __syncthreads();                                               // (the LDS is the row paths' again)
+        }
+        u = u < a.n_wg_units ? grid - a.n_wg_units + u : u - a.n_wg_units;
+    }
     // The train positives' sort, inside this launch and shared by its workgroups (sort_share), before the rows: only rows with
     // minority picks ever wait for the result (wait_sorted_keys), and they are busy with their own distance keys meanwhile.
-    int u = bid;
     if (a.n_sort > 0) {
         const int helpers = a.n_sort * a.sort_slices;
         if (u < helpers) {

@@ -61,12 +61,15 @@ __host__ __device__ inline int64_t wgrad_scratch_floats(int F, int E, int R, int
     return (int64_t)((t + 63) / 64 * 64) + (int64_t)t * wgrad_kparts(n_kblocks) * 256;
 }
 
-// workgroup `wg` of wgrad_tiles(...) * kparts (256 threads); red: 4 * 256 floats of LDS
-__device__ __forceinline__ void wgrad_adam_body(const WgradArgs &a, int wg, float (*red)[256]) {
+// workgroup `wg` of wgrad_tiles(...) * kparts (256 threads: tid; a group of four waves of a larger workgroup may pass its own
+// thread index - then kparts must be 1: the groups of a workgroup share its barriers); red: 4 * 256 floats of LDS; NB: K blocks
+// whose operands a wave has in flight
+template <int NB = WG_NB>
+__device__ __forceinline__ void wgrad_adam_body(const WgradArgs &a, int wg, float (*red)[256], int tid = (int)threadIdx.x) {
     typedef float f4 __attribute__((ext_vector_type(4)));
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const int KP = a.kparts > 1 ? a.kparts : 1;
-    if (a.flag_set && wg == 0 && threadIdx.x == 0) a.flag_set[0] = 1u;
+    if (a.flag_set && wg == 0 && tid == 0) a.flag_set[0] = 1u;
     int b = wg / KP;
     const int tile = b, kp = wg - b * KP;
     // the words that say whether (and how much) there is to do are requested first, the first operands - for the batch size
@@ -80,7 +83,7 @@ __device__ __forceinline__ void wgrad_adam_body(const WgradArgs &a, int wg, floa
     const int F = a.F, E = a.E, R = a.R;
     const int K2 = F + R * E, K1 = 2 * F, ne = E / 16;
     const int r_agg = K2, r_dcomb = K2 + R * F, r_dh = r_dcomb + E, r_comb = r_dh + R * E, r_dlog = r_comb + E, r_dcl = r_dlog + 2;
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, kq = lane >> 4;
     // ---- which tile: section, m0, n0 (workgroup-uniform) ----
     int sec, m0, n0, rel = 0;
@@ -134,10 +137,10 @@ __device__ __forceinline__ void wgrad_adam_body(const WgradArgs &a, int wg, floa
     const int ld_blocks = a.ld >> 4;
     int u_lo, u_hi;
     range(hint < ld_blocks ? hint : ld_blocks, u_lo, u_hi);
-    f4 av[WG_NB], bv[WG_NB];
+    f4 av[NB], bv[NB];
     auto fetch = [&](int u0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < WG_NB; ++j) {
+        for (int j = 0; j < NB; ++j) {
             int u = u0 + j < u_hi ? u0 + j : u_hi - 1;
             u = u < 0 ? 0 : u;                                     // (an empty range: any block of the buffer; nothing is added)
             av[j] = *reinterpret_cast<const f4 *>(ap + 16 * u);
@@ -151,14 +154,14 @@ __device__ __forceinline__ void wgrad_adam_body(const WgradArgs &a, int wg, floa
         fetch(u_lo);
     }
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int u0 = u_lo; u0 < u_hi; u0 += WG_NB) {
+    for (int u0 = u_lo; u0 < u_hi; u0 += NB) {
         if (u0 != u_lo) fetch(u0);
         if (ones) {
 #pragma unroll
-            for (int j = 0; j < WG_NB; ++j) bv[j] = f4{1.f, 1.f, 1.f, 1.f};
+            for (int j = 0; j < NB; ++j) bv[j] = f4{1.f, 1.f, 1.f, 1.f};
         }
 #pragma unroll
-        for (int j = 0; j < WG_NB; ++j) {
+        for (int j = 0; j < NB; ++j) {
             if (u0 + j >= u_hi) break;                             // (wave-uniform)
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].x, bv[j].x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].y, bv[j].y, acc, 0, 0, 0);
