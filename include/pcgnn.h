@@ -49,7 +49,9 @@ enum {
 enum {
     PCG_ST_SEL_OVERFLOW = 1,  /* sel_indices capacity too small; nothing was written past it */
     PCG_ST_LIST_ID_RANGE = 2, /* a selection-list entry named no row of the table handed to the gather; it was skipped (a hole) */
-    PCG_ST_SYNC_TIMEOUT = 4   /* a bounded in-kernel wait (the select kernel's wait for its own train-pos sort) ran out */
+    PCG_ST_SYNC_TIMEOUT = 4,  /* a bounded in-kernel wait (the select kernel's wait for its own train-pos sort) ran out */
+    PCG_ST_SORT_OVERFLOW = 8  /* the one-launch bucket sort of the train positives met a bucket of more than 4096 keys (thirteen times
+                                 the mean): its surplus keys were dropped - minority picks of that step may be wrong */
 };
 
 enum { PCG_NORM_COUNT = 0, PCG_NORM_SQRT_COUNT = 1 };
@@ -234,6 +236,13 @@ int pcg_choose_gather_planned(const pcg_graph_desc *g, const int32_t *nodes, con
                               float *agg, int32_t agg_stride, int32_t *cnt, void *workspace, const void *plan,
                               int64_t list_capacity, uint32_t *status, uint32_t *sync_words, void *stream);
 int32_t pcg_pos_sort_in_select(int32_t n_pos);      /* 1: 0 < n_pos <= 16384 (host helper) */
+/* 16384 < n_pos <= 131072 train positives whose UNSORTED keys exist already (pos_keys' scratch half: pcg_choose_gather_train forms
+ * them beside the score pass for these sizes too): the bucket sort in ONE launch - workgroup b sorts the same small sample, takes
+ * its two splitters, streams all keys once (counting those below its range: the bucket's offset; collecting its own in LDS),
+ * ranks them and stores them in place; no counts, no scatter, no hand-off between workgroups (pcg_pos_sort's four launches took
+ * 35 us at 40 K keys).  A bucket of more than 4096 keys sets PCG_ST_SORT_OVERFLOW in *status (may be NULL).  src/layers.py:683-691's order. */
+int32_t pcg_pos_sort_one_launch(int32_t n_pos);
+int pcg_pos_sort_raw(const pcg_graph_desc *g, uint64_t *pos_keys, uint32_t *status, void *stream);
 /* scores of rows [row_begin, row_end) (-> s0_out[row], or s0_out[row_ids[row]]) || the UNSORTED train-pos keys into pos_keys'
  * scratch half (pos_keys may be NULL; pos_row_base >= 0: train positive i's feature row is table row pos_row_base + i - required
  * with row_ids -, else row train_pos[i]); zeroes sync_words[3].  ONE launch, no plan, no parameter update.

@@ -14,6 +14,7 @@ PCG_OK, PCG_E_ARG, PCG_E_UNSUPPORTED, PCG_E_LAUNCH = 0, -1, -2, -3
 PCG_ST_SEL_OVERFLOW = 1
 PCG_ST_LIST_ID_RANGE = 2
 PCG_ST_SYNC_TIMEOUT = 4
+PCG_ST_SORT_OVERFLOW = 8
 PCG_NORM_COUNT, PCG_NORM_SQRT_COUNT = 0, 1
 ABI_VERSION = 3
 
@@ -72,6 +73,8 @@ PROTOTYPES = {
                                   _P]),
     "pcg_pick_shuffled_epochs": (C.c_int, [_P, _P, _I32, _U64, _U64, _P, _I32, _I32, _I32, _P, _P, _P, _P]),
     "pcg_pos_sort_in_select": (_I32, [_I32]),
+    "pcg_pos_sort_one_launch": (_I32, [_I32]),
+    "pcg_pos_sort_raw": (C.c_int, [_G, _P, _P, _P]),
     "pcg_sync_words_count": (_I32, []),
     "pcg_aggregate_lists_planned": (C.c_int, [_P, _I32, _I32, _I64, _I32, _P, _G, _I32, _P, _P, _I64, _I32, _P, _I32, _P, _P]),
     "pcg_gather_lists_planned": (C.c_int, [_P, _I32, _I32, _I64, _I32, _P, _G, _I32, _P, _P, _I64, _P, _I32, _P, _P]),

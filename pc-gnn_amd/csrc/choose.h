@@ -208,6 +208,8 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 
 // select.hip
 int launch_select_rows(const ChooseArgs &a, hipStream_t st);
+// sort.hip: the one-launch bucket sort over raw keys (RANK_MAX < n_pos <= 131072)
+int launch_bk_onepass(const uint64_t *raw, int n_pos, uint64_t *keys, int cap, uint32_t *status, hipStream_t st);
 
 // What rides along the gather launch of a training step (gather.hip: gather_train_kernel): the deferred Adam update of every
 // parameter but the label classifier's (from the previous step's slabs; the dense kernel that follows reads the result), and the

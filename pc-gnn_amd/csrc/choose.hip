@@ -1211,7 +1211,9 @@ int pcg_choose_gather_train(const pcg_graph_desc *g, const int32_t *nodes, const
     sd.bias = clf_next + 2 * g->feat_dim;
     sd.s0 = s0;
     sd.touched = next_touched;
-    sd.raw_keys = (score_next && rank && g->train_pos) ? pos_keys + cap : nullptr;
+    // (the one-launch bucket sort - 16384 < n_pos <= 131072 - works on raw keys formed here too)
+    const bool one_launch = pcg_pos_sort_one_launch(g->n_pos) != 0;
+    sd.raw_keys = (score_next && (rank || one_launch) && g->train_pos) ? pos_keys + cap : nullptr;
     const int rows_per_block = 4 * (PCG_WAVE / pcg::lanes_per_row(g->feat_stride));
     int n_key = sd.raw_keys ? (g->n_pos + rows_per_block - 1) / rows_per_block : 0;
     sd.n_key_blocks = n_key > 256 ? 256 : n_key;
@@ -1219,6 +1221,7 @@ int pcg_choose_gather_train(const pcg_graph_desc *g, const int32_t *nodes, const
     sd.zero_word = sync_words + 3;
     rc = pcg::launch_gather_train(g->X, g->feat_dim, g->feat_stride, g->n_nodes, cnt, g, B, a.w, agg, agg_stride, status, sd, st);
     if (rc != PCG_OK) return rc;
+    if (score_next && one_launch) return pcg::launch_bk_onepass(pos_keys + cap, g->n_pos, pos_keys, (int)cap, status, st);
     if (score_next && g->n_pos > pcg::RANK_MAX) return pcg_pos_sort(g, s0, pos_keys, stream);
     return PCG_OK;
 }

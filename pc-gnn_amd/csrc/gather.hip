@@ -188,7 +188,9 @@ __global__ void __launch_bounds__(256) gather_chunks_dist(const AggArgs a, const
 #ifndef PCG_GT_WPE          // (A/B switch: 1 = cap the registers at the gather's own 80 - 6 waves per SIMD - at the price of a few spills)
 #define PCG_GT_WPE 0
 #endif
-#if PCG_GT_WPE
+#if PCG_GT_WPE == 2      // five waves per SIMD for the 128-B-row instantiation (94 registers, no spill; the weight-gradient workgroups' code took it to 100 + 4)
+#define PCG_GT_ATTR __attribute__((amdgpu_waves_per_eu(NACC == 1 ? 5 : 4, 8)))
+#elif PCG_GT_WPE
 #define PCG_GT_ATTR __attribute__((amdgpu_waves_per_eu(6, 8)))
 #else
 #define PCG_GT_ATTR

@@ -200,9 +200,143 @@ __global__ void __launch_bounds__(RANK_WAVES *PCG_WAVE) bk_sort(const BucketArgs
     rank_sort_body<BK_TILE>(nullptr, nullptr, n_b, n_b, a.keys + off[b], (int)(me - grp[b]), sh, part, a.tmp + off[b]);
 }
 
+// ---- RANK_MAX < n_pos <= BK1_MAX: the bucket sort in ONE launch over the raw keys (round 3: four launches, 35 us at 40 K keys) ----
+// Workgroup b IS bucket b.  Nothing is counted, scattered or handed from one workgroup to another: every workgroup
+//   1. sorts the same sample of the raw keys (n_sample <= 1024 evenly spaced positions, ranked in LDS) and takes ITS two splitters;
+//   2. streams ALL raw keys once (coalesced 8-byte loads, eight in flight per thread): counts the keys below its lower splitter -
+//      that count is the bucket's offset in the sorted order - and collects the keys of its own range in LDS;
+//   3. ranks the collected keys against each other and stores every key at offset + rank.
+// n_pos keys x n_buckets workgroups of streaming (40 K keys, 128 buckets: 41 MB out of L2) instead of three more launches and
+// their hand-offs.  A bucket holds ~n_pos / n_buckets ~ 300 keys with eight samples per bucket; BK_TILE (4096) of them fit - more
+// than thirteen times the mean: a bucket over that is reported (PCG_ST_SORT_OVERFLOW, its surplus keys dropped), never silent.
+constexpr int BK1_MAX = 131072;
+__global__ void __launch_bounds__(SORT_THREADS) bk_onepass(const uint64_t *__restrict__ raw, int n_pos, int n_buckets, int n_sample,
+                                                           uint64_t *__restrict__ keys, int cap, uint32_t *status) {
+    __shared__ __align__(16) uint64_t sh[BK_TILE];
+    __shared__ __align__(16) uint64_t samp[SORT_THREADS];
+    __shared__ uint64_t sorted[SORT_THREADS];
+    __shared__ int red[SORT_THREADS / PCG_WAVE];
+    __shared__ int n_in;
+    const int t = threadIdx.x, b = blockIdx.x;
+    if (b >= n_buckets) {                                       // spare workgroups: the padding behind the keys
+        const int spare = (int)gridDim.x - n_buckets, k = b - n_buckets;
+        for (int64_t i = n_pos + (int64_t)k * SORT_THREADS + t; i < cap; i += (int64_t)spare * SORT_THREADS) keys[i] = ~0ull;
+        return;
+    }
+    // this thread's first keys of the stream are requested with the sample (nothing of them depends on the splitters)
+    constexpr int SU = 8;
+    uint64_t kv[SU];
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+        const int i = t + u * SORT_THREADS;
+        kv[u] = raw[i < n_pos ? i : n_pos - 1];
+    }
+    // pad (n_sample < 1024): all-ones keys rank behind every real one
+    samp[t] = t < n_sample ? raw[(int)(((int64_t)t * n_pos) / n_sample)] : ~0ull;
+    if (t == 0) n_in = 0;
+    __syncthreads();
+    {
+        const uint64_t mine = samp[t];
+        int rank = 0;
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(samp);
+        const int ns8 = (n_sample + 7) & ~7;
+        for (int j = 0; j < ns8; j += 8) {
+            const uint4 q0 = s4[(j >> 1) + 0], q1 = s4[(j >> 1) + 1], q2 = s4[(j >> 1) + 2], q3 = s4[(j >> 1) + 3];
+            rank += ((((uint64_t)q0.y << 32) | q0.x) < mine) + ((((uint64_t)q0.w << 32) | q0.z) < mine) +
+                    ((((uint64_t)q1.y << 32) | q1.x) < mine) + ((((uint64_t)q1.w << 32) | q1.z) < mine) +
+                    ((((uint64_t)q2.y << 32) | q2.x) < mine) + ((((uint64_t)q2.w << 32) | q2.z) < mine) +
+                    ((((uint64_t)q3.y << 32) | q3.x) < mine) + ((((uint64_t)q3.w << 32) | q3.z) < mine);
+        }
+        if (t < n_sample) sorted[rank] = mine;                 // (sample positions are distinct, so the keys - and the ranks - are)
+    }
+    __syncthreads();
+    const int per = n_sample / n_buckets;
+    const uint64_t lo = b == 0 ? 0ull : sorted[b * per], hi = b == n_buckets - 1 ? ~0ull : sorted[(b + 1) * per];
+    // ---- the stream: keys below lo are counted, keys in [lo, hi) collected ----
+    int below = 0;
+    for (int base = 0; base < n_pos; base += SU * SORT_THREADS) {
+        uint64_t nx[SU];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {                         // the next round's keys before this round's are looked at
+            const int i = base + SU * SORT_THREADS + t + u * SORT_THREADS;
+            nx[u] = raw[i < n_pos ? i : n_pos - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int i = base + t + u * SORT_THREADS;
+            if (i < n_pos) {
+                below += kv[u] < lo;
+                if (kv[u] >= lo && kv[u] < hi) {
+                    const int at = atomicAdd(&n_in, 1);
+                    if (at < BK_TILE) sh[at] = kv[u];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) kv[u] = nx[u];
+    }
+    for (int o = 1; o < PCG_WAVE; o <<= 1) below += __shfl_xor(below, o);
+    if ((t & (PCG_WAVE - 1)) == 0) red[t >> 6] = below;
+    __syncthreads();
+    int off = 0;
+#pragma unroll
+    for (int w = 0; w < SORT_THREADS / PCG_WAVE; ++w) off += red[w];
+    int n = n_in;
+    if (n > BK_TILE) {
+        if (t == 0 && status) atomicOr(status, (uint32_t)PCG_ST_SORT_OVERFLOW);
+        n = BK_TILE;
+    }
+    // pad the collected keys to a multiple of eight (all-ones: never smaller than anybody's)
+    const int n8 = (n + 7) & ~7;
+    if (t < n8 - n) sh[n + t] = ~0ull;
+    __syncthreads();
+    // ---- rank inside the bucket (order of collection is whatever the atomics gave: the ranks do not depend on it) ----
+    const uint4 *sh4 = reinterpret_cast<const uint4 *>(sh);
+    for (int i = t; i < n; i += SORT_THREADS) {
+        const uint64_t mine = sh[i];
+        int rank = 0;
+        for (int j = 0; j < n8; j += 8) {
+            const uint4 q0 = sh4[(j >> 1) + 0], q1 = sh4[(j >> 1) + 1], q2 = sh4[(j >> 1) + 2], q3 = sh4[(j >> 1) + 3];
+            rank += ((((uint64_t)q0.y << 32) | q0.x) < mine) + ((((uint64_t)q0.w << 32) | q0.z) < mine) +
+                    ((((uint64_t)q1.y << 32) | q1.x) < mine) + ((((uint64_t)q1.w << 32) | q1.z) < mine) +
+                    ((((uint64_t)q2.y << 32) | q2.x) < mine) + ((((uint64_t)q2.w << 32) | q2.z) < mine) +
+                    ((((uint64_t)q3.y << 32) | q3.x) < mine) + ((((uint64_t)q3.w << 32) | q3.z) < mine);
+        }
+        const int dst = off + rank;
+        if (dst < n_pos) keys[dst] = mine;                     // (a counter never indexes unchecked)
+    }
+}
+
+// the launch geometry of the one-pass sort
+static void bk1_geometry(int n_pos, int &n_buckets, int &n_sample) {
+    int nb = 32;
+    while (nb < 256 && (int64_t)nb * 512 < n_pos) nb <<= 1;    // ~300 - 512 keys per bucket
+    n_buckets = nb;
+    const int ns = nb * 8;
+    n_sample = ns > SORT_THREADS ? SORT_THREADS : ns;          // (a multiple of n_buckets: both are powers of two)
+}
+int launch_bk_onepass(const uint64_t *raw, int n_pos, uint64_t *keys, int cap, uint32_t *status, hipStream_t st) {
+    int nb, ns;
+    bk1_geometry(n_pos, nb, ns);
+    hipLaunchKernelGGL(bk_onepass, dim3(nb + 8), dim3(SORT_THREADS), 0, st, raw, n_pos, nb, ns, keys, cap, status);
+    PCG_LAUNCH_CHECK();
+    return PCG_OK;
+}
+
 }  // namespace pcg
 
 extern "C" {
+
+/* 1: n_pos train positives are sorted by the one-launch bucket sort when their unsorted keys exist already
+ * (pcg_choose_gather_train forms them beside the score pass): 16384 < n_pos <= 131072 (host helper) */
+int32_t pcg_pos_sort_one_launch(int32_t n_pos) { return n_pos > pcg::RANK_MAX && n_pos <= pcg::BK1_MAX ? 1 : 0; }
+
+/* the one-launch bucket sort over raw keys that exist already (pos_keys' scratch half) -> pos_keys' first half */
+int pcg_pos_sort_raw(const pcg_graph_desc *g, uint64_t *keys, uint32_t *status, void *stream) {
+    if (!g || !keys || !pcg_pos_sort_one_launch(g->n_pos)) return PCG_E_ARG;
+    const int64_t cap = pcg::sort_capacity(g->n_pos);
+    return pcg::launch_bk_onepass(keys + cap, g->n_pos, keys, (int)cap, status, static_cast<hipStream_t>(stream));
+}
 
 int64_t pcg_pos_sort_capacity(int32_t n_pos) {
     if (n_pos < 0) return PCG_E_ARG;

@@ -795,6 +795,8 @@ class FusedPCGNN:
         if st & _lib.PCG_ST_SYNC_TIMEOUT:
             what.append("a bounded in-kernel wait ran out: the select kernel's wait for its own train-pos sort, or a plan "
                         "workgroup's wait for its predecessors' totals")
+        if st & _lib.PCG_ST_SORT_OVERFLOW:
+            what.append("the one-launch sort of the train positives met a bucket of more than 4096 keys: minority picks may be wrong")
         raise _lib.PcgnnLibraryError("; ".join(what) or f"device status {st}")
 
     def last_loss(self) -> torch.Tensor:

@@ -473,6 +473,42 @@ def test_pos_sort_sizes(P, n_pos):
     assert np.all(keys[n_pos:cap] == np.uint64(0xFFFFFFFFFFFFFFFF))
 
 
+@pytest.mark.parametrize("n_pos", [16385, 40000, 65537, 131072])
+def test_pos_sort_one_launch(P, n_pos):
+    """The one-launch bucket sort over raw keys (16384 < n_pos <= 131072: what a training step's gather launch is followed by):
+    the same order as pcg_pos_sort's four launches, all-ones padding, nothing reported - on scores with many duplicates (the keys
+    stay unique through their positions), on a constant score (every key in a single run of equal scores: the splitters fall
+    inside it) and on a sorted-descending one."""
+    from pcgnn_amd import _lib
+    ops, lib = P.ops, _lib.load()
+    n = n_pos + 1000
+    rs = np.random.RandomState(n_pos)
+    X = np.zeros((n, 4), np.float32)
+    indptr = np.arange(n + 1, dtype=np.int64)
+    g = P.DeviceGraph(X, [(indptr, np.arange(n, dtype=np.int32))], rs.choice(n, size=n_pos, replace=False).tolist(), dev())
+    assert lib.pcg_pos_sort_one_launch(n_pos) == 1 and lib.pcg_pos_sort_one_launch(16384) == 0
+    cap = int(lib.pcg_pos_sort_capacity(n_pos)) // 2
+    status = torch.zeros(1, dtype=torch.int32, device=dev())
+    for kind in ("duplicates", "constant", "descending"):
+        if kind == "duplicates":
+            s0h = np.round(rs.randn(n).astype(np.float32), 2)
+            s0h[rs.randint(0, n, 50)] = -0.0
+        elif kind == "constant":
+            s0h = np.full(n, 0.25, np.float32)
+        else:
+            s0h = -np.arange(n, dtype=np.float32)
+        s0 = torch.from_numpy(s0h).cuda()
+        want = ops.pos_sort(g, s0).clone()                       # the four-launch sort; its scratch half holds other things
+        keys = torch.zeros_like(want)
+        # raw keys: whatever order the sorted ones are shuffled into (unique 64-bit keys: the sort's input is just that)
+        perm = torch.from_numpy(rs.permutation(n_pos)).cuda()
+        keys[cap:cap + n_pos] = want[:n_pos][perm]
+        _lib.check(lib.pcg_pos_sort_raw(g.desc_ref(), ops._p(keys), ops._p(status), ops._stream(dev())), "pcg_pos_sort_raw")
+        torch.cuda.synchronize()
+        assert torch.equal(keys[:cap], want[:cap]), kind
+        assert int(status.item()) == 0, kind
+
+
 # ---------------------------------------------------------------------------
 # fused dense step + Adam (hand-written MFMA kernels) and the hipGraph-captured step
 # ---------------------------------------------------------------------------
