@@ -50,7 +50,7 @@ enum {
     PCG_ST_SEL_OVERFLOW = 1,  /* sel_indices capacity too small; nothing was written past it */
     PCG_ST_LIST_ID_RANGE = 2, /* a selection-list entry named no row of the table handed to the gather; it was skipped (a hole) */
     PCG_ST_SYNC_TIMEOUT = 4,  /* a bounded in-kernel wait (the select kernel's wait for its own train-pos sort) ran out */
-    PCG_ST_SORT_OVERFLOW = 8  /* the one-launch bucket sort of the train positives met a bucket of more than 4096 keys (thirteen times
+    PCG_ST_SORT_OVERFLOW = 8  /* the one-launch bucket sort of the train positives met a bucket of more than 4096 keys (eight times
                                  the mean): its surplus keys were dropped - minority picks of that step may be wrong */
 };
 

@@ -12,6 +12,8 @@ constexpr int TB_CAP = 64;       // rows of <= 64: one wave, one key per lane, r
 constexpr int T1_CAP = 512;      // rows of <= 512: one wave, up to 8 keys per lane in registers, 256-bin LDS histogram rounds
 constexpr int T4_CAP = 4096;     // workgroup rows are queued in two classes (> 4096 first) so that the longest start first
 constexpr int WG_KEYCAP = 10240; // workgroup rows up to this length keep their distance keys in LDS; longer ones recompute them
+constexpr int BIG_KEYCAP = 16384; // ... on hub-heavy graphs (maximum degree beyond WG_KEYCAP) select_rows runs two workgroups per CU with this
+                                  // many keys of LDS each, so that rows up to it need no launch of their own
 constexpr int LONG_NW = 16;       // waves per workgroup of select_long_rows (rows beyond WG_KEYCAP: a launch of their own, one workgroup per CU)
 constexpr int LONG_KEYCAP = 32768; // ... which keep the keys of rows up to this length in LDS (128 KB of the CU's 160); longer still: global scratch
 constexpr int SEL_NW = 8;        // waves per select workgroup
@@ -172,6 +174,7 @@ struct ChooseArgs {
     uint64_t *sort_out;
     uint32_t *sort_done, *rank_acc, *group_ticket;
     int32_t n_sort, sort_cap, sort_slices, sort_slice_len;
+    int32_t key_cap;           // LDS words of a select_rows workgroup's key area (WG_KEYCAP or BIG_KEYCAP: launch_select_rows sets it)
     uint32_t *pending_clear;   // device word the select kernel zeroes ("the deferred Adam update has been applied"), or null
     ClfStep clf;               // the label classifier's step for this batch (one workgroup), or clf.clf_next == null
     // the previous step's weight gradients + Adam (wgrad.h) by the first n_wg_units row workgroups of the select launch, two 16 x 16

@@ -1317,7 +1317,7 @@ template <int CLF>
 __global__ void __launch_bounds__(SEL_NW *PCG_WAVE) __attribute__((amdgpu_waves_per_eu(6, 8))) select_rows(const ChooseArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t *lds = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *hist = lds + WG_KEYCAP;
+    uint32_t *hist = lds + a.key_cap;
     uint32_t *cand = hist + HIST_WG;
     int *red = reinterpret_cast<int *>(cand + PCG_WAVE);                   // 2 * SEL_NW + 2 + 4 ints, then 2 claim slots
     int *claim = red + 2 * SEL_NW + 6;
@@ -1411,7 +1411,7 @@ __global__ void __launch_bounds__(SEL_NW *PCG_WAVE) __attribute__((amdgpu_waves_
             // (a workgroup row is the launch's long pole and shares its CU with two workgroups of short rows: it goes first)
             static_assert(true, "");
             if (PCG_WG_ROW_PRIO) __builtin_amdgcn_s_setprio(PCG_WG_ROW_PRIO);
-            if (d <= WG_KEYCAP) select_wg_row<true>(a, row, lds, hist, cand, red, tid, keys_ok, sortw);      // (longer rows: select_long_rows)
+            if (d <= a.key_cap) select_wg_row<true>(a, row, lds, hist, cand, red, tid, keys_ok, sortw, nullptr, a.key_cap);      // (longer rows: select_long_rows)
             if (PCG_WG_ROW_PRIO) __builtin_amdgcn_s_setprio(0);
         } else {
             const int j = wave < bs ? (u - n_wg) * bs + wave : n_items;
@@ -1469,7 +1469,7 @@ __global__ void __launch_bounds__(LONG_NW *PCG_WAVE) select_long_rows(const Choo
         const int row = __builtin_amdgcn_readfirstlane(a.w.q16[u]);
         const int d = a.w.recs[row].d;                                      // (workgroup-uniform)
         if (d > LONG_KEYCAP) select_wg_row<false, LONG_NW>(a, row, lds, hist, cand, red, (int)threadIdx.x, keys_ok, nullptr, gk, LONG_KEYCAP);
-        else if (d > WG_KEYCAP) select_wg_row<true, LONG_NW>(a, row, lds, hist, cand, red, (int)threadIdx.x, keys_ok, nullptr, nullptr, LONG_KEYCAP);
+        else if (d > a.key_cap) select_wg_row<true, LONG_NW>(a, row, lds, hist, cand, red, (int)threadIdx.x, keys_ok, nullptr, nullptr, LONG_KEYCAP);
         __syncthreads();
         if (leader) claim[slot] = (int)gridDim.x + (int)atomicAdd(cursor, 1u);
         __syncthreads();
@@ -1485,8 +1485,8 @@ __global__ void __launch_bounds__(LONG_NW *PCG_WAVE) select_long_rows(const Choo
     }
 }
 
-static size_t select_smem_bytes() {
-    return sizeof(uint32_t) * (WG_KEYCAP + HIST_WG + PCG_WAVE) + sizeof(int) * (2 * SEL_NW + 8) + sizeof(void *) * PCG_MAX_REL +   // (claim[2] = red[22..23])
+static size_t select_smem_bytes(int key_cap) {
+    return sizeof(uint32_t) * (key_cap + HIST_WG + PCG_WAVE) + sizeof(int) * (2 * SEL_NW + 8) + sizeof(void *) * PCG_MAX_REL +   // (claim[2] = red[22..23])
            sizeof(int) * (4 + KIDX_MAX);                                                                                            // sortw
 }
 
@@ -1494,7 +1494,7 @@ int launch_select_rows(const ChooseArgs &a, hipStream_t st) {
     static_assert(HIST_WG == 4 * SEL_NW * PCG_WAVE, "one uint4 of bins per thread");
     static_assert(HIST_W == 4 * PCG_WAVE, "one uint4 of bins per lane");
     static_assert(WAVE_AREA >= HIST_W + T1_CAP + PCG_WAVE, "a wave's LDS area: histogram | kept ids | candidates");
-    static_assert(((WG_KEYCAP / SEL_NW + PCG_WAVE - 1) / PCG_WAVE) <= 32, "pass A keeps one bit per iteration in a uint32");
+    static_assert(((BIG_KEYCAP / SEL_NW + PCG_WAVE - 1) / PCG_WAVE) <= 32, "pass A keeps one bit per iteration in a uint32");
     static_assert((2 * SEL_NW + 8) % 2 == 0, "the pointer table behind red stays 8-byte aligned");
     static_assert(SORT_TILE * 2 <= WG_KEYCAP && SEL_NW * PCG_WAVE <= HIST_WG, "the in-kernel sort's tile and partial counts fit the row paths' LDS");
     static int blocks = 0;
@@ -1504,7 +1504,31 @@ int launch_select_rows(const ChooseArgs &a, hipStream_t st) {
         blocks = (v >= SEL_SHARDS && v <= SEL_BLOCKS && v % SEL_SHARDS == 0) ? v : SEL_BLOCKS;
     }
     ChooseArgs as = a;
-    const int row_blocks = blocks - (a.clf.clf_next ? a.clf.n_wg : 0);      // (training: one of the workgroups steps the label classifier)
+    // Option PCG_SEL_BIG=1 (off: measured slower): on hub-heavy graphs (rows beyond WG_KEYCAP exist) two workgroups per CU with
+    // BIG_KEYCAP keys of LDS each instead of three with WG_KEYCAP - rows up to 16384 neighbours are then done HERE, by whichever
+    // workgroup pulls them, and select_long_rows only sees longer rows still.  10 M nodes / 200 M edges, batch 4096: select_rows
+    // 59.6 -> 84.0 us (a third fewer waves for the short rows), select_long_rows 60.4 -> 57.2 (its longest rows are beyond 16384
+    // as well): 141 vs 120 us (profiles/r04/x_select_big_lds_powerlaw_10m_kernel_stats.csv).
+    static int big_knob = -1;
+    if (big_knob < 0) {
+        const char *e = getenv("PCG_SEL_BIG");
+        big_knob = e ? atoi(e) : 0;
+    }
+    const bool big = big_knob && a.g.max_degree > WG_KEYCAP;
+    as.key_cap = big ? BIG_KEYCAP : WG_KEYCAP;
+    const int nblk = big ? (blocks > 512 ? 512 : blocks) : blocks;
+    const size_t smem = select_smem_bytes(as.key_cap);
+    if (big) {
+        static bool attr_big = false;
+        if (!attr_big) {
+            const void *ks[3] = {reinterpret_cast<const void *>(select_rows<0>), reinterpret_cast<const void *>(select_rows<1>),
+                                 reinterpret_cast<const void *>(select_rows<2>)};
+            for (const void *k : ks)
+                if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return PCG_E_LAUNCH;
+            attr_big = true;
+        }
+    }
+    const int row_blocks = nblk - (a.clf.clf_next ? a.clf.n_wg : 0);      // (training: one of the workgroups steps the label classifier)
     if (a.n_sort > 0) {                      // how the sort is shared: slices per key group, keys per slice (>= 128)
         if (a.n_sort > row_blocks) return PCG_E_ARG;
         // (PCG_SORT_SLICES: tuning knob.  More slices = fewer compares per workgroup, but accumulator atomics and a ticket hop,
@@ -1521,11 +1545,11 @@ int launch_select_rows(const ChooseArgs &a, hipStream_t st) {
         as.sort_slices = slices < 1 ? 1 : slices;
         as.sort_slice_len = (a.g.n_pos + as.sort_slices - 1) / as.sort_slices;
     }
-    if (a.clf.clf_next && a.g.feat_stride > 256) hipLaunchKernelGGL(select_rows<2>, dim3(blocks), dim3(SEL_NW * PCG_WAVE), select_smem_bytes(), st, as);
-    else if (a.clf.clf_next) hipLaunchKernelGGL(select_rows<1>, dim3(blocks), dim3(SEL_NW * PCG_WAVE), select_smem_bytes(), st, as);
-    else hipLaunchKernelGGL(select_rows<0>, dim3(blocks), dim3(SEL_NW * PCG_WAVE), select_smem_bytes(), st, as);
+    if (a.clf.clf_next && a.g.feat_stride > 256) hipLaunchKernelGGL(select_rows<2>, dim3(nblk), dim3(SEL_NW * PCG_WAVE), smem, st, as);
+    else if (a.clf.clf_next) hipLaunchKernelGGL(select_rows<1>, dim3(nblk), dim3(SEL_NW * PCG_WAVE), smem, st, as);
+    else hipLaunchKernelGGL(select_rows<0>, dim3(nblk), dim3(SEL_NW * PCG_WAVE), smem, st, as);
     PCG_LAUNCH_CHECK();
-    if (a.g.max_degree > WG_KEYCAP) {        // rows too long for the LDS keys: their own launch (hub-heavy graphs only)
+    if (a.g.max_degree > as.key_cap) {       // rows too long for the LDS keys: their own launch (hub-heavy graphs only)
         const int64_t per_wg = a.g.max_degree;
         int64_t nb = LONG_BLOCKS;                // (rows beyond LONG_KEYCAP keep their keys in scratch: as many workgroups as it holds)
         if (a.g.max_degree > LONG_KEYCAP) {
@@ -1542,7 +1566,7 @@ int launch_select_rows(const ChooseArgs &a, hipStream_t st) {
                 return PCG_E_LAUNCH;
             attr_done = true;
         }
-        ChooseArgs al = a;                   // (the keys are sorted by now: nothing to sort, nothing to wait for)
+        ChooseArgs al = as;                  // (the keys are sorted by now: nothing to sort, nothing to wait for)
         al.n_sort = 0;
         al.pending_clear = nullptr;
         hipLaunchKernelGGL(select_long_rows, dim3((int)nb), dim3(LONG_NW * PCG_WAVE), long_smem, st, al, per_wg);

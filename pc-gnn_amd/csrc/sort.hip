@@ -207,14 +207,15 @@ __global__ void __launch_bounds__(RANK_WAVES *PCG_WAVE) bk_sort(const BucketArgs
 //      that count is the bucket's offset in the sorted order - and collects the keys of its own range in LDS;
 //   3. ranks the collected keys against each other and stores every key at offset + rank.
 // n_pos keys x n_buckets workgroups of streaming (40 K keys, 128 buckets: 41 MB out of L2) instead of three more launches and
-// their hand-offs.  A bucket holds ~n_pos / n_buckets ~ 300 keys with eight samples per bucket; BK_TILE (4096) of them fit - more
-// than thirteen times the mean: a bucket over that is reported (PCG_ST_SORT_OVERFLOW, its surplus keys dropped), never silent.
+// their hand-offs.  A bucket holds ~n_pos / n_buckets ~ 300 - 512 keys with four samples per bucket; BK1_TILE (4096) of them fit -
+// eight to thirteen times the mean: a bucket over that is reported (PCG_ST_SORT_OVERFLOW, its surplus keys dropped), never silent.
 constexpr int BK1_MAX = 131072;
+constexpr int BK1_TILE = 4096;        // keys of a bucket the workgroup holds in LDS (32 KB)
 __global__ void __launch_bounds__(SORT_THREADS) bk_onepass(const uint64_t *__restrict__ raw, int n_pos, int n_buckets, int n_sample,
                                                            uint64_t *__restrict__ keys, int cap, uint32_t *status) {
-    __shared__ __align__(16) uint64_t sh[BK_TILE];
-    __shared__ __align__(16) uint64_t samp[SORT_THREADS];
-    __shared__ uint64_t sorted[SORT_THREADS];
+    extern __shared__ __align__(16) unsigned char bk1_smem[];
+    uint64_t *sh = reinterpret_cast<uint64_t *>(bk1_smem);     // [BK1_TILE] the bucket's keys
+    uint64_t *samp = sh + BK1_TILE;                            // [SORT_THREADS] the sample
     __shared__ int red[SORT_THREADS / PCG_WAVE];
     __shared__ int n_in;
     const int t = threadIdx.x, b = blockIdx.x;
@@ -231,25 +232,21 @@ __global__ void __launch_bounds__(SORT_THREADS) bk_onepass(const uint64_t *__res
         const int i = t + u * SORT_THREADS;
         kv[u] = raw[i < n_pos ? i : n_pos - 1];
     }
-    // pad (n_sample < 1024): all-ones keys rank behind every real one
+    // the sample: n_sample (a power of two <= 1024) evenly spaced raw keys, sorted in LDS by a bitonic network (45 stages for 512
+    // samples, ~0.2 us each - sixteen waves meet at a barrier per stage; ranking every sample against every other cost more in
+    // 64-bit compares, one wave running the network alone more in LDS round trips: both measured)
+    uint64_t *sorted = samp;
     samp[t] = t < n_sample ? raw[(int)(((int64_t)t * n_pos) / n_sample)] : ~0ull;
     if (t == 0) n_in = 0;
     __syncthreads();
-    {
-        const uint64_t mine = samp[t];
-        int rank = 0;
-        const uint4 *s4 = reinterpret_cast<const uint4 *>(samp);
-        const int ns8 = (n_sample + 7) & ~7;
-        for (int j = 0; j < ns8; j += 8) {
-            const uint4 q0 = s4[(j >> 1) + 0], q1 = s4[(j >> 1) + 1], q2 = s4[(j >> 1) + 2], q3 = s4[(j >> 1) + 3];
-            rank += ((((uint64_t)q0.y << 32) | q0.x) < mine) + ((((uint64_t)q0.w << 32) | q0.z) < mine) +
-                    ((((uint64_t)q1.y << 32) | q1.x) < mine) + ((((uint64_t)q1.w << 32) | q1.z) < mine) +
-                    ((((uint64_t)q2.y << 32) | q2.x) < mine) + ((((uint64_t)q2.w << 32) | q2.z) < mine) +
-                    ((((uint64_t)q3.y << 32) | q3.x) < mine) + ((((uint64_t)q3.w << 32) | q3.z) < mine);
+    for (int k = 2; k <= n_sample; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (t < n_sample / 2) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));      // (j is a power of two)
+                cmp_swap(samp[i], samp[i + j], (i & k) == 0);
+            }
+            __syncthreads();
         }
-        if (t < n_sample) sorted[rank] = mine;                 // (sample positions are distinct, so the keys - and the ranks - are)
-    }
-    __syncthreads();
     const int per = n_sample / n_buckets;
     const uint64_t lo = b == 0 ? 0ull : sorted[b * per], hi = b == n_buckets - 1 ? ~0ull : sorted[(b + 1) * per];
     // ---- the stream: keys below lo are counted, keys in [lo, hi) collected ----
@@ -268,7 +265,7 @@ __global__ void __launch_bounds__(SORT_THREADS) bk_onepass(const uint64_t *__res
                 below += kv[u] < lo;
                 if (kv[u] >= lo && kv[u] < hi) {
                     const int at = atomicAdd(&n_in, 1);
-                    if (at < BK_TILE) sh[at] = kv[u];
+                    if (at < BK1_TILE) sh[at] = kv[u];
                 }
             }
         }
@@ -282,28 +279,28 @@ __global__ void __launch_bounds__(SORT_THREADS) bk_onepass(const uint64_t *__res
 #pragma unroll
     for (int w = 0; w < SORT_THREADS / PCG_WAVE; ++w) off += red[w];
     int n = n_in;
-    if (n > BK_TILE) {
+    if (n > BK1_TILE) {
         if (t == 0 && status) atomicOr(status, (uint32_t)PCG_ST_SORT_OVERFLOW);
-        n = BK_TILE;
+        n = BK1_TILE;
     }
-    // pad the collected keys to a multiple of eight (all-ones: never smaller than anybody's)
-    const int n8 = (n + 7) & ~7;
-    if (t < n8 - n) sh[n + t] = ~0ull;
+    // ---- the bucket's keys, sorted in LDS (bitonic over the next power of two, padded with all-ones keys), stored at offset + i.
+    //      (Measured alternatives, 40 K keys: every key ranked against every other of its bucket - by one thread a key, or by all
+    //      threads over slices with LDS atomics - 36 / 44 us a launch against this network's 30; scripts/sort_probe.py) ----
+    int np2 = 64;
+    while (np2 < n) np2 <<= 1;
+    for (int i = n + t; i < np2; i += SORT_THREADS) sh[i] = ~0ull;
     __syncthreads();
-    // ---- rank inside the bucket (order of collection is whatever the atomics gave: the ranks do not depend on it) ----
-    const uint4 *sh4 = reinterpret_cast<const uint4 *>(sh);
-    for (int i = t; i < n; i += SORT_THREADS) {
-        const uint64_t mine = sh[i];
-        int rank = 0;
-        for (int j = 0; j < n8; j += 8) {
-            const uint4 q0 = sh4[(j >> 1) + 0], q1 = sh4[(j >> 1) + 1], q2 = sh4[(j >> 1) + 2], q3 = sh4[(j >> 1) + 3];
-            rank += ((((uint64_t)q0.y << 32) | q0.x) < mine) + ((((uint64_t)q0.w << 32) | q0.z) < mine) +
-                    ((((uint64_t)q1.y << 32) | q1.x) < mine) + ((((uint64_t)q1.w << 32) | q1.z) < mine) +
-                    ((((uint64_t)q2.y << 32) | q2.x) < mine) + ((((uint64_t)q2.w << 32) | q2.z) < mine) +
-                    ((((uint64_t)q3.y << 32) | q3.x) < mine) + ((((uint64_t)q3.w << 32) | q3.z) < mine);
+    for (int k = 2; k <= np2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int p = t; p < np2 / 2; p += SORT_THREADS) {
+                const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                cmp_swap(sh[i], sh[i + j], (i & k) == 0);
+            }
+            __syncthreads();
         }
-        const int dst = off + rank;
-        if (dst < n_pos) keys[dst] = mine;                     // (a counter never indexes unchecked)
+    for (int i = t; i < n; i += SORT_THREADS) {
+        const int dst = off + i;
+        if (dst < n_pos) keys[dst] = sh[i];                    // (a counter never indexes unchecked)
     }
 }
 
@@ -312,13 +309,21 @@ static void bk1_geometry(int n_pos, int &n_buckets, int &n_sample) {
     int nb = 32;
     while (nb < 256 && (int64_t)nb * 512 < n_pos) nb <<= 1;    // ~300 - 512 keys per bucket
     n_buckets = nb;
-    const int ns = nb * 8;
-    n_sample = ns > SORT_THREADS ? SORT_THREADS : ns;          // (a multiple of n_buckets: both are powers of two)
+    // four samples a bucket: a bucket's size is then ~Gamma(4) around its mean - BK1_TILE is eight to thirteen times the mean, a
+    // bucket beyond it a < 1e-10 event (and reported)
+    n_sample = nb * 4;                                         // (<= 1024: a multiple of n_buckets, both powers of two)
 }
 int launch_bk_onepass(const uint64_t *raw, int n_pos, uint64_t *keys, int cap, uint32_t *status, hipStream_t st) {
     int nb, ns;
     bk1_geometry(n_pos, nb, ns);
-    hipLaunchKernelGGL(bk_onepass, dim3(nb + 8), dim3(SORT_THREADS), 0, st, raw, n_pos, nb, ns, keys, cap, status);
+    const size_t smem = sizeof(uint64_t) * (BK1_TILE + SORT_THREADS);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(bk_onepass), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return PCG_E_LAUNCH;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(bk_onepass, dim3(nb + 8), dim3(SORT_THREADS), smem, st, raw, n_pos, nb, ns, keys, cap, status);
     PCG_LAUNCH_CHECK();
     return PCG_OK;
 }

@@ -25,3 +25,23 @@ for P in (8000, 20000, 40000, 100000):
     k = keys.cpu().numpy().view(np.uint64)[:P]
     assert np.all(k[1:] > k[:-1])
     print(f"P {P}: {e0.elapsed_time(e1) / 50 * 1e3:.1f} us")
+    # the one-launch bucket sort over raw keys (16384 < P <= 131072)
+    from pcgnn_amd import _lib
+    lib = _lib.load()
+    if lib.pcg_pos_sort_one_launch(P):
+        cap = int(lib.pcg_pos_sort_capacity(P)) // 2
+        want = keys.clone()
+        k2 = torch.zeros_like(want)
+        k2[cap:cap + P] = want[:P][torch.from_numpy(rs.permutation(P)).to(dev)]
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        run = lambda: _lib.check(lib.pcg_pos_sort_raw(g.desc_ref(), ops._p(k2), ops._p(status), ops._stream(dev)), "raw")
+        for _ in range(5):
+            run()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(50):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        assert torch.equal(k2[:cap], want[:cap]) and int(status.item()) == 0
+        print(f"P {P}: one launch {e0.elapsed_time(e1) / 50 * 1e3:.1f} us")
