@@ -355,14 +355,24 @@ def _run_partitioned(args, w, B, d, dev, dist, world, rank, W, gloo):
             ab.append(algorithmic_bytes(g, ids_h, cnt.view(g.R, -1).cpu().numpy()) + U * (4 * g.feat_dim + 4))
         avg_ms = float(np.mean(ms)) if ms else float("nan")
         achieved = float(np.mean(ab)) / (avg_ms * 1e-3) / 1e9 if ms else float("nan")
+        # HBM-side bytes of the step graph's kernels from two PMC passes of this command at world size 1 (profiles/pmc_traffic.json)
+        traffic, traffic_commit = None, None
+        try:
+            tkey = f"{args.workload}_partitioned_w{world}" if (B == (args.batch_size or B) and args.emb == 64) else None
+            entry = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(tkey, {}) if tkey else {}
+            traffic, traffic_commit = entry.get("choose_agg_bytes_per_launch"), entry.get("commit")
+        except Exception:
+            traffic, traffic_commit = None, None
         roofline = {"bound": "hbm", "kernel": "the step graph of rank 0: front (Adam from the all-reduced gradient || train-pos keys || score "
                                               "pass over owned + train-pos + halo rows), select_rows (sorts the keys), gather_chunks_dist "
                                               "(translates node ids to table rows as it reads the lists), dense_step (transposed activations, "
                                               "no slabs), wgrad (weight-gradient GEMMs over the batch)"
                                               + (", the gradient all-reduce (captured in the graph)" if d.collectives_in_graph else "")
                                               + ": one launch per step; bytes = select + gather + U x F scored rows (U = the batch's unique nodes)",
-                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                    "traffic_note": "no PMC pass of the partitioned step has been collected (profiles/): null",
+                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "traffic_note": (f"profiles/pmc_traffic.json: two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of the world-size-1 step graph's "
+                                     f"kernels at commit {traffic_commit}") if traffic is not None else
+                                    "no PMC pass of this partitioned configuration has been collected (profiles/): null",
                     "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": float(np.mean(ab)) if ab else None,
                     "launches_timed": len(ms)}
         out = {

@@ -20,6 +20,11 @@ CALL_KERNELS = ("select_rows", "select_long_rows", "gather_train_kernel", "gathe
 # 16 B per lane: FETCH_SIZE x 2.  (gather_train_kernel's Adam workgroups read the gradient slabs 4 B per lane - at most
 # n_tiles x n_params x 4 B per launch, 6.9 MB on the YelpChi-like batch: doubled with the rest, so that entry is an upper bound)
 WIDE_READERS = ("gather_train_kernel", "gather_chunks")
+# PCG_PMC_KERNELS=step: the partitioned path's whole step graph instead (its roofline line is about that one launch): the front
+# (score pass: float4 per lane), select, the translating gather (float4), the dense kernel, the weight-gradient GEMMs (float4)
+if os.environ.get("PCG_PMC_KERNELS") == "step":
+    CALL_KERNELS = ("front_dist_kernel", "select_rows", "select_long_rows", "gather_chunks_dist", "dense_step_kernel", "wgrad_adam_kernel")
+    WIDE_READERS = ("front_dist_kernel", "gather_chunks_dist", "wgrad_adam_kernel")
 
 
 def per_kernel(path, counter):
