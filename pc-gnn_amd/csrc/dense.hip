@@ -760,11 +760,22 @@ static bool dense_wlds(int F, int E, int R) {
 static unsigned long long *g_dense_stamps = nullptr;
 
 }  // namespace pcg
-/* 1: pcg_train_dense(adam_clf = 3, sort_keys) for a batch of B rows also sorts the next step's train-pos keys (n_pos of them) -
- * its tiles' workgroups and the sort's together leave no CU with two of them, and the rank sort fits (host helper) */
+/* 1: pcg_train_dense(adam_clf = 3, sort_keys) for a batch of B rows also sorts the next step's train-pos keys (n_pos of them: the
+ * rank sort's sizes) - when its tiles' workgroups and the sort's together leave no CU with two of them (up to ~3000 rows): the
+ * sort is then free.  (PCG_PRESORT_MAX_TILES=n also allows batches of up to n tiles, the sorting workgroups running behind the
+ * tiles'.  Measured at 256 tiles: power-law 2 M / 8000 keys - where the in-kernel sort publishes 13 us into the select launch and
+ * every positive row waits for it - the call 123.3 -> 117.3 us but the step 136.5 -> 142.8: 125 rank-sorting workgroups behind the
+ * tiles cost the dense launch more than the select launch gains; emb 128 / 2670 keys: 94.1 -> 93.5.  Off.)  Host helper. */
 extern "C" int32_t pcg_dense_sorts_keys(int32_t B, int32_t n_pos) {
     if (B < 1 || n_pos < 1 || n_pos > pcg::RANK_MAX) return 0;
-    return (B + pcg::TB - 1) / pcg::TB + (n_pos + PCG_WAVE - 1) / PCG_WAVE <= 256 ? 1 : 0;
+    static int max_tiles = -1;
+    if (max_tiles < 0) {
+        const char *e = getenv("PCG_PRESORT_MAX_TILES");
+        max_tiles = e ? atoi(e) : 0;
+    }
+    const int tiles = (B + pcg::TB - 1) / pcg::TB;
+    if (tiles + (n_pos + PCG_WAVE - 1) / PCG_WAVE <= 256) return 1;
+    return tiles <= max_tiles ? 1 : 0;
 }
 namespace pcg {
 
