@@ -1538,7 +1538,7 @@ int launch_select_rows(const ChooseArgs &a, hipStream_t st) {
             const char *e = getenv("PCG_SORT_SLICES");
             knob = e ? atoi(e) : 0;
         }
-        int slices = knob > 0 ? knob : 4;
+        int slices = knob > 0 ? knob : 3;   // (measured, batch 4096: power-law 2 M / 8000 keys 1: 142.1, 2: 140.2, 3: 133.3, 4: 136.8, 6: 143.0 us per step; emb 128 / 2670 keys 2: 93.4, 3: 93.5, 4: 94.1, 6: 95.4)
         if (slices > row_blocks / a.n_sort) slices = row_blocks / a.n_sort;
         const int most = (a.g.n_pos + 127) / 128;
         slices = slices > most ? most : slices;
