@@ -148,3 +148,69 @@ def test_ranks_match_single_gpu(world):
         p.join(timeout=60)
     for rank, msg in res:
         assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def _worker_w1(port, q):
+    """world size 1 through RCCL: the captured collectives and the whole-window graph against the step-by-step path"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    engines = []
+    try:
+        from pcgnn_amd import synth
+        from pcgnn_amd.dist import DistributedPCGNN
+        w = synth.make_workload("t", 40000, 32, (8000, 60000, 200000), 0.15, seed=5, skew=1.5)
+        B, W = 256, 4
+        cfg = dict(emb_size=64, rho=0.5, alpha=2.0, lr=0.01, weight_decay=0.001, batch_size=B, seed=11)
+        os.environ["PCG_DIST_WINDOW_GRAPH"] = "1"
+        a = DistributedPCGNN(w, cfg, dev, window=W)            # captured all-reduce; a window = one graph launch
+        os.environ["PCG_DIST_WINDOW_GRAPH"] = "0"
+        b = DistributedPCGNN(w, cfg, dev, window=W)            # captured all-reduce; one graph per step
+        os.environ["PCG_DIST_GRAPH_COLLECTIVES"] = "0"
+        c = DistributedPCGNN(w, cfg, dev, window=W)            # eager all-reduce behind every step's graph
+        del os.environ["PCG_DIST_GRAPH_COLLECTIVES"], os.environ["PCG_DIST_WINDOW_GRAPH"]
+        engines = [a, b, c]
+        assert a.collectives_in_graph and a.window_graphs and b.collectives_in_graph and not b.window_graphs
+        assert not c.collectives_in_graph
+        assert torch.equal(a.theta, b.theta) and torch.equal(a.theta, c.theta)
+        for d in engines:
+            for k in range(4):                                  # the first window of a size runs step by step, the others replay
+                ids = d.pick_epoch(W * B, k)
+                d.train_window(ids, d.labels_of(ids))
+            ids = d.pick_epoch(2 * B + 100, 9)                  # a shorter window with a partial last batch: another graph
+            for _ in range(2):
+                d.train_window(ids, d.labels_of(ids))
+            d.flush()
+            d.check()
+        torch.cuda.synchronize()
+        assert ("window", W * B) in a._graphs and ("window", 2 * B + 100) in a._graphs
+        for name in ("theta", "m", "v", "step_counter", "grad"):
+            assert torch.equal(getattr(a, name), getattr(b, name)), name + " (window graph vs one graph per step)"
+            assert torch.equal(getattr(a, name), getattr(c, name)), name + " (captured vs eager all-reduce)"
+        assert not torch.isnan(a.theta).any() and int(a.step_counter.item()) == 4 * W + 2 * 3
+        q.put((0, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((0, traceback.format_exc()))
+    finally:
+        for d in engines:
+            d.close()                                           # (captured collectives go before their communicator does)
+        dist.destroy_process_group()
+
+
+def test_window_graph_and_captured_collectives_world_size_1():
+    """RCCL at world size 1 (what a one-GPU box can run): the step's all-reduce captured inside its hipGraph, and a whole window -
+    halo exchange, plans, steps, all-reduces - as ONE graph launch, leave bit for bit what one graph per step + an eager all-reduce
+    leave; windows of two sizes (the second with a partial last batch)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_w1, args=(_free_port(), q))
+    p.start()
+    rank, msg = q.get(timeout=600)
+    p.join(timeout=120)
+    if p.is_alive():        # (a teardown that does not return must not hang the test run)
+        p.kill()
+        raise AssertionError("the worker did not exit after its result: " + msg)
+    assert msg == "ok", msg
