@@ -358,7 +358,8 @@ def _run_partitioned(args, w, B, d, dev, dist, world, rank, W, gloo):
         # HBM-side bytes of the step graph's kernels from two PMC passes of this command at world size 1 (profiles/pmc_traffic.json)
         traffic, traffic_commit = None, None
         try:
-            tkey = f"{args.workload}_partitioned_w{world}" if (B == (args.batch_size or B) and args.emb == 64) else None
+            # (collected at world size 1: a rank's step graph does the same work at any world size but for the share of remote rows)
+            tkey = f"{args.workload}_partitioned_w1" if (args.batch_size in (0, None, 1024) and args.emb == 64 and args.workload == "yelp") else None
             entry = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(tkey, {}) if tkey else {}
             traffic, traffic_commit = entry.get("choose_agg_bytes_per_launch"), entry.get("commit")
         except Exception:
@@ -371,7 +372,7 @@ def _run_partitioned(args, w, B, d, dev, dist, world, rank, W, gloo):
                                               + ": one launch per step; bytes = select + gather + U x F scored rows (U = the batch's unique nodes)",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "traffic_note": (f"profiles/pmc_traffic.json: two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of the world-size-1 step graph's "
-                                     f"kernels at commit {traffic_commit}") if traffic is not None else
+                                     f"kernels at commit {traffic_commit} (rank 0's step graph at world size 1)") if traffic is not None else
                                     "no PMC pass of this partitioned configuration has been collected (profiles/): null",
                     "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": float(np.mean(ab)) if ab else None,
                     "launches_timed": len(ms)}

@@ -460,7 +460,11 @@ class DistributedPCGNN:
         # eight floats, replayed and checked) and only used if every rank's probe passed; PCG_DIST_GRAPH_COLLECTIVES=0 turns it off.
         self.collectives_in_graph = self._probe_collective_capture()
         import os
-        self.window_graphs = self.collectives_in_graph and os.environ.get("PCG_DIST_WINDOW_GRAPH", "1") != "0"
+        # a whole window as ONE graph (train_window): on by default at world size 1 - where its all-to-alls are copies -, opt-in
+        # (PCG_DIST_WINDOW_GRAPH=1) beyond: there they are grouped send / receive pairs, a capture path that no one-GPU box can
+        # rehearse; the per-step graphs with the captured all-reduce (the probe above covers exactly that) are the default at N > 1
+        wg_env = os.environ.get("PCG_DIST_WINDOW_GRAPH")
+        self.window_graphs = self.collectives_in_graph and (wg_env == "1" or (wg_env is None and self.world == 1))
         if self.collectives_in_graph:
             # graphs holding captured collectives must be gone before the communicator is torn down (close()): also when the
             # process ends without the caller having said so
