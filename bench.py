@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=24)
     ap.add_argument("--workload", default="yelp", choices=["yelp", "amazon", "powerlaw"])
     ap.add_argument("--batch-size", type=int, default=None)
+    ap.add_argument("--relabel-by-degree", action="store_true", help="power-law workload: renumber the nodes by descending degree "
+                    "(diagnostic for the select kernel's score-gather over-fetch: DESIGN.md section 9)")
     ap.add_argument("--emb", type=int, default=64)
     ap.add_argument("--rho", type=float, default=0.5)
     ap.add_argument("--nodes", type=int, default=2_000_000, help="powerlaw only")
@@ -89,7 +91,10 @@ def make_workload(args):
         return synth.yelp_like(args.seed), 1024, 0.01, 0.001
     if args.workload == "amazon":
         return synth.amazon_like(args.seed), 256, 0.005, 0.0005
-    return synth.power_law(args.nodes, args.edges, args.seed), 4096, 0.01, 0.001
+    w = synth.power_law(args.nodes, args.edges, args.seed)
+    if args.relabel_by_degree:       # diagnostic: nodes renumbered by descending degree (synth.relabel_by_degree)
+        w = synth.relabel_by_degree(w)
+    return w, 4096, 0.01, 0.001
 
 
 def unique_rows(csr, n_nodes, ids_host):

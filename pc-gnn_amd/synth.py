@@ -119,6 +119,28 @@ def power_law(n, n_edges, seed=0, feat=32, pos_rate=0.01, split=(0.05, 0.25, 0.7
                          skew, max_share=max_share)
 
 
+def relabel_by_degree(w: Workload) -> Workload:
+    """The same graph with its nodes renumbered by DESCENDING total degree (new id 0 = the largest hub): popular nodes' scores and
+    feature rows become neighbours in memory.  A diagnostic (bench.py --relabel-by-degree: does the select kernel's line
+    over-fetch of 4-byte score gathers shrink?) - rows are ascending in the NEW ids, so ties at a cut break differently than in `w`."""
+    n = w.n
+    deg = sum(np.diff(ip) for ip, _ in w.csr)
+    perm = np.argsort(-deg, kind="stable")             # perm[new] = old
+    inv = np.empty(n, dtype=np.int64)
+    inv[perm] = np.arange(n, dtype=np.int64)
+    csr = []
+    for indptr, idx in w.csr:
+        rows_old = np.repeat(np.arange(n, dtype=np.int64), np.diff(indptr))
+        key = np.sort(inv[rows_old] * n + inv[idx])    # (row, column) in new ids, row-major, columns ascending
+        rows = key // n
+        ip = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(np.bincount(rows, minlength=n), out=ip[1:])
+        csr.append((ip, (key - rows * n).astype(np.int32)))
+    idx_train = np.sort(inv[w.idx_train])
+    return Workload(w.name + "-by-degree", w.X[perm], w.labels[perm], csr, w.homo_deg[perm], idx_train,
+                    [int(inv[v]) for v in w.train_pos], dict(w.meta, relabelled="descending total degree"))
+
+
 def pick_cum_weights(w: Workload) -> np.ndarray:
     """deg / LF, then the sequential fp64 running sum random.choices uses (utils.py:275-278)."""
     y = w.labels[w.idx_train]
