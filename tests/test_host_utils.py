@@ -219,3 +219,30 @@ def test_bench_algorithmic_bytes_counts_the_riders_once():
     assert bench.unique_rows(csr, 4, np.array([1])) == 1
     by_csr = bench.algorithmic_bytes(g, ids, counts, dict(csr=csr, n_nodes=4, n_pos=7, n_params=50))
     assert by_csr == bench.algorithmic_bytes(g, ids, counts, dict(table_rows=4, n_pos=7, n_params=50))
+
+
+def test_relabel_by_degree_is_the_same_graph():
+    """synth.relabel_by_degree (bench.py --relabel-by-degree, a diagnostic): the graph renumbered by descending total degree is
+    isomorphic to the original - same edges under the permutation, rows ascending in the new ids, features / labels / training
+    split carried along, the train positives in their original ORDER (it is the minority picks' tie-break)."""
+    from pcgnn_amd import synth
+    w = synth.power_law(3000, 30000, 1)
+    r = synth.relabel_by_degree(w)
+    deg_w = sum(np.diff(ip) for ip, _ in w.csr)
+    deg_r = sum(np.diff(ip) for ip, _ in r.csr)
+    assert np.all(np.diff(deg_r) <= 0) and sorted(deg_w.tolist()) == sorted(deg_r.tolist())
+    # recover the permutation from the features (distinct rows): new -> old
+    key = {tuple(np.round(row, 6)): i for i, row in enumerate(w.X)}
+    perm = np.array([key[tuple(np.round(row, 6))] for row in r.X])
+    assert sorted(perm.tolist()) == list(range(w.n))
+    inv = np.empty(w.n, dtype=np.int64)
+    inv[perm] = np.arange(w.n)
+    assert np.array_equal(r.labels, w.labels[perm]) and np.array_equal(r.homo_deg, w.homo_deg[perm])
+    assert np.array_equal(r.idx_train, np.sort(inv[w.idx_train]))
+    assert r.train_pos == [int(inv[v]) for v in w.train_pos]
+    for (ip_w, idx_w), (ip_r, idx_r) in zip(w.csr, r.csr):
+        for new in (0, 1, 17, w.n - 1):
+            row = idx_r[ip_r[new]:ip_r[new + 1]]
+            assert np.all(np.diff(row) > 0)
+            old = perm[new]
+            assert sorted(inv[idx_w[ip_w[old]:ip_w[old + 1]]].tolist()) == row.tolist()
