@@ -665,6 +665,11 @@ class DistributedPCGNN:
             step = lambda: self._seg_step(ids, lab, B, plan)
         step()                                     # warm-up: kernel attributes, plan slots (its head applies a waiting gradient: due anyway)
         self.opt_flag.zero_()                      # ... and the gradient the warm-up itself left behind is not one to apply
+        if self.collectives_in_graph and not getattr(self, "_ar_warm", False):
+            # an eager all-reduce of the gradient's size first: whatever the communicator sets up lazily for a message of this
+            # size (channels, staging buffers) is set up outside a capture, where allocating is allowed
+            dist.all_reduce(torch.zeros_like(self.grad), group=self.group)
+            self._ar_warm = True
         torch.cuda.synchronize(self.dev)           # no collective of ours is in flight while capturing
         gr = torch.cuda.CUDAGraph()
         # thread_local: RCCL's watchdog thread may query events while this thread captures
