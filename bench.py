@@ -65,7 +65,7 @@ def parse():
                     help="run the node-partitioned RCCL path even at world size 1 (rehearsal of the N>1 code)")
     ap.add_argument("--window", type=int, default=8, help="partitioned path: steps per halo prefetch (feature rows never change, "
                     "so the remote rows of a window's centres are fetched once)")
-    ap.add_argument("--epochs-per-launch", type=int, default=4, help="graph engine: epochs sampled, planned and replayed together (one "
+    ap.add_argument("--epochs-per-launch", type=int, default=0, help="(0 = four, or as many as make a group of >= 24 steps: epochs of two or three batches) graph engine: epochs sampled, planned and replayed together (one "
                     "sampler launch, one plan launch, one graph launch per group; 1 = epoch by epoch)")
     ap.add_argument("--event-every", type=int, default=3,
                     help="graph engine: bracket the select+aggregate launch of the first batch of every Nth group of epochs with HIP events")
@@ -547,7 +547,10 @@ def main():
     K = 1
     if epoch_graphs:
         slot = tr.fused._plan_bytes(B)
-        K = max(1, min(args.epochs_per_launch, (3 << 30) // max(2 * nb * slot, 1)))
+        # (default: four epochs, or as many as make a group of >= 24 steps - an Amazon-like epoch is two batches: measured 4 / 12 /
+        #  24 epochs per launch 39.7 / 38.5 / 38.1 us per step; YelpChi-like, six batches an epoch, 4 / 8: 43.4 / 42.9)
+        want = args.epochs_per_launch if args.epochs_per_launch > 0 else max(4, -(-24 // max(nb, 1)))
+        K = max(1, min(want, (3 << 30) // max(2 * nb * slot, 1)))
     G = K * nb
 
     def run_steps(n_steps, measure):
