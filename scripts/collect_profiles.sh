@@ -44,6 +44,7 @@ trace yelp --cpu-batches 0 || exit 1
 pmc pl2m powerlaw_2000000_40000000_b4096 powerlaw_2m $PL --steps 24 $NOX || exit 1
 echo "[collect] bench powerlaw 2M"; python3 $R/bench.py $PL --cpu-batches 1 > $O/bench_powerlaw_2m.log 2>&1 || exit 1
 trace pl2m $PL --steps 60 --cpu-batches 0 --report-epochs 0 --verify-batches 0 || exit 1
+pmc amazon amazon amazon --workload amazon --steps 36 $NOX || exit 1
 echo "[collect] bench amazon"; python3 $R/bench.py --workload amazon --cpu-batches 4 > $O/bench_amazon.log 2>&1 || exit 1
 for rho in 0.2 0.8; do echo "[collect] bench amazon rho $rho"; python3 $R/bench.py --workload amazon --rho $rho --cpu-batches 0 > $O/bench_amazon_rho$rho.log 2>&1 || exit 1; done
 pmc e128 yelp_b4096 e128 --emb 128 --batch-size 4096 --steps 24 $NOX || exit 1
@@ -67,6 +68,11 @@ PCG_WGRAD_OFF=1 python3 $R/bench.py $NOX > $O/x_no_wgrad_riders_timing_only_yelp
 echo "[collect] sort probe"; rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_sort -o y -- python3 $R/scripts/sort_probe.py > $O/sort_probe.log 2>&1 || exit 1
 cp $O/trace_sort/y_kernel_stats.csv $O/kernel_stats_sort_probe.csv && stamp $O/kernel_stats_sort_probe.csv; rm -rf $O/trace_sort
 echo "[collect] partitioned path, world size 1, sharded power-law 10M / 200M"; python3 $R/bench.py --force-partitioned $PL10 --steps 40 --cpu-batches 0 > $O/bench_partitioned_w1_powerlaw_10m.log 2>&1 || exit 1
+fi
+if [ "$MODE" = "amazon" ]; then       # (the Amazon-like lines on their own: PMC passes, then the three bench lines)
+pmc amazon amazon amazon --workload amazon --steps 36 $NOX || exit 1
+echo "[collect] bench amazon"; python3 $R/bench.py --workload amazon --cpu-batches 4 > $O/bench_amazon.log 2>&1 || exit 1
+for rho in 0.2 0.8; do echo "[collect] bench amazon rho $rho"; python3 $R/bench.py --workload amazon --rho $rho --cpu-batches 0 > $O/bench_amazon_rho$rho.log 2>&1 || exit 1; done
 fi
 if [ "$MODE" = "big" ]; then
 pmc pl10m powerlaw_10000000_200000000_b4096 powerlaw_10m $PL10 --steps 20 $NOX || exit 1
